@@ -1,0 +1,71 @@
+"""Oracle: the assembled iSegProbe forward (test infrastructure only).
+
+Functional restatement of iSegBaseModel.forward (reference
+core/model/iseg_base_model.py:67-89) + iSegProbeModel.backbone_forward
+(core/model/iseg_probe_model.py:110-134) on a flat weight dict whose keys are the
+reference model's state-dict keys (``backbone.model.*``, ``upsampler.*``,
+``embed_coords.proj.*``, ``head.*``).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import upsamplers as ups
+from .click_maps import click_maps
+from .vit import dinov2_features, patch_tokens
+
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+
+
+def normalize(image):
+    """BatchImageNormalize (core/model/ops.py:96-105)."""
+    m = torch.tensor(MEAN, dtype=image.dtype)[None, :, None, None]
+    s = torch.tensor(STD, dtype=image.dtype)[None, :, None, None]
+    return (image.clone() - m) / s
+
+
+def conv_head(x, w, prefix="head.", kind="convhead"):
+    """ConvSegHead / SimpleConvSegHead / SimpleClassifierHead
+    (core/model/heads/conv_heads.py:10-73).  mmcv ConvModule defaults = conv+bias -> ReLU."""
+    i = 0
+    while f"{prefix}convs.{i}.conv.weight" in w:
+        wt = w[f"{prefix}convs.{i}.conv.weight"]
+        x = F.relu(F.conv2d(x, wt, w[f"{prefix}convs.{i}.conv.bias"], padding=wt.shape[-1] // 2))
+        i += 1
+    return F.conv2d(x, w[prefix + "classifier.weight"], w[prefix + "classifier.bias"])
+
+
+def forward(image, points, w, cfg):
+    """image [B,3|4,H,W] in [0,1]; points [B,2P,3].  cfg keys: patch, depth, heads,
+    injection, upsampler ('identity'|'nearest'|'bilinear'|'bicubic'|'lift'|'loftup'|'jbu_featup'),
+    with_prev_mask, use_disks, norm_radius.  Returns logits [B,1,H,W]."""
+    with torch.no_grad():
+        image = image.float()
+        prev = None
+        if cfg.get("with_prev_mask", True):  # iseg_base_model.py:91-98
+            prev, image = image[:, 3:], image[:, :3]
+        image = normalize(image)
+        H, W = image.shape[2:]
+        maps = torch.from_numpy(click_maps(points.numpy(), H, W, cfg.get("norm_radius", 5),
+                                           1.0, cfg.get("use_disks", True)))
+        coord = torch.cat((prev, maps), dim=1) if prev is not None else maps  # :103-110
+        clicks = patch_tokens(coord, w["embed_coords.proj.weight"], w["embed_coords.proj.bias"],
+                              cfg["patch"])  # featurizers/utils/patch_embed.py:37-42
+        feats = dinov2_features(image, w, patch=cfg["patch"], depth=cfg["depth"], heads=cfg["heads"],
+                                click_tokens=clicks, injection=cfg.get("injection", "before_backbone"),
+                                prefix="backbone.model.")
+        up = cfg.get("upsampler", "bilinear")
+        if up == "lift":
+            hr = ups.lift(feats, image, w, "upsampler.lift.")
+        elif up == "loftup":
+            hr = ups.loftup(feats, image, w, "upsampler.upsampler.")
+        elif up == "jbu_featup":
+            hr = ups.jbu_stack(feats, image, w, "upsampler.upsampler.")
+        else:
+            hr = getattr(ups, up)(feats, image)
+        if up != "identity" and hr.shape[2:] != image.shape[2:]:  # iseg_probe_model.py:120-129
+            hr = F.interpolate(hr, size=image.shape[2:], mode="bilinear", align_corners=True)
+        logits = conv_head(hr, w)
+        # iseg_base_model.py:75-80 (runs even when already H x W)
+        return F.interpolate(logits, size=image.shape[2:], mode="bilinear", align_corners=True)

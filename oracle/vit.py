@@ -1,0 +1,112 @@
+"""Oracle: DINOv2 ViT featurizer with click injection (test infrastructure only).
+
+Functional torch-CPU fp32 restatement.  Weights come in as a flat dict using
+the reference's DINOv2 hub key layout (``cls_token, pos_embed, patch_embed.proj.*,
+blocks.{i}.{norm1,attn.qkv,attn.proj,ls1.gamma,norm2,mlp.fc1,mlp.fc2,ls2.gamma}.*,
+norm.*``; reference core/model/featurizers/DINOv2.py:53-180).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-6  # DINOv2.py:98  partial(nn.LayerNorm, eps=1e-6)
+
+
+def patch_tokens(x, weight, bias, patch):
+    """Conv k=p,s=p then BCHW -> B(hw)C (dinov2/layers/patch_embed.py:71-87 and
+    featurizers/utils/patch_embed.py:37-42 do the same thing)."""
+    assert x.shape[2] % patch == 0 and x.shape[3] % patch == 0  # patch_embed.py:74-79
+    y = F.conv2d(x, weight, bias, stride=patch)
+    return y.flatten(2).transpose(1, 2)
+
+
+def interpolated_pos_embed(pos_embed, n_tokens, img_rows, img_cols, patch):
+    """DINOv2.py:199-230.  ``pos_embed`` is [1, 1+M*M, D]; returns [1, n_tokens, D].
+    Bicubic resize of the M x M grid with scale_factor=((h0+0.1)/M, (w0+0.1)/M)."""
+    npatch = n_tokens - 1
+    N = pos_embed.shape[1] - 1
+    if npatch == N and img_rows == img_cols:
+        return pos_embed
+    pe = pos_embed.float()
+    cls_pe, grid_pe = pe[:, 0], pe[:, 1:]
+    dim = pe.shape[-1]
+    m = int(math.sqrt(N))
+    r0 = img_rows // patch + 0.1  # the reference names this w0 (DINOv2.py:209-213)
+    c0 = img_cols // patch + 0.1
+    grid = F.interpolate(
+        grid_pe.reshape(1, m, m, dim).permute(0, 3, 1, 2),
+        scale_factor=(r0 / math.sqrt(N), c0 / math.sqrt(N)),
+        mode="bicubic",
+    )
+    assert int(r0) == grid.shape[-2] and int(c0) == grid.shape[-1]
+    grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
+    return torch.cat((cls_pe.unsqueeze(0), grid), dim=1)
+
+
+def attention(x, w, prefix, heads):
+    """dinov2/layers/attention.py:54-71 (the non-xFormers path MemEffAttention falls
+    back to, :75-79)."""
+    B, N, C = x.shape
+    hd = C // heads
+    qkv = F.linear(x, w[prefix + "qkv.weight"], w.get(prefix + "qkv.bias"))
+    qkv = qkv.reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+    p = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+    y = (p @ v).transpose(1, 2).reshape(B, N, C)
+    return F.linear(y, w[prefix + "proj.weight"], w.get(prefix + "proj.bias"))
+
+
+def mlp(x, w, prefix):
+    """dinov2/layers/mlp.py:34-40 (exact-erf GELU, nn.GELU default)."""
+    y = F.gelu(F.linear(x, w[prefix + "fc1.weight"], w.get(prefix + "fc1.bias")))
+    return F.linear(y, w[prefix + "fc2.weight"], w.get(prefix + "fc2.bias"))
+
+
+def block(x, w, prefix, heads):
+    """dinov2/layers/block.py:92-117, eval branch: x + ls1(attn(norm1 x)); x + ls2(mlp(norm2 x))."""
+    C = x.shape[-1]
+    a = attention(
+        F.layer_norm(x, (C,), w[prefix + "norm1.weight"], w[prefix + "norm1.bias"], LN_EPS),
+        w, prefix + "attn.", heads)
+    if prefix + "ls1.gamma" in w:  # layer_scale.py:25-26
+        a = a * w[prefix + "ls1.gamma"]
+    x = x + a
+    m = mlp(
+        F.layer_norm(x, (C,), w[prefix + "norm2.weight"], w[prefix + "norm2.bias"], LN_EPS),
+        w, prefix + "mlp.")
+    if prefix + "ls2.gamma" in w:
+        m = m * w[prefix + "ls2.gamma"]
+    return x + m
+
+
+def dinov2_features(image, w, *, patch, depth, heads, click_tokens=None,
+                    injection="no_injection", prefix="", return_tokens=False):
+    """DINOv2Featurizer.forward (DINOv2.py:500-546).
+
+    image: [B,3,H,W] normalised; click_tokens: [B,h*w,D] or None.
+    Returns [B,D,h,w] (a permuted view in the reference, :545)."""
+    w = {k[len(prefix):]: v for k, v in w.items() if k.startswith(prefix)} if prefix else w
+    B, _, H, W = image.shape
+    h, wd = H // patch, W // patch
+    D = w["cls_token"].shape[-1]
+    inject = click_tokens is not None and injection != "no_injection"
+    if inject and injection not in ("before_backbone", "after_backbone"):
+        raise NameError(f"Unknown feats_injection_mode: {injection}")  # DINOv2.py:535-538
+
+    x = patch_tokens(image, w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], patch)
+    if inject and injection == "before_backbone":  # DINOv2.py:518-523
+        assert x.shape == click_tokens.shape
+        x = x + click_tokens
+    x = torch.cat((w["cls_token"].expand(B, -1, -1), x), dim=1)  # :525 / :240
+    x = x + interpolated_pos_embed(w["pos_embed"], x.shape[1], H, W, patch)  # :526-528
+    for i in range(depth):
+        x = block(x, w, f"blocks.{i}.", heads)
+    x = F.layer_norm(x, (D,), w["norm.weight"], w["norm.bias"], LN_EPS)  # :533
+    feats = x[:, 1:]
+    if inject and injection == "after_backbone":  # :509-516
+        assert feats.shape == click_tokens.shape
+        feats = feats + click_tokens
+    if return_tokens:
+        return feats
+    return feats.reshape(-1, h, wd, D).permute(0, 3, 1, 2)  # :545

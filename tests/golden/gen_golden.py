@@ -1,0 +1,470 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by importing the REFERENCE's own
+Python files from /root/reference (build container only; the reference never travels).
+
+    python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+
+What is real and what is a stand-in
+-----------------------------------
+The reference's own files are executed unmodified: core/model/ops.py (DistMaps),
+core/utils/cython/_get_dist_maps.pyx (compiled with Cython here), DINOv2.py + dinov2/layers,
+featurizers/utils/patch_embed.py, upsamplers/{basic_upsamplers,LiFT,loftup/*}.py,
+heads/conv_heads.py, iseg_base_model.py, iseg_probe_model.py, inference/{clicker,
+transforms/*, predictors/base_predictor, evaluation}.py, inference/utils.get_iou /
+compute_noc_metric.
+
+Third-party packages that are not installed here are replaced by import stand-ins so the
+files above can be imported at all.  Only three of them carry arithmetic, and those are
+flagged "parity unpinned (third-party)" in oracle/__init__.py:
+  * mmcv.cnn.ConvModule       -> Conv2d(bias) + ReLU (mmcv 1.6.2 defaults)
+  * cv2.distanceTransform     -> scipy exact EDT
+  * torchvision ToTensor      -> HWC uint8 -> CHW float/255
+Everything else (wandb, omegaconf, tensorboard, timm, ftfy, easydict, albumentations,
+hydra, pycocotools, ...) is inert plumbing that the path never executes.
+
+Pretrained weights cannot be fetched (no network), so every module is instantiated with
+seeded random weights, bypassing only the constructors that download
+(DINOv2Featurizer.__init__ -> torch.hub, LiFT/LoftUp checkpoint loaders).
+"""
+import importlib
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------- stand-ins
+class _AnyMeta(type):
+    def __getattr__(cls, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+
+class _Anything(metaclass=_AnyMeta):
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+
+class _StubModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return type(name, (_Anything,), {})
+
+
+_STUB_ROOTS = {"wandb", "omegaconf", "timm", "ftfy", "easydict", "albumentations", "hydra",
+               "pycocotools", "tensorboard", "mmcv", "cv2", "torchvision", "lvis"}
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        root = fullname.split(".")[0]
+        if root in _STUB_ROOTS or fullname == "torch.utils.tensorboard":
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _StubModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def install_standins():
+    sys.meta_path.insert(0, _StubFinder())
+    sys.path.insert(0, REF)
+
+    import mmcv.cnn  # noqa: stub
+
+    class ConvModule(nn.Module):  # mmcv 1.6.2 ConvModule defaults: conv(bias) -> ReLU, no norm
+        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+            super().__init__()
+            self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding)
+            self.activate = nn.ReLU(inplace=True)
+
+        def forward(self, x):
+            return self.activate(self.conv(x))
+
+    mmcv.cnn.ConvModule = ConvModule
+
+    import cv2  # noqa: stub
+    from scipy.ndimage import distance_transform_edt
+
+    cv2.DIST_L2 = 2
+
+    def distanceTransform(mask, dist_type, mask_size):
+        assert dist_type == 2 and mask_size == 0, "only exact EDT is stood in"
+        return distance_transform_edt(mask).astype(np.float32)
+
+    cv2.distanceTransform = distanceTransform
+
+    import torchvision.transforms as T  # noqa: stub
+
+    class ToTensor:
+        def __call__(self, img):
+            return torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255)
+
+    T.ToTensor = ToTensor
+    import torchvision
+    torchvision.transforms = T
+
+
+# --------------------------------------------------------------------------- helpers
+def seeded_(module, seed, scale=1.0):
+    """Seeded, non-degenerate weights: randomise every parameter AND BatchNorm statistics."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) * (scale / fan_in ** 0.5))
+            elif "gamma" in name or name.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+        for name, b in module.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(0.1 * torch.randn(b.shape, generator=g))
+            elif name.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+    return module
+
+
+def sd_np(module, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()
+            if "num_batches_tracked" not in k}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays)")
+
+
+def rand_points(rng, B, P, H, W, fractional=False, all_invalid_neg=False):
+    pts = -np.ones((B, 2 * P, 3), dtype=np.float32)
+    for b in range(B):
+        npos = rng.integers(1, P + 1)
+        nneg = 0 if all_invalid_neg else rng.integers(0, P + 1)
+        k = 0
+        for pol, n in ((0, npos), (1, nneg)):
+            for i in range(n):
+                r, c = rng.uniform(0, H - 1), rng.uniform(0, W - 1)
+                if not fractional:
+                    r, c = np.floor(r), np.floor(c)
+                pts[b, pol * P + i] = (r, c, k)
+                k += 1
+    return pts
+
+
+# --------------------------------------------------------------------------- fixtures
+def gen_click_maps():
+    from core.model.ops import DistMaps
+    rng = np.random.default_rng(1)
+    out = {}
+    cases = [  # name, B, P, H, W, fractional, all_invalid_neg
+        ("int_p1", 2, 1, 56, 70, False, False),
+        ("int_p3", 3, 3, 56, 70, False, False),
+        ("frac_p3", 3, 3, 56, 70, True, False),
+        ("int_p24", 2, 24, 64, 48, False, False),
+        ("noneg_p3", 2, 3, 40, 40, False, True),
+        ("frac_p24_224", 1, 24, 224, 224, True, False),
+    ]
+    for name, B, P, H, W, frac, noneg in cases:
+        pts = rand_points(rng, B, P, H, W, frac, noneg)
+        out[name + "_points"] = pts
+        out[name + "_hw"] = np.array([H, W])
+        for disks in (True, False):
+            dm = DistMaps(norm_radius=5, spatial_scale=1.0, cpu_mode=False, use_disks=disks)
+            y = dm(torch.zeros(B, 3, H, W), torch.from_numpy(pts)).numpy()
+            if disks:
+                out[name + "_disks_bits"] = np.packbits(y.astype(np.uint8))
+            else:
+                out[name + "_tanh"] = y.astype(np.float32)
+    save("click_maps", **out)
+
+
+def gen_bfs():
+    """The reference's one native component, compiled here by Cython (pyximport)."""
+    from core.utils.cython import get_dist_maps
+    rng = np.random.default_rng(2)
+    out = {}
+    cases = [("p2", 2, 30, 41), ("p5", 5, 48, 36), ("half", 3, 24, 24)]
+    for name, P, H, W in cases:
+        pts = rand_points(rng, 1, P, H, W)[0]
+        if name == "half":  # half-integer coords pin the rounding rule (pyx:31)
+            pts[0, :2] = (2.5, 3.5)
+            pts[1, :2] = (7.5, 8.5)
+            pts[P, :2] = (10.5, 0.5)
+            pts[P, 2] = 9
+        out[name + "_points"] = pts
+        out[name + "_hw"] = np.array([H, W])
+        for delim in (1.0, 5.0):
+            out[f"{name}_d{int(delim)}"] = get_dist_maps(pts.copy(), H, W, delim)
+    save("dist_maps_bfs", **out)
+
+
+TINY = dict(embed_dim=64, depth=2, num_heads=2, patch=14, img_size=70)
+
+
+def build_ref_backbone(injection, cfg=TINY, seed=11):
+    from core.model.featurizers.DINOv2 import DinoVisionTransformer, DINOv2Featurizer
+    from core.model.featurizers.dinov2.layers import MemEffAttention, NestedTensorBlock
+    from functools import partial
+    feat = DINOv2Featurizer.__new__(DINOv2Featurizer)  # skip torch.hub.load (DINOv2.py:491)
+    nn.Module.__init__(feat)
+    feat.arch = "dinov2_vits14"
+    feat.feats_injection_mode = injection
+    feat.model = DinoVisionTransformer(
+        img_size=cfg["img_size"], patch_size=cfg["patch"], embed_dim=cfg["embed_dim"],
+        depth=cfg["depth"], num_heads=cfg["num_heads"], mlp_ratio=4, init_values=1.0,
+        block_chunks=0, block_fn=partial(NestedTensorBlock, attn_class=MemEffAttention))
+    feat.patch_size = feat.model.patch_size
+    seeded_(feat, seed)
+    with torch.no_grad():
+        feat.model.pos_embed.mul_(0.3)
+    return feat.eval()
+
+
+def gen_vit():
+    rng = np.random.default_rng(3)
+    torch.manual_seed(3)
+    out = {}
+    for injection in ("before_backbone", "after_backbone", "no_injection"):
+        feat = build_ref_backbone(injection)
+        for tag, (H, W) in (("sq", (56, 56)), ("rect", (42, 70)), ("native", (70, 70))):
+            x = torch.randn(2, 3, H, W)
+            clicks = 0.5 * torch.randn(2, (H // 14) * (W // 14), TINY["embed_dim"])
+            with torch.no_grad():
+                y = feat(x, clicks)
+            out[f"{injection}_{tag}_x"] = x.numpy()
+            out[f"{injection}_{tag}_clicks"] = clicks.numpy()
+            out[f"{injection}_{tag}_y"] = y.contiguous().numpy()
+        if injection == "before_backbone":
+            for k, v in sd_np(feat.model).items():
+                out["w::" + k] = v
+            # per-stage activations of block 0 for unit tests (56x56)
+            x = torch.from_numpy(out["before_backbone_sq_x"])
+            with torch.no_grad():
+                m = feat.model
+                t = m.patch_embed(x)
+                out["stage_patch_tokens"] = t.numpy()
+                t = torch.cat((m.cls_token.expand(2, -1, -1), t), dim=1)
+                pe = m.interpolate_pos_encoding(t, 56, 56)
+                out["stage_pos_embed"] = pe.numpy()
+                t = t + pe
+                b0 = m.blocks[0]
+                out["stage_norm1"] = b0.norm1(t).numpy()
+                out["stage_attn"] = b0.attn(b0.norm1(t)).numpy()
+                out["stage_block0"] = b0(t).numpy()
+    save("vit_tiny", **out)
+
+
+def gen_upsamplers_and_head():
+    from core.model.heads import HEAD_REGISTRY
+    from core.model.upsamplers import UPSAMPLER_REGISTRY
+    from core.model.upsamplers.LiFT import LiFT, LiFTUpsampler
+    from core.model.upsamplers.loftup.layers import ChannelNorm
+    from core.model.upsamplers.loftup.loftup import LoftUp, UpsamplerwithChannelNorm
+    from core.model.upsamplers.LoftUp import LoftUpUpsampler
+    torch.manual_seed(4)
+    out = {}
+    C, h, w, H, W = 64, 4, 5, 56, 70
+    src = torch.randn(2, C, h, w)
+    gd = torch.randn(2, 3, H, W)
+    out["source"], out["guidance"] = src.numpy(), gd.numpy()
+    for name in ("identity", "nearest", "bilinear", "bicubic"):
+        with torch.no_grad():
+            out["basic_" + name] = UPSAMPLER_REGISTRY[name]()(source=src, guidance=gd).numpy()
+    # LiFT (wrapper bypasses the torch.load + .to("cuda") loader, LiFT.py:125-136)
+    lift = LiFTUpsampler.__new__(LiFTUpsampler)
+    nn.Module.__init__(lift)
+    lift.lift = seeded_(LiFT(C, 14), 21).eval()
+    with torch.no_grad():
+        out["lift_y"] = lift(src, gd).numpy()
+    for k, v in sd_np(lift).items():
+        out["lift_w::" + k] = v
+    # LoftUp (wrapper bypasses torch.load, loftup.py:152-177)
+    lu = LoftUpUpsampler.__new__(LoftUpUpsampler)
+    nn.Module.__init__(lu)
+    lu.upsampler = UpsamplerwithChannelNorm(seeded_(LoftUp(C, lr_pe_type="sine", lr_size=16), 22),
+                                            seeded_(ChannelNorm(C), 23)).eval()
+    gd_small = gd[:, :, :28, :42].contiguous()
+    out["loftup_guidance"] = gd_small.numpy()
+    with torch.no_grad():
+        out["loftup_y"] = lu(src[:, :, :2, :3].contiguous(), gd_small).numpy()
+    for k, v in sd_np(lu).items():
+        out["loftup_w::" + k] = v
+    # heads
+    x = torch.randn(2, C, 20, 24)
+    out["head_x"] = x.numpy()
+    for kind, kw in (("convhead", dict(in_channels=C, num_layers=2, num_classes=1)),
+                     ("simple_conv", dict(in_channels=C, num_layers=2, num_classes=1)),
+                     ("linear", dict(in_channels=C, num_classes=1))):
+        head = seeded_(HEAD_REGISTRY[kind](**kw), 31).eval()
+        with torch.no_grad():
+            out[f"head_{kind}_y"] = head(x).numpy()
+        for k, v in sd_np(head).items():
+            out[f"head_{kind}_w::" + k] = v
+    save("upsamplers_head", **out)
+
+
+class _Builder:
+    """Duck-typed stand-in for ModelBuilder that hands iSegProbeModel prebuilt reference
+    modules (the real builder's constructors download weights)."""
+
+    def __init__(self, backbone, upsampler, head):
+        self.b, self.u, self.h = backbone, upsampler, head
+
+    def load_featurizer(self, *a, **k):
+        return self.b
+
+    def load_upsampler(self, *a, **k):
+        return self.u
+
+    def load_head(self, *a, **k):
+        return self.h
+
+
+def build_ref_model(upsampler_type, injection="before_backbone", seed=40):
+    from core.model.heads import ConvSegHead
+    from core.model.iseg_probe_model import iSegProbeModel
+    from core.model.upsamplers import UPSAMPLER_REGISTRY
+    from core.model.upsamplers.LiFT import LiFT, LiFTUpsampler
+    from core.model.upsamplers.loftup.layers import ChannelNorm
+    from core.model.upsamplers.loftup.loftup import LoftUp, UpsamplerwithChannelNorm
+    from core.model.upsamplers.LoftUp import LoftUpUpsampler
+    C = TINY["embed_dim"]
+    backbone = build_ref_backbone(injection, seed=seed)
+    if upsampler_type == "lift":
+        up = LiFTUpsampler.__new__(LiFTUpsampler)
+        nn.Module.__init__(up)
+        up.lift = seeded_(LiFT(C, 14), seed + 1)
+    elif upsampler_type == "loftup":
+        up = LoftUpUpsampler.__new__(LoftUpUpsampler)
+        nn.Module.__init__(up)
+        up.upsampler = UpsamplerwithChannelNorm(seeded_(LoftUp(C, lr_pe_type="sine"), seed + 2),
+                                                seeded_(ChannelNorm(C), seed + 3))
+    else:
+        up = UPSAMPLER_REGISTRY[upsampler_type]()
+    head = seeded_(ConvSegHead(C, 2, 1), seed + 4)
+    model = iSegProbeModel(
+        backbone_cfg={"type": "dinov2", "params": {}},
+        head_cfg={"type": "convhead", "params": {}},
+        embed_coords_cfg={"type": "patchEmbed", "params": {"img_size": (56, 56), "patch_size": (14, 14),
+                                                             "embed_dim": C}},
+        upsampler_cfg={"type": upsampler_type, "params": None},
+        model_builder=_Builder(backbone, up, head),
+        use_disks=True, norm_radius=5, with_prev_mask=True)
+    seeded_(model.embed_coords, seed + 5)
+    return model.eval()
+
+
+def gen_model():
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    out = {}
+    H = W = 56
+    img = torch.rand(2, 4, H, W)
+    img[:, 3] = (img[:, 3] > 0.7).float()
+    pts = torch.from_numpy(rand_points(rng, 2, 3, H, W))
+    out["image"], out["points"] = img.numpy(), pts.numpy()
+    for up in ("bilinear", "identity", "lift", "loftup"):
+        model = build_ref_model(up)
+        with torch.no_grad():
+            y = model(img, pts)["instances"]
+        out[f"{up}_logits"] = y.numpy()
+        for k, v in sd_np(model).items():
+            out[f"{up}_w::" + k] = v
+    model = build_ref_model("bilinear", injection="after_backbone")
+    with torch.no_grad():
+        out["bilinear_after_logits"] = model(img, pts)["instances"].numpy()
+    for k, v in sd_np(model).items():
+        out["bilinear_after_w::" + k] = v
+    save("model_tiny", **out)
+
+
+def gen_inference():
+    """BasePredictor fusion (flip + zoom-in + sigmoid), robot clicker, IoU, NoC."""
+    from core.inference.clicker import Clicker
+    from core.inference.evaluation import evaluate_sample
+    from core.inference.predictors import get_predictor
+    from core.inference.utils import compute_noc_metric, get_iou
+    rng = np.random.default_rng(6)
+    out = {}
+    model = build_ref_model("bilinear", seed=60)
+    for k, v in sd_np(model).items():
+        out["w::" + k] = v
+    H0, W0 = 90, 120
+    yy, xx = np.mgrid[:H0, :W0]
+    gt = (((yy - 45) / 28.0) ** 2 + ((xx - 70) / 36.0) ** 2 <= 1).astype(np.int32)
+    gt[40:50, 20:30] = -1  # ignore region
+    image = (rng.uniform(0, 1, (H0, W0, 3)) * 60 + gt[..., None].clip(0) * 120).astype(np.uint8)
+    out["image_u8"], out["gt"] = image, gt
+    for tag, zoom in (("nozoom", None),
+                      ("zoom", {"skip_clicks": -1, "target_size": (56, 56)})):
+        predictor = get_predictor(model, "NoBRS", torch.device("cpu"), prob_thresh=0.5,
+                                  zoom_in_params=zoom)
+        if zoom is None:
+            # without zoom the net must see a multiple of 14: crop the image
+            img_c, gt_c = image[:84, :112], gt[:84, :112]
+        else:
+            img_c, gt_c = image, gt
+        clicks, ious, probs = evaluate_sample(img_c, gt_c, predictor, max_iou_thr=1.01,
+                                              pred_thr=0.5, max_clicks=6)
+        out[f"{tag}_clicks"] = np.array([(c.coords[0], c.coords[1], int(c.is_positive)) for c in clicks],
+                                        dtype=np.int64)
+        out[f"{tag}_ious"] = ious
+        out[f"{tag}_probs"] = probs.astype(np.float32)
+    # clicker known answers
+    pred = np.zeros_like(gt, dtype=bool)
+    ck = Clicker(gt_mask=gt)
+    seq = []
+    for _ in range(4):
+        ck.make_next_click(pred)
+        c = ck.get_clicks()[-1]
+        seq.append((c.coords[0], c.coords[1], int(c.is_positive)))
+        pred = pred.copy()
+        pred[max(0, c.coords[0] - 12):c.coords[0] + 12, max(0, c.coords[1] - 30):c.coords[1] + 9] = c.is_positive
+    out["clicker_seq"] = np.array(seq, dtype=np.int64)
+    out["clicker_final_pred"] = pred
+    out["iou_value"] = np.array(get_iou(gt, pred))
+    all_ious = [np.array([0.3, 0.85, 0.91, 0.95]), np.array([0.5, 0.6]), np.array([0.92])]
+    noc, noc_std, over = compute_noc_metric(all_ious, [0.8, 0.85, 0.9], max_clicks=20)
+    out["noc"] = np.array(noc)
+    out["noc_std"] = np.array(noc_std)
+    out["noc_over"] = np.array(over)
+    save("inference", **out)
+
+
+def main():
+    torch.set_num_threads(4)
+    install_standins()
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "upsamplers", "model", "inference"]
+    fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit,
+           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference}
+    for w in which:
+        fns[w]()
+
+
+if __name__ == "__main__":
+    main()
