@@ -1,0 +1,122 @@
+/* isegprobe_hip.h -- C ABI of libisegprobe_hip.so: the MI355X (gfx950) kernels behind the
+ * iSegProbe per-click dense-feature path (click maps -> ViT featurizer -> upsampler -> conv
+ * seg head -> click-map fusion).
+ *
+ * Conventions (every entry point):
+ *   - plain C types only: device pointers, sizes, a hipStream_t passed as void*;
+ *   - stateless: never allocates, never synchronises, no globals; the caller owns every
+ *     buffer (including workspaces) and the stream; safe from any host thread;
+ *   - returns ISP_OK (0) or a negative ISP_ERR_* code; nothing is launched on error;
+ *   - "bf16" buffers hold raw bfloat16 bits (uint16); activations are NHWC / token-major;
+ *   - dense weights use the nn.Linear / flattened Conv2d layout Wt[N][K], bf16.
+ *
+ * The reference (havrylovv/iSegProbe) has exactly one native entry point,
+ *   get_dist_maps(points f32[2P,3], H, W, norm_delimeter) -> f32[2,H,W]
+ *   (core/utils/cython/_get_dist_maps.pyx:18-21, called from core/model/ops.py:21-34);
+ * isp_click_maps_fwd(..., round_clicks=1) is its drop-in.  Every other function replaces a
+ * torch op sequence of the reference's Python path; the file:line each one replaces is
+ * cited on its declaration.  INTEGRATION.md shows the ctypes binding for each.
+ */
+#ifndef ISEGPROBE_HIP_H
+#define ISEGPROBE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISP_OK 0
+#define ISP_ERR_INVALID (-1)     /* bad pointer / dimension / alignment */
+#define ISP_ERR_UNSUPPORTED (-2) /* valid request this build has no kernel for */
+#define ISP_ERR_LAUNCH (-3)      /* HIP refused the launch */
+
+#define ISP_F32 0
+#define ISP_BF16 1
+
+/* ABI version; bumped on any signature change. */
+int isp_abi_version(void);
+
+/* ---- click maps: DistMaps.get_coord_features, core/model/ops.py:35-77 (torch path, exact
+ * fp32 op order, fractional clicks kept) and, with round_clicks=1, get_dist_maps
+ * (_get_dist_maps.pyx:18-64: clicks rounded half-to-even, row<0 = empty).
+ * points [B,2P,3] f32 (row, col, order; first P rows positive), out [B,2,H,W] f32. */
+int isp_click_maps_fwd(const float* points, float* out, int B, int P, int H, int W, float norm_radius,
+                       float spatial_scale, int use_disks, int round_clicks, void* stream);
+
+/* ---- BatchImageNormalize + prev-mask split: ops.py:96-105, iseg_base_model.py:91-98.
+ * image [B,in_ch(3|4),H,W] f32 -> out [B,3,H,W] f32, prev_mask [B,1,H,W] f32 (may be NULL).
+ * mean3/std3 are HOST pointers to 3 floats. */
+int isp_normalize_fwd(const float* image, float* out, float* prev_mask, int B, int in_ch, int H, int W,
+                      const float* mean3, const float* std3, void* stream);
+
+/* ---- patch matrix for the fused image+click patch-embed GEMM: the im2col side of
+ * dinov2/layers/patch_embed.py:71-87 and featurizers/utils/patch_embed.py:37-42 joined as in
+ * DINOv2.py:518-523.  A [B*h*w, Kpad] bf16, row = [img(3,p,p) | prev(n_prev,p,p) |
+ * maps(n_maps,p,p) | 0...]. */
+int isp_patchify_fwd(const float* image, const float* prev_mask, const float* click_maps, void* A_bf16, int B, int H,
+                     int W, int patch, int n_prev, int n_maps, int Kpad, void* stream);
+
+/* ---- fused GEMM epilogues */
+#define ISP_EP_BIAS_BF16 0      /* out bf16 = v + bias                                   */
+#define ISP_EP_BIAS_RELU_BF16 1 /* out bf16 = relu(v + bias)        ConvModule, conv_heads.py:59 */
+#define ISP_EP_BIAS_GELU_BF16 2 /* out bf16 = gelu_erf(v + bias)    Mlp, mlp.py:34-40     */
+#define ISP_EP_BIAS_F32 3       /* out f32  = v + bias                                   */
+#define ISP_EP_RESIDUAL_F32 4   /* out f32 += gamma * (v + bias)    LayerScale + residual, block.py:92-117 */
+#define ISP_EP_TOKENS_F32 5     /* out f32 [b*(T+1)+1+t] = v + bias + pos[1+t]   DINOv2.py:523-528 */
+
+typedef struct isp_epilogue {
+    int kind;             /* ISP_EP_* */
+    void* out;            /* bf16 or f32 per kind */
+    long ldo;             /* row stride of out in elements (0 = N) */
+    const float* bias;    /* [N] or NULL */
+    const float* gamma;   /* [N] LayerScale or NULL (RESIDUAL) */
+    const float* pos;     /* [(T+1), ldo] interpolated pos-embed or NULL (TOKENS) */
+    int tokens_per_image; /* T (TOKENS) */
+} isp_epilogue;
+
+/* ---- C = A . Wt^T with a fused epilogue.  A [M, lda>=K] bf16, Wt [N,K] bf16, K % 64 == 0,
+ * N % 4 == 0.  Replaces nn.Linear in attention.py:54-71, mlp.py:34-40, the patch-embed convs
+ * (as GEMMs) and every 1x1 conv on the path. */
+int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* ep, void* stream);
+
+/* ---- 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on NHWC bf16.
+ * in [B,H,W,C] (C % 64 == 0), Wt [N][9*C] with K index = ((ky*3+kx)*C + c), i.e.
+ * conv.weight.permute(0,2,3,1).  Replaces ConvModule/Conv2d 3x3 in heads/conv_heads.py:51-73,
+ * loftup/loftup.py:53-63 and LiFT.py:12-27. */
+int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int H, int W, int C, int N, const isp_epilogue* ep,
+                          void* stream);
+
+/* ---- LayerNorm over the last dim (fp32 statistics), nn.LayerNorm(eps) of DINOv2.py:98 and
+ * loftup/layers.py.  group_out>0 drops `skip` leading rows of every (group_out+skip)-row
+ * group of the input (cls-token drop, DINOv2.py:533-534). */
+int isp_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, long rows, int D, float eps,
+                      int in_dtype, int out_dtype, int group_out, int skip, void* stream);
+
+/* ---- softmax(Q K^T * scale) V, head_dim 64, bf16 in/out, fp32 online softmax; never
+ * materialises the score matrix.  Element strides are explicit so the packed qkv tensor of
+ * attention.py:56-60 is consumed in place.  Q [B,Lq,H,64], K/V [B,Lk,H,64], O [B,Lq,H,64]. */
+int isp_attention_fwd(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
+                      long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
+                      long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
+
+/* ---- F.interpolate(mode="bilinear", align_corners=True): basic_upsamplers.py:28-33,
+ * iseg_probe_model.py:120-129 (NHWC bf16 feature maps) and iseg_base_model.py:75-80,
+ * base_predictor.py:95-97, zoom_in.py:113-118,240-247 (NCHW f32 planes). */
+int isp_resize_bilinear_ac_nhwc_bf16(const void* in, void* out, int B, int h, int w, int H, int W, int C, void* stream);
+int isp_resize_bilinear_ac_nchw_f32(const float* in, float* out, long planes, int h, int w, int H, int W,
+                                    long in_plane_stride, void* stream);
+
+/* ---- BaseClassifierHead.classifier (1x1 conv C->1), heads/base_head.py:15.
+ * x [M,C] NHWC bf16, weight [C] f32 -> out [M] f32. */
+int isp_classifier_fwd(const void* x_nhwc_bf16, const float* weight, float bias, float* out, long M, int C,
+                       void* stream);
+
+/* ---- layout converters between the plugin API (NCHW f32) and the kernels (NHWC bf16).
+ * The f32 source is addressed in[b*sb + c*sc + p*sp] so permuted views need no copy. */
+int isp_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int C, long HW, void* stream);
+int isp_nchw_f32_to_nhwc_bf16(const float* in, void* out, int B, int C, long HW, long stride_b, long stride_c,
+                              long stride_p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISEGPROBE_HIP_H */

@@ -1,0 +1,81 @@
+"""ctypes loader for libisegprobe_hip.so (the C-ABI declared in include/isegprobe_hip.h).
+
+There is no fallback: if the library is missing the product path raises.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C isegprobe_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libisegprobe_hip.so")
+
+ABI_VERSION = 1
+
+ISP_F32, ISP_BF16 = 0, 1
+EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32 = range(6)
+
+_ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed"}
+
+
+class IspError(RuntimeError):
+    pass
+
+
+class Epilogue(ctypes.Structure):
+    _fields_ = [
+        ("kind", ctypes.c_int),
+        ("out", ctypes.c_void_p),
+        ("ldo", ctypes.c_long),
+        ("bias", ctypes.c_void_p),
+        ("gamma", ctypes.c_void_p),
+        ("pos", ctypes.c_void_p),
+        ("tokens_per_image", ctypes.c_int),
+    ]
+
+
+_vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_EP = ctypes.POINTER(Epilogue)
+
+# name -> argtypes; must list every symbol include/isegprobe_hip.h declares
+SIGNATURES = {
+    "isp_abi_version": [],
+    "isp_click_maps_fwd": [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp],
+    "isp_normalize_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.POINTER(_f), ctypes.POINTER(_f), _vp],
+    "isp_patchify_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "isp_gemm_bf16": [_vp, _l, _vp, _l, _i, _i, _EP, _vp],
+    "isp_conv3x3_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _EP, _vp],
+    "isp_layernorm_fwd": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _vp],
+    "isp_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
+    "isp_resize_bilinear_ac_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "isp_resize_bilinear_ac_nchw_f32": [_vp, _vp, _l, _i, _i, _i, _i, _l, _vp],
+    "isp_classifier_fwd": [_vp, _vp, _f, _vp, _l, _i, _vp],
+    "isp_nhwc_bf16_to_nchw_f32": [_vp, _vp, _i, _i, _l, _vp],
+    "isp_nchw_f32_to_nhwc_bf16": [_vp, _vp, _i, _i, _l, _l, _l, _l, _vp],
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IspError(
+                f"{LIB_PATH} is missing: the HIP extension is not built and there is no CPU fallback. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'`."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        if handle.isp_abi_version() != ABI_VERSION:
+            raise IspError(f"ABI mismatch: library {handle.isp_abi_version()} != binding {ABI_VERSION}")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise IspError(f"{what} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,57 @@
+// Shared device/host helpers for the iSegProbe gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/isegprobe_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define ISP_LDS __attribute__((address_space(3)))
+#define ISP_GLOBAL __attribute__((address_space(1)))
+
+#define ISP_CHECK_ARG(cond) \
+    do {                    \
+        if (!(cond)) return ISP_ERR_INVALID; \
+    } while (0)
+
+static inline int isp_launch_status() {
+    return hipGetLastError() == hipSuccess ? ISP_OK : ISP_ERR_LAUNCH;
+}
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// f32 -> bf16, round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
+// and keeps NaNs NaN (MI355X_MICROARCH "Correctness boundaries").
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// 16-byte async global -> LDS copy.  LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const ISP_GLOBAL void*)gsrc, (ISP_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+// Bijective XCD-aware block remap (blocks b and b+8 share an XCD under round-robin
+// dispatch): gives each XCD a contiguous chunk of the tile grid so neighbouring tiles
+// share that XCD's L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (orig >> 3);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// 16 zero bytes for out-of-image taps of the implicit-GEMM convs (LDS-DMA cannot
+// predicate a lane, so out-of-range lanes read here instead).
+static __device__ const uint4 g_isp_zero16[4] = {};

@@ -1,0 +1,282 @@
+// Row-wise HBM-bound kernels on the token / pixel axis: LayerNorm (fp32 stats), the
+// bilinear(align_corners=True) NHWC resize, the C->1 classifier, layout converters.
+#include "isp_common.h"
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm over the last dim.  One wave per row; the row lives in registers (two-pass
+// mean / variance exactly like torch: var = mean((x-mean)^2)), output bf16 or fp32.
+// Row remap: out row r reads input row  r + (r / group_out) * skip + skip_first  where
+// skip_first rows are dropped at the start of each group of group_in = group_out + skip
+// rows (used to drop the cls token: DINOv2.py:533-534).
+template <typename TIN, typename TOUT, int MAXV>  // MAXV: float4 chunks per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ x, TOUT* __restrict__ y,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, long rows, int D, float eps,
+                                                         int group_out, int skip) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long rin = group_out > 0 ? r + (r / group_out + 1) * skip : r;
+    const TIN* xr = x + rin * D;
+    const int nchunk = D >> 2;
+    float4 v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            if constexpr (sizeof(TIN) == 4) {
+                v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
+            } else {
+                const uint2 u = *reinterpret_cast<const uint2*>(xr + c * 4);
+                v[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                   __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+            }
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)D + eps);
+    TOUT* yr = y + r * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c * 4);
+            const float4 b = *reinterpret_cast<const float4*>(beta + c * 4);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x;
+            o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z;
+            o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            if constexpr (sizeof(TOUT) == 4) {
+                *reinterpret_cast<float4*>(yr + c * 4) = o;
+            } else {
+                *reinterpret_cast<uint2*>(yr + c * 4) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+            }
+        }
+    }
+}
+
+template <typename TIN, typename TOUT>
+static int launch_ln(const void* x, void* y, const float* g, const float* b, long rows, int D, float eps, int group_out,
+                     int skip, hipStream_t s) {
+    const int nchunk = D / 4;
+    dim3 grid((unsigned)((rows + 3) / 4));
+#define LN_CASE(MV)                                                                                                  \
+    layernorm_kernel<TIN, TOUT, MV><<<grid, 256, 0, s>>>((const TIN*)x, (TOUT*)y, g, b, rows, D, eps, group_out, skip)
+    if (nchunk <= 64) LN_CASE(1);
+    else if (nchunk <= 128) LN_CASE(2);
+    else if (nchunk <= 256) LN_CASE(4);
+    else if (nchunk <= 512) LN_CASE(8);
+    else return ISP_ERR_UNSUPPORTED;
+#undef LN_CASE
+    return isp_launch_status();
+}
+
+extern "C" int isp_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, long rows, int D,
+                                 float eps, int in_dtype, int out_dtype, int group_out, int skip, void* stream) {
+    ISP_CHECK_ARG(x && y && gamma && beta && rows > 0 && D > 0 && D % 4 == 0 && group_out >= 0 && skip >= 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_dtype == ISP_F32 && out_dtype == ISP_BF16) return launch_ln<float, bf16_t>(x, y, gamma, beta, rows, D, eps, group_out, skip, s);
+    if (in_dtype == ISP_F32 && out_dtype == ISP_F32) return launch_ln<float, float>(x, y, gamma, beta, rows, D, eps, group_out, skip, s);
+    if (in_dtype == ISP_BF16 && out_dtype == ISP_BF16) return launch_ln<bf16_t, bf16_t>(x, y, gamma, beta, rows, D, eps, group_out, skip, s);
+    if (in_dtype == ISP_BF16 && out_dtype == ISP_F32) return launch_ln<bf16_t, float>(x, y, gamma, beta, rows, D, eps, group_out, skip, s);
+    return ISP_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------
+// Bilinear resize, align_corners=True, NHWC bf16 -> NHWC bf16 (F.interpolate semantics of
+// basic_upsamplers.py:28-33 / iseg_probe_model.py:120-129).  A thread owns 8 channels of
+// one output pixel: 4 x 16-B loads, one 16-B store.  src = dst * (in-1)/(out-1) in fp32.
+__global__ __launch_bounds__(256) void bilinear_nhwc_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                             int h, int w, int H, int W, int C, float sy, float sx,
+                                                             long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C >> 3;
+    const int c8 = (int)(idx % cv);
+    long pix = idx / cv;
+    const int X = (int)(pix % W);
+    pix /= W;
+    const int Y = (int)(pix % H);
+    const int b = (int)(pix / H);
+    const float fy = sy * (float)Y, fx = sx * (float)X;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    const bf16_t* base = in + (size_t)b * h * w * C + c8 * 8;
+    const uint4 a = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * w + x0) * C);
+    const uint4 bq = *reinterpret_cast<const uint4*>(base + ((size_t)y0 * w + x1) * C);
+    const uint4 c = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * w + x0) * C);
+    const uint4 d = *reinterpret_cast<const uint4*>(base + ((size_t)y1 * w + x1) * C);
+    const unsigned* ua = &a.x;
+    const unsigned* ub = &bq.x;
+    const unsigned* uc = &c.x;
+    const unsigned* ud = &d.x;
+    unsigned r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = w00 * __uint_as_float(ua[i] << 16) + w01 * __uint_as_float(ub[i] << 16) +
+                         w10 * __uint_as_float(uc[i] << 16) + w11 * __uint_as_float(ud[i] << 16);
+        const float hi = w00 * __uint_as_float(ua[i] & 0xffff0000u) + w01 * __uint_as_float(ub[i] & 0xffff0000u) +
+                         w10 * __uint_as_float(uc[i] & 0xffff0000u) + w11 * __uint_as_float(ud[i] & 0xffff0000u);
+        r[i] = pack2bf(lo, hi);
+    }
+    *reinterpret_cast<uint4*>(out + idx * 8) = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+extern "C" int isp_resize_bilinear_ac_nhwc_bf16(const void* in, void* out, int B, int h, int w, int H, int W, int C,
+                                                void* stream) {
+    ISP_CHECK_ARG(in && out && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const long total = (long)B * H * W * (C / 8);
+    bilinear_nhwc_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)in, (bf16_t*)out, h, w, H, W, C, sy, sx, total);
+    return isp_launch_status();
+}
+
+// Same resize on fp32 NCHW single/multi-channel maps (logits, probabilities, ROI crops):
+// iseg_base_model.py:75-80, base_predictor.py:95-97, zoom_in.py:113-118,240-247.
+__global__ __launch_bounds__(256) void bilinear_nchw_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 int h, int w, int H, int W, float sy, float sx,
+                                                                 long in_plane_stride, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int X = (int)(idx % W);
+    const long t = idx / W;
+    const int Y = (int)(t % H);
+    const long plane = t / H;
+    const float fy = sy * (float)Y, fx = sx * (float)X;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* p = in + plane * in_plane_stride;
+    // torch's upsample_bilinear2d accumulation order: h0*(w0*a + w1*b) + h1*(w0*c + w1*d)
+    const float top = (1.f - lx) * p[(size_t)y0 * w + x0] + lx * p[(size_t)y0 * w + x1];
+    const float bot = (1.f - lx) * p[(size_t)y1 * w + x0] + lx * p[(size_t)y1 * w + x1];
+    out[idx] = (1.f - ly) * top + ly * bot;
+}
+
+extern "C" int isp_resize_bilinear_ac_nchw_f32(const float* in, float* out, long planes, int h, int w, int H, int W,
+                                               long in_plane_stride, void* stream) {
+    ISP_CHECK_ARG(in && out && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0 && in_plane_stride >= (long)h * w);
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const long total = planes * H * W;
+    bilinear_nchw_f32_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        in, out, h, w, H, W, sy, sx, in_plane_stride, total);
+    return isp_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// 1x1 classifier C -> 1 (BaseClassifierHead.classifier, heads/base_head.py:15): one dot
+// product per pixel over an NHWC bf16 map, fp32 out.  16 lanes per pixel, 16-B loads.
+__global__ __launch_bounds__(256) void classifier_kernel(const bf16_t* __restrict__ x, const float* __restrict__ wt,
+                                                          float bias, float* __restrict__ out, long M, int C) {
+    const int sub = threadIdx.x & 15;
+    const long pix = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    float acc = 0.f;
+    if (pix < M) {
+        const bf16_t* xr = x + pix * C;
+        for (int c = sub * 8; c < C; c += 128) {
+            const uint4 u = *reinterpret_cast<const uint4*>(xr + c);
+            const float4 w0 = *reinterpret_cast<const float4*>(wt + c);
+            const float4 w1 = *reinterpret_cast<const float4*>(wt + c + 4);
+            acc += __uint_as_float(u.x << 16) * w0.x + __uint_as_float(u.x & 0xffff0000u) * w0.y +
+                   __uint_as_float(u.y << 16) * w0.z + __uint_as_float(u.y & 0xffff0000u) * w0.w +
+                   __uint_as_float(u.z << 16) * w1.x + __uint_as_float(u.z & 0xffff0000u) * w1.y +
+                   __uint_as_float(u.w << 16) * w1.z + __uint_as_float(u.w & 0xffff0000u) * w1.w;
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (pix < M && sub == 0) out[pix] = acc + bias;
+}
+
+extern "C" int isp_classifier_fwd(const void* x_nhwc_bf16, const float* weight, float bias, float* out, long M, int C,
+                                  void* stream) {
+    ISP_CHECK_ARG(x_nhwc_bf16 && weight && out && M > 0 && C > 0 && C % 8 == 0);
+    const long threads = M * 16;
+    classifier_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)x_nhwc_bf16, weight, bias, out, M, C);
+    return isp_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// Layout converters between the plugin API's NCHW fp32 tensors and the kernels' NHWC bf16.
+__global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const bf16_t* __restrict__ in,
+                                                                     float* __restrict__ out, int C, long HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const long p = p0 + i;
+        const int c = c0 + tx;
+        tile[i][tx] = (p < HW && c < C) ? bf2f(in[((size_t)b * HW + p) * C + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i;
+        const long p = p0 + tx;
+        if (p < HW && c < C) out[((size_t)b * C + c) * HW + p] = tile[tx][i];
+    }
+}
+
+extern "C" int isp_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int C, long HW, void* stream) {
+    ISP_CHECK_ARG(in && out && B > 0 && C > 0 && HW > 0 && B <= 65535);
+    dim3 grid((unsigned)((HW + 31) / 32), (C + 31) / 32, B);
+    nhwc_bf16_to_nchw_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)in, out, C, HW);
+    return isp_launch_status();
+}
+
+__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ in,
+                                                                     bf16_t* __restrict__ out, int C, long HW,
+                                                                     long sb, long sc, long sp) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i;
+        const long p = p0 + tx;
+        tile[i][tx] = (p < HW && c < C) ? in[(size_t)b * sb + (size_t)c * sc + (size_t)p * sp] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const long p = p0 + i;
+        const int c = c0 + tx;
+        if (p < HW && c < C) out[((size_t)b * HW + p) * C + c] = f2bf(tile[tx][i]);
+    }
+}
+
+// in is addressed as in[b*sb + c*sc + p*sp] (element strides) so permuted NCHW views
+// (the featurizer's [B,D,h,w] view of [B,h*w,D], DINOv2.py:545) need no copy first.
+extern "C" int isp_nchw_f32_to_nhwc_bf16(const float* in, void* out, int B, int C, long HW, long stride_b,
+                                         long stride_c, long stride_p, void* stream) {
+    ISP_CHECK_ARG(in && out && B > 0 && C > 0 && HW > 0 && B <= 65535);
+    dim3 grid((unsigned)((HW + 31) / 32), (C + 31) / 32, B);
+    nchw_f32_to_nhwc_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, (bf16_t*)out, C, HW, stride_b, stride_c,
+                                                                        stride_p);
+    return isp_launch_status();
+}

@@ -1,0 +1,233 @@
+"""Thin torch-tensor wrappers over the C-ABI (include/isegprobe_hip.h).
+
+torch is used here only for device memory and the current stream; every arithmetic op on
+the path is a HIP kernel in libisegprobe_hip.so.  All functions raise ``IspError`` on a
+non-zero return code and require CUDA(HIP) tensors -- there is no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import Epilogue, IspError, check
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need(t, dtype, name, contiguous=True):
+    if not t.is_cuda:
+        raise IspError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise IspError(f"{name}: expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise IspError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def click_maps(points, H, W, norm_radius, spatial_scale=1.0, use_disks=False, round_clicks=False, out=None):
+    """points [B,2P,3] f32 -> [B,2,H,W] f32 (reference core/model/ops.py:35-77)."""
+    points = _need(points.float().contiguous(), torch.float32, "points")
+    B, P2, three = points.shape
+    if three != 3 or P2 % 2:
+        raise IspError("points must be [B, 2P, 3]")
+    if out is None:
+        out = torch.empty(B, 2, H, W, device=points.device, dtype=torch.float32)
+    check(_lib.lib().isp_click_maps_fwd(_p(points), _p(out), B, P2 // 2, H, W, float(norm_radius),
+                                        float(spatial_scale), int(use_disks), int(round_clicks), _stream()),
+          "isp_click_maps_fwd")
+    return out
+
+
+def normalize(image, mean, std, want_prev=True):
+    """image [B,3|4,H,W] f32 -> (normalised [B,3,H,W], prev_mask [B,1,H,W] or None)."""
+    image = _need(image, torch.float32, "image")
+    B, C, H, W = image.shape
+    out = torch.empty(B, 3, H, W, device=image.device, dtype=torch.float32)
+    prev = torch.empty(B, 1, H, W, device=image.device, dtype=torch.float32) if (C == 4 and want_prev) else None
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    check(_lib.lib().isp_normalize_fwd(_p(image), _p(out), _p(prev), B, C, H, W, m, s, _stream()), "isp_normalize_fwd")
+    return out, prev
+
+
+def patchify(image, prev, maps, patch, Kpad):
+    image = _need(image, torch.float32, "image")
+    B, _, H, W = image.shape
+    n_prev = 0 if prev is None else prev.shape[1]
+    n_maps = 0 if maps is None else maps.shape[1]
+    if prev is not None:
+        _need(prev, torch.float32, "prev")
+    if maps is not None:
+        _need(maps, torch.float32, "maps")
+    A = torch.empty(B * (H // patch) * (W // patch), Kpad, device=image.device, dtype=BF16)
+    check(_lib.lib().isp_patchify_fwd(_p(image), _p(prev), _p(maps), _p(A), B, H, W, patch, n_prev, n_maps, Kpad,
+                                      _stream()), "isp_patchify_fwd")
+    return A
+
+
+def _epilogue(kind, out, ldo=0, bias=None, gamma=None, pos=None, tokens=0):
+    ep = Epilogue()
+    ep.kind = kind
+    ep.out = out.data_ptr()
+    ep.ldo = ldo
+    ep.bias = bias.data_ptr() if bias is not None else None
+    ep.gamma = gamma.data_ptr() if gamma is not None else None
+    ep.pos = pos.data_ptr() if pos is not None else None
+    ep.tokens_per_image = tokens
+    return ep
+
+
+def gemm(A, Wt, ep, M=None):
+    """A [M,K] bf16 (row stride A.stride(0)), Wt [N,K] bf16, ep from _epilogue."""
+    _need(A, BF16, "A", contiguous=False)
+    _need(Wt, BF16, "Wt")
+    if A.stride(1) != 1:
+        raise IspError("A must be row-major")
+    N, K = Wt.shape
+    M = A.shape[0] if M is None else M
+    check(_lib.lib().isp_gemm_bf16(_p(A), A.stride(0), _p(Wt), M, N, K, ctypes.byref(ep), _stream()), "isp_gemm_bf16")
+
+
+def linear(A, Wt, bias=None, act=None, out_dtype=BF16):
+    """bf16 A [M,K] x Wt[N,K]^T + bias, optional 'relu'/'gelu'; returns [M,N]."""
+    N = Wt.shape[0]
+    out = torch.empty(A.shape[0], N, device=A.device, dtype=out_dtype)
+    if out_dtype == BF16:
+        kind = {None: _lib.EP_BIAS_BF16, "relu": _lib.EP_BIAS_RELU_BF16, "gelu": _lib.EP_BIAS_GELU_BF16}[act]
+    else:
+        if act is not None:
+            raise IspError("fp32 output supports no activation")
+        kind = _lib.EP_BIAS_F32
+    gemm(A, Wt, _epilogue(kind, out, N, bias))
+    return out
+
+
+def linear_residual_(x, A, Wt, bias=None, gamma=None):
+    """x (f32 [M,N]) += gamma * (A Wt^T + bias), in place."""
+    _need(x, torch.float32, "x")
+    gemm(A, Wt, _epilogue(_lib.EP_RESIDUAL_F32, x, x.shape[-1], bias, gamma))
+    return x
+
+
+def conv3x3(x, Wt, bias=None, act="relu", out_dtype=BF16):
+    """x [B,H,W,C] bf16 NHWC, Wt [N, 9*C] bf16 (ky,kx,c order) -> [B,H,W,N]."""
+    _need(x, BF16, "x")
+    _need(Wt, BF16, "Wt")
+    B, H, W, C = x.shape
+    N = Wt.shape[0]
+    if Wt.shape[1] != 9 * C:
+        raise IspError("conv3x3 weight must be [N, 9*C]")
+    out = torch.empty(B, H, W, N, device=x.device, dtype=out_dtype)
+    if out_dtype == BF16:
+        kind = {None: _lib.EP_BIAS_BF16, "relu": _lib.EP_BIAS_RELU_BF16, "gelu": _lib.EP_BIAS_GELU_BF16}[act]
+    else:
+        kind = _lib.EP_BIAS_F32
+    ep = _epilogue(kind, out, N, bias)
+    check(_lib.lib().isp_conv3x3_nhwc_bf16(_p(x), _p(Wt), B, H, W, C, N, ctypes.byref(ep), _stream()),
+          "isp_conv3x3_nhwc_bf16")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out_dtype=BF16, group_out=0, skip=0, rows_out=None):
+    """LayerNorm over the last dim of a [rows, D] f32/bf16 tensor."""
+    if x.dtype not in (torch.float32, BF16):
+        raise IspError("layernorm input must be f32 or bf16")
+    _need(x, x.dtype, "x")
+    D = x.shape[-1]
+    rows = x.numel() // D if rows_out is None else rows_out
+    out = torch.empty(rows, D, device=x.device, dtype=out_dtype)
+    check(_lib.lib().isp_layernorm_fwd(_p(x), _p(out), _p(gamma), _p(beta), rows, D, float(eps),
+                                       _lib.ISP_F32 if x.dtype == torch.float32 else _lib.ISP_BF16,
+                                       _lib.ISP_F32 if out_dtype == torch.float32 else _lib.ISP_BF16,
+                                       group_out, skip, _stream()), "isp_layernorm_fwd")
+    return out
+
+
+def attention_packed_qkv(qkv, B, L, heads, scale):
+    """qkv [B*L, 3*heads*64] bf16 laid out (3, heads, 64) per token (attention.py:56-60)."""
+    _need(qkv, BF16, "qkv")
+    D = heads * 64
+    out = torch.empty(B * L, D, device=qkv.device, dtype=BF16)
+    base = qkv.data_ptr()
+    q, k, v = (ctypes.c_void_p(base + i * D * 2) for i in range(3))
+    check(_lib.lib().isp_attention_fwd(q, k, v, _p(out), B, heads, L, L,
+                                       L * 3 * D, 3 * D, 64, L * 3 * D, 3 * D, 64, L * D, D, 64,
+                                       float(scale), _stream()), "isp_attention_fwd")
+    return out
+
+
+def attention(q, k, v, scale):
+    """q [B,Lq,H,64], k/v [B,Lk,H,64] bf16 (any strides with unit last-dim stride)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _need(t, BF16, n, contiguous=False)
+        if t.stride(3) != 1 or t.shape[3] != 64:
+            raise IspError(f"{n}: head_dim must be 64 with unit stride")
+    if k.stride() != v.stride():
+        raise IspError("k and v must share strides")
+    B, Lq, H, _ = q.shape
+    Lk = k.shape[1]
+    out = torch.empty(B, Lq, H, 64, device=q.device, dtype=BF16)
+    check(_lib.lib().isp_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, Lq, Lk,
+                                       q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                                       out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()),
+          "isp_attention_fwd")
+    return out
+
+
+def resize_bilinear_nhwc(x, H, W):
+    _need(x, BF16, "x")
+    B, h, w, C = x.shape
+    out = torch.empty(B, H, W, C, device=x.device, dtype=BF16)
+    check(_lib.lib().isp_resize_bilinear_ac_nhwc_bf16(_p(x), _p(out), B, h, w, H, W, C, _stream()),
+          "isp_resize_bilinear_ac_nhwc_bf16")
+    return out
+
+
+def resize_bilinear_nchw_f32(x, H, W):
+    """x [..., h, w] f32 whose last two dims are contiguous; leading dims must be collapsible."""
+    _need(x, torch.float32, "x")
+    h, w = x.shape[-2:]
+    planes = x.numel() // (h * w)
+    out = torch.empty(*x.shape[:-2], H, W, device=x.device, dtype=torch.float32)
+    check(_lib.lib().isp_resize_bilinear_ac_nchw_f32(_p(x), _p(out), planes, h, w, H, W, h * w, _stream()),
+          "isp_resize_bilinear_ac_nchw_f32")
+    return out
+
+
+def classifier(x, weight, bias):
+    """x [..., C] bf16 NHWC, weight [C] f32, bias python float -> [...] f32."""
+    _need(x, BF16, "x")
+    _need(weight, torch.float32, "weight")
+    C = x.shape[-1]
+    M = x.numel() // C
+    out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.float32)
+    check(_lib.lib().isp_classifier_fwd(_p(x), _p(weight), float(bias), _p(out), M, C, _stream()), "isp_classifier_fwd")
+    return out
+
+
+def nhwc_bf16_to_nchw_f32(x):
+    _need(x, BF16, "x")
+    B, H, W, C = x.shape
+    out = torch.empty(B, C, H, W, device=x.device, dtype=torch.float32)
+    check(_lib.lib().isp_nhwc_bf16_to_nchw_f32(_p(x), _p(out), B, C, H * W, _stream()), "isp_nhwc_bf16_to_nchw_f32")
+    return out
+
+
+def nchw_f32_to_nhwc_bf16(x):
+    """x [B,C,H,W] f32 view with collapsible (H,W); returns NHWC bf16."""
+    _need(x, torch.float32, "x", contiguous=False)
+    B, C, H, W = x.shape
+    if W > 1 and x.stride(2) != x.stride(3) * W:
+        x = x.contiguous()
+    out = torch.empty(B, H, W, C, device=x.device, dtype=BF16)
+    check(_lib.lib().isp_nchw_f32_to_nhwc_bf16(_p(x), _p(out), B, C, H * W, x.stride(0), x.stride(1), x.stride(3),
+                                               _stream()), "isp_nchw_f32_to_nhwc_bf16")
+    return out

@@ -1,0 +1,195 @@
+"""GPU: each HIP kernel (through the C-ABI) against a torch fp32 reference of the same op."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from isegprobe_amd import hip_ops
+    assert torch.cuda.is_available()
+    return hip_ops
+
+
+def bf(x):
+    return x.to(BF)
+
+
+def rel_err(a, b):
+    return (a.float() - b.float()).abs().max().item() / (b.float().abs().max().item() + 1e-12)
+
+
+def test_library_loads(ops):
+    from isegprobe_amd import _lib
+    assert _lib.lib().isp_abi_version() == _lib.ABI_VERSION
+
+
+@pytest.mark.parametrize("disks", [True, False])
+@pytest.mark.parametrize("shape", [(2, 3, 56, 70), (2, 24, 224, 224), (1, 5, 30, 41)])
+def test_click_maps_vs_oracle(ops, disks, shape):
+    from oracle.click_maps import click_maps
+    B, P, H, W = shape
+    rng = np.random.default_rng(0)
+    pts = -np.ones((B, 2 * P, 3), np.float32)
+    for b in range(B):
+        for pol in range(2):
+            n = rng.integers(0 if pol else 1, P + 1)
+            for i in range(n):
+                pts[b, pol * P + i] = (rng.uniform(0, H - 1), rng.uniform(0, W - 1), i)
+    pts[0, :1, :2] = np.floor(pts[0, :1, :2])
+    ref = click_maps(pts, H, W, 5, 1.0, disks)
+    out = ops.click_maps(torch.from_numpy(pts).cuda(), H, W, 5, 1.0, disks).cpu().numpy()
+    if disks:
+        assert np.array_equal(out, ref)  # bit-exact
+    else:
+        np.testing.assert_allclose(out, ref, atol=1e-6, rtol=0)
+
+
+def test_normalize(ops):
+    x = torch.rand(2, 4, 28, 40, device="cuda")
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    y, prev = ops.normalize(x, mean, std)
+    ref = (x[:, :3].cpu() - torch.tensor(mean)[None, :, None, None]) / torch.tensor(std)[None, :, None, None]
+    assert torch.equal(y.cpu(), ref)
+    assert torch.equal(prev, x[:, 3:])
+
+
+@pytest.mark.parametrize("D", [64, 384, 404, 1024])
+def test_layernorm(ops, D):
+    x = torch.randn(1000, D, device="cuda") * 3 + 1
+    g, b = torch.randn(D, device="cuda"), torch.randn(D, device="cuda")
+    y = ops.layernorm(x, g, b, 1e-6, out_dtype=torch.float32)
+    ref = F.layer_norm(x, (D,), g, b, 1e-6)
+    assert (y - ref).abs().max().item() < 2e-5
+    y16 = ops.layernorm(x, g, b, 1e-6)
+    assert rel_err(y16, ref) < 1e-2
+    # cls-drop remap
+    T = 9
+    xs = torch.randn(4 * (T + 1), D, device="cuda")
+    yd = ops.layernorm(xs, g, b, 1e-6, out_dtype=torch.float32, group_out=T, skip=1, rows_out=4 * T)
+    refd = F.layer_norm(xs.view(4, T + 1, D)[:, 1:], (D,), g, b, 1e-6).reshape(-1, D)
+    assert (yd - refd).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 192, 128), (1000, 384, 384), (4100, 1152, 384),
+                                   (257, 64, 1216), (129, 132, 64)])
+@pytest.mark.parametrize("act", [None, "relu", "gelu"])
+def test_gemm_bias_act(ops, M, N, K, act):
+    torch.manual_seed(M + N + K)
+    A, W = bf(torch.randn(M, K, device="cuda")), bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    bias = torch.randn(N, device="cuda")
+    y = ops.linear(A, W, bias, act)
+    ref = A.float() @ W.float().t() + bias
+    ref = {None: lambda t: t, "relu": F.relu, "gelu": F.gelu}[act](ref)
+    assert rel_err(y, ref) < 1e-2
+    if act is None:
+        y32 = ops.linear(A, W, bias, None, out_dtype=torch.float32)
+        assert (y32 - ref).abs().max().item() < 2e-3
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I against an asymmetric W catches transposed / permuted fragment layouts."""
+    K = N = 128
+    A = bf(torch.eye(K, device="cuda"))
+    W = bf((torch.arange(N * K, device="cuda").float().reshape(N, K) % 251) / 16)
+    y = ops.linear(A, W, None, None, out_dtype=torch.float32)
+    assert torch.equal(y, W.float().t())
+
+
+def test_gemm_residual_and_tokens(ops):
+    from isegprobe_amd import _lib
+    M, N, K = 515, 384, 1536
+    A, W = bf(torch.randn(M, K, device="cuda")), bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+    bias, gamma = torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
+    x0 = torch.randn(M, N, device="cuda")
+    x = x0.clone()
+    ops.linear_residual_(x, A, W, bias, gamma)
+    ref = x0 + gamma * (A.float() @ W.float().t() + bias)
+    assert (x - ref).abs().max().item() < 5e-3
+    # token scatter: B=3 images, T=5 tokens each -> rows b*(T+1)+1+t
+    Bn, T = 3, 5
+    A2 = bf(torch.randn(Bn * T, 64, device="cuda"))
+    W2 = bf(torch.randn(N, 64, device="cuda") / 8)
+    pos = torch.randn(T + 1, N, device="cuda")
+    xt = torch.zeros(Bn * (T + 1), N, device="cuda")
+    ops.gemm(A2, W2, ops._epilogue(_lib.EP_TOKENS_F32, xt, N, bias, None, pos, T))
+    ref2 = (A2.float() @ W2.float().t() + bias).view(Bn, T, N) + pos[1:]
+    assert (xt.view(Bn, T + 1, N)[:, 1:] - ref2).abs().max().item() < 5e-3
+    assert xt.view(Bn, T + 1, N)[:, 0].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(1, 8, 8, 64, 64), (2, 20, 24, 64, 64), (1, 37, 45, 128, 192),
+                                       (2, 56, 56, 384, 384)])
+def test_conv3x3(ops, B, H, W, C, N):
+    torch.manual_seed(C + H)
+    x = bf(torch.randn(B, C, H, W, device="cuda"))
+    w = bf(torch.randn(N, C, 3, 3, device="cuda") / math.sqrt(9 * C))
+    bias = torch.randn(N, device="cuda")
+    ref = F.relu(F.conv2d(x.float(), w.float(), bias, padding=1))
+    y = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), bias, "relu")
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-2
+
+
+@pytest.mark.parametrize("B,L,heads", [(1, 64, 1), (2, 257, 2), (2, 1025, 6), (1, 130, 3)])
+def test_attention_packed(ops, B, L, heads):
+    torch.manual_seed(L)
+    D = heads * 64
+    qkv = bf(torch.randn(B * L, 3 * D, device="cuda"))
+    out = ops.attention_packed_qkv(qkv, B, L, heads, 64 ** -0.5)
+    q, k, v = qkv.float().view(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    p = ((q * 64 ** -0.5) @ k.transpose(-2, -1)).softmax(-1)
+    ref = (p @ v).transpose(1, 2).reshape(B * L, D)
+    assert (out.float() - ref).abs().max().item() < 2e-2
+    assert rel_err(out, ref) < 2e-2
+
+
+def test_attention_online_softmax_rescale(ops):
+    """A key whose score dwarfs the rest in a LATE tile forces the running-max rescale."""
+    B, L, heads = 1, 256, 1
+    q = torch.randn(B, L, heads, 64, device="cuda") * 0.1
+    k = torch.randn(B, L, heads, 64, device="cuda") * 0.1
+    v = torch.randn(B, L, heads, 64, device="cuda")
+    k[0, 200] = q[0, 17] * 400  # spike for query 17 in the 4th KV tile
+    out = ops.attention(bf(q), bf(k), bf(v), 1.0)
+    qf, kf, vf = bf(q).float(), bf(k).float(), bf(v).float()
+    p = (qf.permute(0, 2, 1, 3) @ kf.permute(0, 2, 3, 1)).softmax(-1)
+    ref = (p @ vf.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+    assert (out.float() - ref).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 5, 56, 70, 64), (1, 32, 32, 448, 448, 384)])
+def test_bilinear_nhwc(ops, shape):
+    B, h, w, H, W, C = shape
+    x = bf(torch.randn(B, C, h, w, device="cuda"))
+    y = ops.resize_bilinear_nhwc(x.permute(0, 2, 3, 1).contiguous(), H, W)
+    ref = F.interpolate(x.float(), (H, W), mode="bilinear", align_corners=True)
+    assert (y.permute(0, 3, 1, 2).float() - ref).abs().max().item() < 2e-2
+
+
+def test_bilinear_nchw_f32_and_identity(ops):
+    x = torch.randn(3, 1, 37, 53, device="cuda")
+    y = ops.resize_bilinear_nchw_f32(x, 90, 120)
+    ref = F.interpolate(x, (90, 120), mode="bilinear", align_corners=True)
+    assert (y - ref).abs().max().item() < 1e-5
+    assert torch.equal(ops.resize_bilinear_nchw_f32(x, 37, 53), x)  # same-size resize is exact
+
+
+def test_classifier_and_layout(ops):
+    x = bf(torch.randn(2, 20, 24, 384, device="cuda"))
+    w = torch.randn(384, device="cuda")
+    y = ops.classifier(x, w, 0.3)
+    ref = (x.float() * w).sum(-1) + 0.3
+    assert (y - ref).abs().max().item() < 1e-3
+    n = ops.nhwc_bf16_to_nchw_f32(x)
+    assert torch.equal(n, x.float().permute(0, 3, 1, 2))
+    f = torch.randn(2, 9, 384, device="cuda")  # token-major view as [B,C,h,w]
+    view = f.reshape(2, 3, 3, 384).permute(0, 3, 1, 2)
+    back = ops.nchw_f32_to_nhwc_bf16(view)
+    assert torch.equal(back, f.reshape(2, 3, 3, 384).to(BF))
