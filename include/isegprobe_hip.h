@@ -50,10 +50,10 @@ int isp_normalize_fwd(const float* image, float* out, float* prev_mask, int B, i
 
 /* ---- patch matrix for the fused image+click patch-embed GEMM: the im2col side of
  * dinov2/layers/patch_embed.py:71-87 and featurizers/utils/patch_embed.py:37-42 joined as in
- * DINOv2.py:518-523.  A [B*h*w, Kpad] bf16, row = [img(3,p,p) | prev(n_prev,p,p) |
+ * DINOv2.py:518-523.  A [B*h*w, Kpad] bf16, row = [img(n_img,p,p) | prev(n_prev,p,p) |
  * maps(n_maps,p,p) | 0...]. */
 int isp_patchify_fwd(const float* image, const float* prev_mask, const float* click_maps, void* A_bf16, int B, int H,
-                     int W, int patch, int n_prev, int n_maps, int Kpad, void* stream);
+                     int W, int patch, int n_img, int n_prev, int n_maps, int Kpad, void* stream);
 
 /* ---- fused GEMM epilogues */
 #define ISP_EP_BIAS_BF16 0      /* out bf16 = v + bias                                   */
@@ -104,6 +104,17 @@ int isp_attention_fwd(const void* Q, const void* K, const void* V, void* O, int 
 int isp_resize_bilinear_ac_nhwc_bf16(const void* in, void* out, int B, int h, int w, int H, int W, int C, void* stream);
 int isp_resize_bilinear_ac_nchw_f32(const float* in, float* out, long planes, int h, int w, int H, int W,
                                     long in_plane_stride, void* stream);
+
+/* ---- F.interpolate nearest / bicubic (align_corners=False) on NHWC bf16:
+ * basic_upsamplers.py:18-25,36-42; mode ISP_RESIZE_BILINEAR_AC forwards to the call above. */
+#define ISP_RESIZE_NEAREST 0
+#define ISP_RESIZE_BILINEAR_AC 1
+#define ISP_RESIZE_BICUBIC 2
+int isp_resize_nhwc_bf16(const void* in, void* out, int B, int h, int w, int H, int W, int C, int mode, void* stream);
+
+/* ---- click-token injection x[b,(cls)+t,:] += add[b,t,:]: DINOv2.py:516,523. */
+int isp_token_add_fwd(void* x, int x_dtype, const void* add, int add_dtype, long B, int T, int D, int x_has_cls,
+                      void* stream);
 
 /* ---- BaseClassifierHead.classifier (1x1 conv C->1), heads/base_head.py:15.
  * x [M,C] NHWC bf16, weight [C] f32 -> out [M] f32. */

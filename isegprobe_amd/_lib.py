@@ -41,13 +41,15 @@ SIGNATURES = {
     "isp_abi_version": [],
     "isp_click_maps_fwd": [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp],
     "isp_normalize_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, ctypes.POINTER(_f), ctypes.POINTER(_f), _vp],
-    "isp_patchify_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "isp_patchify_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "isp_gemm_bf16": [_vp, _l, _vp, _l, _i, _i, _EP, _vp],
     "isp_conv3x3_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _EP, _vp],
     "isp_layernorm_fwd": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _vp],
     "isp_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
     "isp_resize_bilinear_ac_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_resize_bilinear_ac_nchw_f32": [_vp, _vp, _l, _i, _i, _i, _i, _l, _vp],
+    "isp_resize_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "isp_token_add_fwd": [_vp, _i, _vp, _i, _l, _i, _i, _i, _vp],
     "isp_classifier_fwd": [_vp, _vp, _f, _vp, _l, _i, _vp],
     "isp_nhwc_bf16_to_nchw_f32": [_vp, _vp, _i, _i, _l, _vp],
     "isp_nchw_f32_to_nhwc_bf16": [_vp, _vp, _i, _i, _l, _l, _l, _l, _vp],

@@ -1,0 +1,271 @@
+"""DINOv2 featurizer with click injection (reference core/model/featurizers/DINOv2.py).
+
+``DinoVisionTransformer`` here is a parameter container with the DINOv2 hub state-dict
+layout (``cls_token, pos_embed, mask_token, patch_embed.proj.*, blocks.{i}.{norm1, attn.qkv,
+attn.proj, ls1.gamma, norm2, mlp.fc1, mlp.fc2, ls2.gamma}.*, norm.*``; DINOv2.py:53-180);
+the forward pass is a sequence of HIP launches: patchify -> fused patch-embed GEMM (+bias
++pos-embed) -> per block [LayerNorm, QKV GEMM, fused attention, proj GEMM (+LayerScale
++residual), LayerNorm, fc1 GEMM (+GELU), fc2 GEMM (+LayerScale +residual)] -> final
+LayerNorm that also drops the cls token.  Residual stream fp32, GEMM operands bf16,
+accumulation / LayerNorm / softmax statistics fp32.
+
+The reference fetches weights with torch.hub (DINOv2.py:491); there is no network here, so
+weights come from ``weights=`` (a state dict or a path to one in the hub key layout) or from
+``$ISEGPROBE_DINOV2_WEIGHTS``; otherwise the model keeps its (timm-style) random init.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.init import trunc_normal_
+
+from .... import hip_ops as ops
+from ...._lib import IspError
+from ...utils.log import logger
+from .._tensor import BF16, PackedCache, nchw_view
+
+ARCHS = {  # DINOv2.py:413-449 (vit_giant2 uses SwiGLU: not built)
+    "dinov2_vits14": dict(embed_dim=384, depth=12, num_heads=6),
+    "dinov2_vitb14": dict(embed_dim=768, depth=12, num_heads=12),
+    "dinov2_vitl14": dict(embed_dim=1024, depth=24, num_heads=16),
+}
+LN_EPS = 1e-6  # DINOv2.py:98
+
+
+def _pad64(k):
+    return (k + 63) // 64 * 64
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim, bias=True)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _Gamma(nn.Module):
+    def __init__(self, dim, init):
+        super().__init__()
+        self.gamma = nn.Parameter(init * torch.ones(dim))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, mlp_ratio, init_values):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=LN_EPS)
+        self.attn = _Attn(dim)
+        self.ls1 = _Gamma(dim, init_values) if init_values else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim, eps=LN_EPS)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.ls2 = _Gamma(dim, init_values) if init_values else nn.Identity()
+
+
+class _PatchProj(nn.Module):
+    def __init__(self, patch, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, kernel_size=patch, stride=patch)
+
+
+class DinoVisionTransformer(nn.Module):
+    """Parameter container with the hub key layout; see module docstring."""
+
+    def __init__(self, img_size=518, patch_size=14, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4.0,
+                 init_values=1.0):
+        super().__init__()
+        if embed_dim % num_heads or embed_dim // num_heads != 64:
+            raise NotImplementedError("the fused attention kernel is built for head_dim 64")
+        self.embed_dim = self.num_features = embed_dim
+        self.n_blocks = depth
+        self.num_heads = num_heads
+        self.patch_size = patch_size
+        grid = img_size // patch_size
+        self.patch_embed = _PatchProj(patch_size, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, grid * grid + 1, embed_dim))
+        self.blocks = nn.ModuleList([_Block(embed_dim, mlp_ratio, init_values) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=LN_EPS)
+        self.mask_token = nn.Parameter(torch.zeros(1, embed_dim))
+        trunc_normal_(self.pos_embed, std=0.02)  # DINOv2.py:194-197
+        nn.init.normal_(self.cls_token, std=1e-6)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+
+class DINOv2Featurizer(nn.Module):
+    """Adapter with the reference's constructor and forward contract (DINOv2.py:468-546):
+    ``forward(x, additional_features=None) -> [B, D, h, w]`` (an NCHW-shaped view of NHWC bf16
+    storage), attributes ``patch_size`` and ``feats_injection_mode``.  Unlike the reference
+    (which hard-limits to ``dinov2_vits14``) the S/B/L archs and a ``vit_kwargs`` override for
+    test-sized models are accepted."""
+
+    def __init__(self, arch: str = "dinov2_vits14", feats_injection_mode: str = "no_injection",
+                 weights=None, vit_kwargs=None) -> None:
+        super().__init__()
+        self.arch = arch
+        self.feats_injection_mode = feats_injection_mode
+        if vit_kwargs is None:
+            if arch not in ARCHS:
+                raise NotImplementedError(f"Only {sorted(ARCHS)} are supported, got {arch}")
+            vit_kwargs = ARCHS[arch]
+        self.model = DinoVisionTransformer(**vit_kwargs)
+        self.patch_size = self.model.patch_size
+        weights = weights or os.environ.get("ISEGPROBE_DINOV2_WEIGHTS")
+        if weights is not None:
+            sd = torch.load(weights, map_location="cpu") if isinstance(weights, (str, os.PathLike)) else weights
+            self.model.load_state_dict(sd)
+            logger.info(f"Loaded checkpoint for DINOv2: {arch}")
+        else:
+            logger.info(f"DINOv2 {arch}: no weights given, keeping random init (no network for torch.hub)")
+        logger.info(f"Feats Injection Mode: {feats_injection_mode}")
+        self._packed = PackedCache()
+        self._pos_cache = {}
+
+    # ------------------------------------------------------------------ weight packing
+    def _params(self):
+        return list(self.model.parameters())
+
+    def packed(self):
+        def build():
+            m = self.model
+            f32 = lambda t: t.detach().float().contiguous()
+            b16 = lambda t: t.detach().to(BF16).contiguous()
+            blocks = []
+            for blk in m.blocks:
+                blocks.append(dict(
+                    n1w=f32(blk.norm1.weight), n1b=f32(blk.norm1.bias),
+                    qkv_w=b16(blk.attn.qkv.weight), qkv_b=f32(blk.attn.qkv.bias),
+                    proj_w=b16(blk.attn.proj.weight), proj_b=f32(blk.attn.proj.bias),
+                    ls1=f32(blk.ls1.gamma) if isinstance(blk.ls1, _Gamma) else None,
+                    n2w=f32(blk.norm2.weight), n2b=f32(blk.norm2.bias),
+                    fc1_w=b16(blk.mlp.fc1.weight), fc1_b=f32(blk.mlp.fc1.bias),
+                    fc2_w=b16(blk.mlp.fc2.weight), fc2_b=f32(blk.mlp.fc2.bias),
+                    ls2=f32(blk.ls2.gamma) if isinstance(blk.ls2, _Gamma) else None))
+            self._pos_cache.clear()
+            return dict(blocks=blocks, nw=f32(m.norm.weight), nb=f32(m.norm.bias),
+                        patch_w=m.patch_embed.proj.weight.detach().flatten(1).float(),
+                        patch_b=f32(m.patch_embed.proj.bias))
+        return self._packed.get(self._params(), build)
+
+    def _pos_embed(self, H, W):
+        """Interpolated pos-embed for an H x W input, computed once per resolution with the
+        reference's own recipe (bicubic, scale_factor=((h+0.1)/M, (w+0.1)/M); DINOv2.py:199-230)
+        -- a weight transform, cached: returns ([T+1, D] f32 table, cls row = cls_token+pos[0])."""
+        key = (H, W)
+        if key not in self._pos_cache:
+            with torch.no_grad():
+                m = self.model
+                pe = m.pos_embed.detach().float()
+                N = pe.shape[1] - 1
+                h, w = H // self.patch_size, W // self.patch_size
+                if not (h * w == N and H == W):
+                    M = int(math.sqrt(N))
+                    grid = F.interpolate(pe[:, 1:].reshape(1, M, M, -1).permute(0, 3, 1, 2),
+                                         scale_factor=((h + 0.1) / math.sqrt(N), (w + 0.1) / math.sqrt(N)),
+                                         mode="bicubic")
+                    assert grid.shape[-2:] == (h, w)
+                    pe = torch.cat((pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, h * w, -1)), dim=1)
+                table = pe[0].contiguous()
+                cls_row = (m.cls_token.detach().float()[0, 0] + table[0]).contiguous()
+                self._pos_cache[key] = (table, cls_row)
+        return self._pos_cache[key]
+
+    # ------------------------------------------------------------------ forward
+    def _embed(self, A, Wcat, bias, B, H, W):
+        """Patch-matrix GEMM straight into the fp32 residual stream (token rows 1..T of each
+        image, + bias + pos-embed) and the cls rows."""
+        D = self.model.embed_dim
+        T = (H // self.patch_size) * (W // self.patch_size)
+        table, cls_row = self._pos_embed(H, W)
+        x = torch.empty(B * (T + 1), D, device=A.device, dtype=torch.float32)
+        ops.gemm(A, Wcat, ops._epilogue(ops._lib.EP_TOKENS_F32, x, D, bias, None, table, T))
+        x.view(B, T + 1, D)[:, 0].copy_(cls_row)  # cls_token + pos[0] (DINOv2.py:525-528)
+        return x, T
+
+    def _blocks(self, x, B, T):
+        P = self.packed()
+        heads = self.model.num_heads
+        L = T + 1
+        for blk in P["blocks"]:
+            hbuf = ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS)
+            qkv = ops.linear(hbuf, blk["qkv_w"], blk["qkv_b"])
+            att = ops.attention_packed_qkv(qkv, B, L, heads, 64 ** -0.5)
+            ops.linear_residual_(x, att, blk["proj_w"], blk["proj_b"], blk["ls1"])
+            hbuf = ops.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS)
+            hid = ops.linear(hbuf, blk["fc1_w"], blk["fc1_b"], "gelu")
+            ops.linear_residual_(x, hid, blk["fc2_w"], blk["fc2_b"], blk["ls2"])
+        # final norm + cls drop -> [B*T, D] bf16 == NHWC [B,h,w,D]
+        return ops.layernorm(x, P["nw"], P["nb"], LN_EPS, group_out=T, skip=1, rows_out=B * T)
+
+    def _image_weights(self):
+        P = self.packed()
+        if "img_w" not in P:
+            K = P["patch_w"].shape[1]
+            w = torch.zeros(P["patch_w"].shape[0], _pad64(K), device=P["patch_w"].device, dtype=BF16)
+            w[:, :K] = P["patch_w"].to(BF16)
+            P["img_w"] = w
+        return P["img_w"], P["patch_b"]
+
+    def forward(self, x, additional_features=None):
+        b, nc, H, W = x.shape
+        p = self.patch_size
+        if H % p or W % p:
+            raise AssertionError(f"Input image size {H}x{W} is not a multiple of patch size {p}")
+        h, w = H // p, W // p
+        mode = self.feats_injection_mode
+        inject = additional_features is not None and mode != "no_injection"
+        if inject and mode not in ("before_backbone", "after_backbone"):
+            raise NameError(f"Unknown feats_injection_mode: {mode}")
+        x = x.float().contiguous()
+        Wimg, bimg = self._image_weights()
+        A = ops.patchify(x, None, None, p, Wimg.shape[1])
+        xs, T = self._embed(A, Wimg, bimg, b, H, W)
+        D = self.model.embed_dim
+        if inject:
+            if tuple(additional_features.shape) != (b, T, D):
+                raise AssertionError(f"x.shape: {(b, T, D)}, additional_features.shape: {tuple(additional_features.shape)}")
+            if mode == "before_backbone":  # DINOv2.py:518-523
+                ops.token_add_(xs, additional_features, b, T, has_cls=True)
+        feats = self._blocks(xs, b, T)
+        if inject and mode == "after_backbone":  # DINOv2.py:509-516
+            ops.token_add_(feats, additional_features, b, T, has_cls=False)
+        return nchw_view(feats.view(b, h, w, D))  # DINOv2.py:545
+
+    def forward_fused_clicks(self, image, prev_mask, click_maps, embed_coords):
+        """before_backbone fast path: image patches and click-map patches are embedded by ONE
+        GEMM over the concatenated K axis ([W_img | W_click], bias summed) -- numerically
+        patch_embed(image) + embed_coords(coord) (DINOv2.py:518-523) without the token
+        round trip.  ``embed_coords`` is the model's PatchEmbed."""
+        b, _, H, W = image.shape
+        p = self.patch_size
+        if H % p or W % p:
+            raise AssertionError(f"Input image size {H}x{W} is not a multiple of patch size {p}")
+        P = self.packed()
+        cw, cb = embed_coords.proj.weight, embed_coords.proj.bias
+        key = (cw.data_ptr(), cw._version, cb.data_ptr(), cb._version)
+        if P.get("fused_key") != key:
+            with torch.no_grad():
+                wi = P["patch_w"]
+                wc = cw.detach().flatten(1).float()
+                K = wi.shape[1] + wc.shape[1]
+                wcat = torch.zeros(wi.shape[0], _pad64(K), device=wi.device, dtype=BF16)
+                wcat[:, :wi.shape[1]] = wi.to(BF16)
+                wcat[:, wi.shape[1]:K] = wc.to(BF16)
+                P["fused_w"], P["fused_b"], P["fused_key"] = wcat, (P["patch_b"] + cb.detach().float()).contiguous(), key
+        n_prev = 0 if prev_mask is None else prev_mask.shape[1]
+        if embed_coords.in_chans != n_prev + click_maps.shape[1]:
+            raise IspError("embed_coords.in_chans does not match prev-mask + click-map channels")
+        A = ops.patchify(image, prev_mask, click_maps, p, P["fused_w"].shape[1])
+        xs, T = self._embed(A, P["fused_w"], P["fused_b"], b, H, W)
+        feats = self._blocks(xs, b, T)
+        return nchw_view(feats.view(b, H // p, W // p, self.model.embed_dim))

@@ -1,0 +1,33 @@
+"""Base class for segmentation heads (reference core/model/heads/base_head.py:8-18)."""
+from abc import abstractmethod
+
+import torch
+import torch.nn as nn
+
+from .... import hip_ops as ops
+from ...._lib import IspError
+from .._tensor import BF16, PackedCache
+
+
+class BaseClassifierHead(nn.Module):
+    def __init__(self, in_channels: int, num_classes: int) -> None:
+        super().__init__()
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.classifier = nn.Conv2d(in_channels, num_classes, kernel_size=1)  # parameter holder
+        self._cls_packed = PackedCache()
+
+    def _classify(self, x_nhwc):
+        """1x1 conv C -> num_classes on an NHWC bf16 map -> [B, num_classes, H, W] f32."""
+        if self.num_classes != 1:
+            raise IspError("only num_classes == 1 (binary interactive segmentation) is built")
+        w, b = self._cls_packed.get(
+            (self.classifier.weight, self.classifier.bias),
+            lambda: (self.classifier.weight.detach().float().reshape(-1).contiguous(),
+                     float(self.classifier.bias.detach().float().item())))
+        B, H, W, _ = x_nhwc.shape
+        return ops.classifier(x_nhwc, w, b).view(B, 1, H, W)
+
+    @abstractmethod
+    def forward(self, x):
+        pass

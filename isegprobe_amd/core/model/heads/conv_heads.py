@@ -1,0 +1,73 @@
+"""Convolutional segmentation heads (reference core/model/heads/conv_heads.py:10-73).
+
+The reference builds its layers from mmcv's ``ConvModule`` (conv + bias -> ReLU with mmcv
+1.6.2 defaults); ``ConvModule`` below is an mmcv-free parameter container with the same
+state-dict keys (``convs.{i}.conv.{weight,bias}``).  3x3 layers run as bf16 implicit-GEMM
+convolutions with bias+ReLU fused, 1x1 layers as GEMMs; the final C->1 classifier is a
+per-pixel dot product."""
+import torch
+import torch.nn as nn
+
+from .... import hip_ops as ops
+from .._tensor import BF16, PackedCache, to_nhwc_bf16
+from .base_head import BaseClassifierHead
+
+
+class ConvModule(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding)
+        self.activate = nn.ReLU(inplace=True)
+        self._packed = PackedCache()
+
+    def packed(self):
+        def build():
+            w = self.conv.weight.detach()
+            n = w.shape[0]
+            # [N, C, kh, kw] -> [N, kh*kw*C] (tap-major, channel-minor: the implicit-GEMM K order)
+            return (w.permute(0, 2, 3, 1).reshape(n, -1).to(BF16).contiguous(),
+                    self.conv.bias.detach().float().contiguous())
+        return self._packed.get((self.conv.weight, self.conv.bias), build)
+
+    def run(self, x_nhwc):
+        w, b = self.packed()
+        if self.conv.kernel_size == (3, 3):
+            return ops.conv3x3(x_nhwc, w, b, "relu")
+        B, H, W, C = x_nhwc.shape
+        return ops.linear(x_nhwc.view(-1, C), w, b, "relu").view(B, H, W, -1)
+
+
+class SimpleClassifierHead(BaseClassifierHead):
+    """Single 1x1 conv layer."""
+
+    def __init__(self, in_channels: int, num_classes: int) -> None:
+        super().__init__(in_channels, num_classes)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._classify(to_nhwc_bf16(x))
+
+
+class _StackedHead(BaseClassifierHead):
+    kernel_size, padding = 1, 0
+
+    def __init__(self, in_channels: int, num_layers: int, num_classes: int) -> None:
+        super().__init__(in_channels, num_classes)
+        self.num_layers = num_layers
+        self.convs = nn.Sequential(*[
+            ConvModule(in_channels, in_channels, kernel_size=self.kernel_size, stride=1, padding=self.padding)
+            for _ in range(num_layers)])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = to_nhwc_bf16(x)
+        for layer in self.convs:
+            y = layer.run(y)
+        return self._classify(y)
+
+
+class SimpleConvSegHead(_StackedHead):
+    """Several 1x1 conv layers."""
+
+
+class ConvSegHead(_StackedHead):
+    """Several 3x3 conv layers, followed by a 1x1 conv layer."""
+    kernel_size, padding = 3, 1

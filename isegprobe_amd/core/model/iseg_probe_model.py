@@ -1,0 +1,140 @@
+"""Interactive segmentation model for probing VFMs and upsamplers (reference
+core/model/iseg_probe_model.py:16-258): backbone -> upsampler -> head, every stage a HIP
+module behind the reference's plugin contracts."""
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+from ... import hip_ops as ops
+from ..utils.log import logger
+from ..utils.model_builder import ModelBuilder
+from ..utils.serialization import serialize
+from ._tensor import nchw_view, to_nhwc_bf16
+from .featurizers import DINOv2Featurizer
+from .featurizers.utils import PatchEmbed
+from .iseg_base_model import iSegBaseModel
+
+
+class iSegProbeModel(iSegBaseModel):
+    """Same constructor as the reference (iseg_probe_model.py:34-46)."""
+
+    @serialize
+    def __init__(self, backbone_cfg: Dict = None, head_cfg: Dict = None, embed_coords_cfg: Dict = None,
+                 neck_cfg: Dict = None, upsampler_cfg: Dict = None, save_cfg: Dict = None,
+                 architecture: str = "backbone_upsampler_head", model_builder: ModelBuilder = None,
+                 **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.save_cfg = save_cfg
+        self.architecture = architecture
+        assert backbone_cfg is not None and head_cfg is not None and embed_coords_cfg is not None, \
+            "backbone, head and embed_coords configurations must be provided"
+        assert self.architecture in ["backbone_upsampler_head", "backbone_neck_head"], \
+            f"Unknown architecture: {self.architecture}"
+        self.embed_coords_type = embed_coords_cfg["type"]
+        self.upsampler_type = upsampler_cfg["type"] if upsampler_cfg else None
+        self.model_builder = model_builder if model_builder is not None else ModelBuilder()
+
+        # frozen modules
+        self.backbone = self.model_builder.load_featurizer(backbone_cfg["type"], backbone_cfg["params"], freeze=True)
+        self.upsampler = (
+            self.model_builder.load_upsampler(upsampler_cfg["type"], upsampler_cfg["params"], freeze=True)
+            if upsampler_cfg else self.model_builder.load_upsampler("bilinear", None, freeze=True))
+        # trainable modules
+        self.neck = (self.model_builder.load_neck(neck_cfg["type"], neck_cfg["params"], freeze=False)
+                     if neck_cfg else nn.Identity())
+        self.head = self.model_builder.load_head(head_cfg["type"], head_cfg["params"], freeze=False)
+        if self.embed_coords_type == "patchEmbed":
+            self.embed_coords = PatchEmbed(
+                img_size=embed_coords_cfg["params"]["img_size"],
+                patch_size=embed_coords_cfg["params"]["patch_size"],
+                in_chans=3 if self.with_prev_mask else 2,
+                embed_dim=embed_coords_cfg["params"]["embed_dim"])
+        elif self.embed_coords_type == "simple_vit":
+            self.embed_coords = self.model_builder.load_featurizer("simple_vit", embed_coords_cfg["params"], freeze=False)
+        else:
+            raise ValueError(f"Unknown embed_coords_type: {self.embed_coords_type}")
+        self._count_parameters()
+
+    # ---------------------------------------------------------------- forward
+    def _fusable(self):
+        return (isinstance(self.backbone, DINOv2Featurizer) and isinstance(self.embed_coords, PatchEmbed)
+                and self.backbone.feats_injection_mode == "before_backbone"
+                and self.embed_coords.patch_size[0] == self.backbone.patch_size
+                and isinstance(self.maps_transform, nn.Identity))
+
+    def _forward_prepared(self, image, prev_mask, points):
+        if self._fusable():
+            # click maps go straight into the patch matrix: no torch.cat, no token round trip
+            maps = self.dist_maps(image, points)
+            feats = self.backbone.forward_fused_clicks(image, prev_mask, maps, self.embed_coords)
+            return self._after_backbone(image, feats)
+        return super()._forward_prepared(image, prev_mask, points)
+
+    def backbone_forward(self, image: torch.Tensor, coord_features: torch.Tensor = None) -> Dict:
+        coord_features = self.embed_coords(coord_features)
+        backbone_features = self.backbone(image, coord_features)
+        return self._after_backbone(image, backbone_features)
+
+    def _after_backbone(self, image, backbone_features):
+        if self.architecture == "backbone_upsampler_head":
+            backbone_features = self.upsampler(source=backbone_features, guidance=image)
+            if self.upsampler_type != "identity" and image.size()[2:] != backbone_features.size()[2:]:
+                # iseg_probe_model.py:120-129: bilinear(align_corners=True) to the image size
+                backbone_features = nchw_view(ops.resize_nhwc(to_nhwc_bf16(backbone_features),
+                                                              image.shape[2], image.shape[3], "bilinear"))
+        elif self.architecture == "backbone_neck_head":
+            backbone_features = self.neck(backbone_features, guidance=image)
+        output = self.head(backbone_features)
+        return {"instances": output, "instances_aux": None}
+
+    def get_lowres_highres_feats(self, image: torch.Tensor, points: torch.Tensor) -> Tuple:
+        """Low / high resolution features for PCA dumps (iseg_probe_model.py:136-174)."""
+        image, prev_mask = self.prepare_input(image)
+        coord_features = self.maps_transform(self.get_coord_features(image, prev_mask, points))
+        lr_feats = self.backbone(image, self.embed_coords(coord_features))
+        hr_feats = self.upsampler(source=lr_feats, guidance=image)
+        feats = {"LowRes": lr_feats, "HighRes": hr_feats}
+        if self.upsampler.__class__.__name__ in ["IdentityUpsampler", "LiFTUpsampler"]:
+            feats["HighRes"] = nchw_view(ops.resize_nhwc(to_nhwc_bf16(hr_feats), image.shape[2], image.shape[3],
+                                                         "bilinear"))
+        return {"coord_features": coord_features}, feats
+
+    def _count_parameters(self):
+        n = lambda m: sum(p.numel() for p in m.parameters())
+        params_count = {
+            "backbone (M)": round(n(self.backbone) / 1e6, 2),
+            "head (M)": round(n(self.head) / 1e6, 2),
+            "embed_coords (k)": round(n(self.embed_coords) / 1e3, 2),
+            "neck (M)": round(n(self.neck) / 1e6, 2),
+            "trainable (M)": round(sum(p.numel() for p in self.parameters() if p.requires_grad) / 1e6, 2),
+            "total (M)": round(n(self) / 1e6, 2),
+        }
+        if isinstance(self.upsampler, nn.Module):
+            params_count["upsampler (k)"] = round(n(self.upsampler) / 1e3, 2)
+        logger.info(f"PARAMETERS COUNT: {params_count}")
+
+    def get_state_dict_to_save(self):
+        """state_dict filtered by ``save_cfg`` (iseg_probe_model.py:199-258): keys of save_cfg are
+        sub-module names; True keeps, False drops, {'save': bool, 'exclude': [...]} refines."""
+        state_dict = self.state_dict()
+        if not self.save_cfg:
+            return state_dict
+
+        def keep(name):
+            cfg = self.save_cfg
+            for part in name.split("."):
+                if not isinstance(cfg, dict):
+                    break
+                if part in cfg.get("exclude", ()):
+                    return False
+                cfg = cfg.get(part, None)
+                if cfg is False:
+                    return False
+                if cfg is None:
+                    return True
+                if isinstance(cfg, dict) and not cfg.get("save", False):
+                    return False
+            return True
+
+        return {k: v for k, v in state_dict.items() if keep(k)}

@@ -147,20 +147,20 @@ extern "C" int isp_normalize_fwd(const float* image, float* out, float* prev_mas
 
 // ---------------------------------------------------------------------------------------
 // Patch matrix for the fused patch-embed GEMM.  Row t of sample b holds, as bf16,
-//   [ img(c=0..2, i, j) | coord(c=0..nc-1, i, j) | 0 padding ]   (c-major, then i, then j:
+//   [ img(c=0..n_img-1, i, j) | coord(c=0..nc-1, i, j) | 0 padding ]   (c-major, then i, then j:
 // the flattening order of a Conv2d weight [D, C, p, p]), so that
 //   tokens = A . [W_img | W_click]^T  reproduces  patch_embed(image) + embed_coords(coord)
 // (DINOv2.py:518-523) in ONE GEMM.  coord channels come from up to two NCHW fp32 tensors
 // (prev mask [B,1,H,W] then click maps [B,2,H,W]; either may be null).
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, const float* __restrict__ prev,
                                                         const float* __restrict__ maps, bf16_t* __restrict__ A, int H,
-                                                        int W, int p, int gw, int hw_tokens, int n_prev, int n_maps,
-                                                        int Kpad) {
+                                                        int W, int p, int gw, int hw_tokens, int n_img, int n_prev,
+                                                        int n_maps, int Kpad) {
     // one block per token; threads sweep the K axis
     const int tok = blockIdx.x, b = blockIdx.y;
     const int ty = tok / gw, tx = tok % gw;
     const int pp = p * p;
-    const int kimg = 3 * pp, kall = (3 + n_prev + n_maps) * pp;
+    const int kimg = n_img * pp, kall = (n_img + n_prev + n_maps) * pp;
     bf16_t* row = A + ((size_t)b * hw_tokens + tok) * Kpad;
     const size_t plane = (size_t)H * W;
     for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
@@ -169,24 +169,26 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
             const int c = k / pp, r = k % pp, i = r / p, j = r % p;
             const size_t off = (size_t)(ty * p + i) * W + tx * p + j;
             if (k < kimg)
-                v = img[((size_t)b * 3 + c) * plane + off];
-            else if (c - 3 < n_prev)
-                v = prev[((size_t)b * n_prev + (c - 3)) * plane + off];
+                v = img[((size_t)b * n_img + c) * plane + off];
+            else if (c - n_img < n_prev)
+                v = prev[((size_t)b * n_prev + (c - n_img)) * plane + off];
             else
-                v = maps[((size_t)b * n_maps + (c - 3 - n_prev)) * plane + off];
+                v = maps[((size_t)b * n_maps + (c - n_img - n_prev)) * plane + off];
         }
         row[k] = f2bf(v);
     }
 }
 
 extern "C" int isp_patchify_fwd(const float* image, const float* prev_mask, const float* click_maps, void* A_bf16,
-                                int B, int H, int W, int patch, int n_prev, int n_maps, int Kpad, void* stream) {
-    ISP_CHECK_ARG(image && A_bf16 && B > 0 && patch > 0 && H % patch == 0 && W % patch == 0);
-    ISP_CHECK_ARG((n_prev == 0 || prev_mask) && (n_maps == 0 || click_maps) && n_prev >= 0 && n_maps >= 0);
-    ISP_CHECK_ARG(Kpad >= (3 + n_prev + n_maps) * patch * patch && Kpad % 8 == 0 && B <= 65535);
+                                int B, int H, int W, int patch, int n_img, int n_prev, int n_maps, int Kpad,
+                                void* stream) {
+    ISP_CHECK_ARG(A_bf16 && B > 0 && patch > 0 && H > 0 && W > 0 && H % patch == 0 && W % patch == 0);
+    ISP_CHECK_ARG(n_img >= 0 && n_prev >= 0 && n_maps >= 0 && n_img + n_prev + n_maps > 0);
+    ISP_CHECK_ARG((n_img == 0 || image) && (n_prev == 0 || prev_mask) && (n_maps == 0 || click_maps));
+    ISP_CHECK_ARG(Kpad >= (n_img + n_prev + n_maps) * patch * patch && Kpad % 8 == 0 && B <= 65535);
     const int gh = H / patch, gw = W / patch;
     dim3 grid(gh * gw, B);
     patchify_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(image, prev_mask, click_maps, (bf16_t*)A_bf16, H, W, patch,
-                                                           gw, gh * gw, n_prev, n_maps, Kpad);
+                                                           gw, gh * gw, n_img, n_prev, n_maps, Kpad);
     return isp_launch_status();
 }

@@ -280,3 +280,131 @@ extern "C" int isp_nchw_f32_to_nhwc_bf16(const float* in, void* out, int B, int 
                                                                         stride_p);
     return isp_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------
+// Token add with optional cls skip: x[b, (has_cls ? 1 : 0) + t, :] += add[b, t, :]
+// (click injection, DINOv2.py:516 and :523).  x f32 or bf16, add f32 or bf16.
+template <typename TX, typename TA>
+__global__ __launch_bounds__(256) void token_add_kernel(TX* __restrict__ x, const TA* __restrict__ add, long total4,
+                                                         int T, int D4, int has_cls) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total4) return;
+    const long row = idx / D4;
+    const int c4 = (int)(idx - row * D4);
+    const long b = row / T;
+    const long xrow = has_cls ? row + b + 1 : row;
+    float a[4];
+    if constexpr (sizeof(TA) == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(add + idx * 4);
+        a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w;
+    } else {
+        const uint2 u = *reinterpret_cast<const uint2*>(add + idx * 4);
+        a[0] = __uint_as_float(u.x << 16), a[1] = __uint_as_float(u.x & 0xffff0000u);
+        a[2] = __uint_as_float(u.y << 16), a[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+    TX* px = x + (xrow * D4 + c4) * 4;
+    if constexpr (sizeof(TX) == 4) {
+        float4 v = *reinterpret_cast<float4*>(px);
+        v.x += a[0], v.y += a[1], v.z += a[2], v.w += a[3];
+        *reinterpret_cast<float4*>(px) = v;
+    } else {
+        const uint2 u = *reinterpret_cast<const uint2*>(px);
+        *reinterpret_cast<uint2*>(px) =
+            make_uint2(pack2bf(__uint_as_float(u.x << 16) + a[0], __uint_as_float(u.x & 0xffff0000u) + a[1]),
+                       pack2bf(__uint_as_float(u.y << 16) + a[2], __uint_as_float(u.y & 0xffff0000u) + a[3]));
+    }
+}
+
+extern "C" int isp_token_add_fwd(void* x, int x_dtype, const void* add, int add_dtype, long B, int T, int D,
+                                 int x_has_cls, void* stream) {
+    ISP_CHECK_ARG(x && add && B > 0 && T > 0 && D > 0 && D % 4 == 0);
+    const long total4 = B * T * (D / 4);
+    const unsigned grid = (unsigned)((total4 + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+#define TA_CASE(TX, TA) token_add_kernel<TX, TA><<<grid, 256, 0, s>>>((TX*)x, (const TA*)add, total4, T, D / 4, x_has_cls)
+    if (x_dtype == ISP_F32 && add_dtype == ISP_F32) TA_CASE(float, float);
+    else if (x_dtype == ISP_F32 && add_dtype == ISP_BF16) TA_CASE(float, bf16_t);
+    else if (x_dtype == ISP_BF16 && add_dtype == ISP_F32) TA_CASE(bf16_t, float);
+    else if (x_dtype == ISP_BF16 && add_dtype == ISP_BF16) TA_CASE(bf16_t, bf16_t);
+    else return ISP_ERR_UNSUPPORTED;
+#undef TA_CASE
+    return isp_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// Nearest and bicubic (align_corners=False, A=-0.75) NHWC bf16 resizes: F.interpolate of
+// basic_upsamplers.py:18-25,36-42 and FeatUp JBU's bicubic x2 (third-party, see oracle).
+// PyTorch source-index rules: nearest src = floor(dst * in/out); bicubic
+// src = (dst + 0.5) * in/out - 0.5 with border-clamped taps.
+__device__ __forceinline__ void cubic_coeffs(float t, float* w) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+template <int MODE>  // 0 nearest, 1 bicubic
+__global__ __launch_bounds__(256) void resize_nhwc_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                           int h, int w, int H, int W, int C, float sy, float sx,
+                                                           long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C >> 3;
+    const int c8 = (int)(idx % cv);
+    long pix = idx / cv;
+    const int X = (int)(pix % W);
+    pix /= W;
+    const int Y = (int)(pix % H);
+    const int b = (int)(pix / H);
+    const bf16_t* base = in + (size_t)b * h * w * C + c8 * 8;
+    if (MODE == 0) {
+        const int ys = min((int)floorf((float)Y * sy), h - 1), xs = min((int)floorf((float)X * sx), w - 1);
+        *reinterpret_cast<uint4*>(out + idx * 8) = *reinterpret_cast<const uint4*>(base + ((size_t)ys * w + xs) * C);
+        return;
+    }
+    const float fy = sy * ((float)Y + 0.5f) - 0.5f, fx = sx * ((float)X + 0.5f) - 0.5f;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_coeffs(fy - (float)iy, wy);
+    cubic_coeffs(fx - (float)ix, wx);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = min(max(iy - 1 + i, 0), h - 1);
+        float rowacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = min(max(ix - 1 + j, 0), w - 1);
+            const uint4 u = *reinterpret_cast<const uint4*>(base + ((size_t)yy * w + xx) * C);
+            const unsigned* p = &u.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                rowacc[2 * k] += wx[j] * __uint_as_float(p[k] << 16);
+                rowacc[2 * k + 1] += wx[j] * __uint_as_float(p[k] & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += wy[i] * rowacc[k];
+    }
+    *reinterpret_cast<uint4*>(out + idx * 8) =
+        make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+}
+
+extern "C" int isp_resize_nhwc_bf16(const void* in, void* out, int B, int h, int w, int H, int W, int C, int mode,
+                                    void* stream) {
+    ISP_CHECK_ARG(in && out && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+    if (mode == ISP_RESIZE_BILINEAR_AC) return isp_resize_bilinear_ac_nhwc_bf16(in, out, B, h, w, H, W, C, stream);
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const long total = (long)B * H * W * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == ISP_RESIZE_NEAREST)
+        resize_nhwc_kernel<0><<<grid, 256, 0, s>>>((const bf16_t*)in, (bf16_t*)out, h, w, H, W, C, sy, sx, total);
+    else if (mode == ISP_RESIZE_BICUBIC)
+        resize_nhwc_kernel<1><<<grid, 256, 0, s>>>((const bf16_t*)in, (bf16_t*)out, h, w, H, W, C, sy, sx, total);
+    else
+        return ISP_ERR_UNSUPPORTED;
+    return isp_launch_status();
+}

@@ -59,17 +59,18 @@ def normalize(image, mean, std, want_prev=True):
 
 
 def patchify(image, prev, maps, patch, Kpad):
-    image = _need(image, torch.float32, "image")
-    B, _, H, W = image.shape
-    n_prev = 0 if prev is None else prev.shape[1]
-    n_maps = 0 if maps is None else maps.shape[1]
-    if prev is not None:
-        _need(prev, torch.float32, "prev")
-    if maps is not None:
-        _need(maps, torch.float32, "maps")
-    A = torch.empty(B * (H // patch) * (W // patch), Kpad, device=image.device, dtype=BF16)
-    check(_lib.lib().isp_patchify_fwd(_p(image), _p(prev), _p(maps), _p(A), B, H, W, patch, n_prev, n_maps, Kpad,
-                                      _stream()), "isp_patchify_fwd")
+    """Rows of [image | prev | maps] patches (channel-major, then i, j), zero-padded to Kpad, bf16.
+    Any of the three NCHW f32 inputs may be None."""
+    srcs = [t for t in (image, prev, maps) if t is not None]
+    if not srcs:
+        raise IspError("patchify needs at least one input")
+    for t in srcs:
+        _need(t, torch.float32, "patchify input")
+    B, _, H, W = srcs[0].shape
+    nch = [0 if t is None else t.shape[1] for t in (image, prev, maps)]
+    A = torch.empty(B * (H // patch) * (W // patch), Kpad, device=srcs[0].device, dtype=BF16)
+    check(_lib.lib().isp_patchify_fwd(_p(image), _p(prev), _p(maps), _p(A), B, H, W, patch, nch[0], nch[1], nch[2],
+                                      Kpad, _stream()), "isp_patchify_fwd")
     return A
 
 
@@ -189,6 +190,30 @@ def resize_bilinear_nhwc(x, H, W):
     check(_lib.lib().isp_resize_bilinear_ac_nhwc_bf16(_p(x), _p(out), B, h, w, H, W, C, _stream()),
           "isp_resize_bilinear_ac_nhwc_bf16")
     return out
+
+
+RESIZE_MODES = {"nearest": 0, "bilinear": 1, "bicubic": 2}
+
+
+def resize_nhwc(x, H, W, mode):
+    """NHWC bf16 resize: 'nearest' | 'bilinear' (align_corners=True) | 'bicubic' (align_corners=False)."""
+    _need(x, BF16, "x")
+    B, h, w, C = x.shape
+    out = torch.empty(B, H, W, C, device=x.device, dtype=BF16)
+    check(_lib.lib().isp_resize_nhwc_bf16(_p(x), _p(out), B, h, w, H, W, C, RESIZE_MODES[mode], _stream()),
+          "isp_resize_nhwc_bf16")
+    return out
+
+
+def token_add_(x, add, B, T, has_cls):
+    """x[b,(cls)+t,:] += add[b,t,:] in place; x/add f32 or bf16."""
+    _need(x, x.dtype, "x")
+    add = _need(add.contiguous(), add.dtype, "add")
+    D = x.shape[-1]
+    dt = {torch.float32: _lib.ISP_F32, BF16: _lib.ISP_BF16}
+    check(_lib.lib().isp_token_add_fwd(_p(x), dt[x.dtype], _p(add), dt[add.dtype], B, T, D, int(has_cls), _stream()),
+          "isp_token_add_fwd")
+    return x
 
 
 def resize_bilinear_nchw_f32(x, H, W):

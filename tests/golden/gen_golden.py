@@ -223,7 +223,7 @@ def gen_bfs():
     save("dist_maps_bfs", **out)
 
 
-TINY = dict(embed_dim=64, depth=2, num_heads=2, patch=14, img_size=70)
+TINY = dict(embed_dim=128, depth=2, num_heads=2, patch=14, img_size=70)
 
 
 def build_ref_backbone(injection, cfg=TINY, seed=11):
@@ -288,13 +288,15 @@ def gen_upsamplers_and_head():
     from core.model.upsamplers.LoftUp import LoftUpUpsampler
     torch.manual_seed(4)
     out = {}
-    C, h, w, H, W = 64, 4, 5, 56, 70
+    C, h, w, H, W = 128, 4, 5, 56, 70
     src = torch.randn(2, C, h, w)
     gd = torch.randn(2, 3, H, W)
     out["source"], out["guidance"] = src.numpy(), gd.numpy()
+    src8 = src[:, :8].contiguous()  # the parameter-free upsamplers are channel-independent
+    out["source8"] = src8.numpy()
     for name in ("identity", "nearest", "bilinear", "bicubic"):
         with torch.no_grad():
-            out["basic_" + name] = UPSAMPLER_REGISTRY[name]()(source=src, guidance=gd).numpy()
+            out["basic_" + name] = UPSAMPLER_REGISTRY[name]()(source=src8, guidance=gd).numpy()
     # LiFT (wrapper bypasses the torch.load + .to("cuda") loader, LiFT.py:125-136)
     lift = LiFTUpsampler.__new__(LiFTUpsampler)
     nn.Module.__init__(lift)
@@ -393,13 +395,19 @@ def gen_model():
         with torch.no_grad():
             y = model(img, pts)["instances"]
         out[f"{up}_logits"] = y.numpy()
+        # backbone / head / embed_coords are seeded identically for every variant: store once
         for k, v in sd_np(model).items():
-            out[f"{up}_w::" + k] = v
+            if k.startswith("upsampler."):
+                out[f"{up}_w::" + k] = v
+            else:
+                key = "common_w::" + k
+                assert key not in out or np.array_equal(out[key], v)
+                out[key] = v
     model = build_ref_model("bilinear", injection="after_backbone")
     with torch.no_grad():
         out["bilinear_after_logits"] = model(img, pts)["instances"].numpy()
     for k, v in sd_np(model).items():
-        out["bilinear_after_w::" + k] = v
+        assert np.array_equal(out["common_w::" + k], v)
     save("model_tiny", **out)
 
 

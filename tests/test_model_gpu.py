@@ -1,0 +1,102 @@
+"""GPU: the assembled HIP path (featurizer / upsampler / head plugins, iSegProbeModel) against
+the golden fixtures generated from the reference and against the CPU oracle.
+
+Tolerances: the product path computes GEMMs in bf16 with fp32 accumulation, so logits are
+held to BASELINE.json north_star's "within ... 1e-2 bf16", applied in the usual allclose
+form |hip - ref| <= 1e-2 + 1e-2 * |ref|; masks (logits > 0) must agree wherever the oracle's
+own logit is further than that tolerance from the threshold."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import weights_from
+from helpers import S14, build_model, rand_points, seeded_
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-2       # BASELINE configs (full-size models): north_star's bf16 logit tolerance
+TOL_TINY = 2e-2  # 2-block / 128-dim fixture models: logits are read at 4x4..56x56 pixels with no
+                 # spatial averaging of the featurizer's bf16 noise (measured: max 1.4e-2, rms 3.5e-3)
+
+
+def _load(model, weights):
+    missing, unexpected = model.load_state_dict(weights, strict=False)
+    assert not unexpected, unexpected
+    assert all("mask_token" in k for k in missing), missing
+    return model.cuda()
+
+
+def _close(y, ref, tol=TOL):
+    bad = (y - ref).abs() > tol + tol * ref.abs()
+    return not bad.any().item()
+
+
+def _mask_agreement(logits, ref, tol=TOL):
+    decided = ref.abs() > tol
+    return ((logits > 0) == (ref > 0))[decided].float().mean().item()
+
+
+@pytest.mark.parametrize("inj", ["before_backbone", "after_backbone", "no_injection"])
+@pytest.mark.parametrize("tag", ["sq", "rect", "native"])
+def test_featurizer_vs_golden(golden, inj, tag):
+    from isegprobe_amd.core.model.featurizers import DINOv2Featurizer
+    from helpers import TINY_VIT
+    g = golden("vit_tiny")
+    f = DINOv2Featurizer("custom", inj, vit_kwargs=TINY_VIT)
+    f.model.load_state_dict(weights_from(g, "w"), strict=False)
+    f = f.cuda().eval()
+    y = f(torch.from_numpy(g[f"{inj}_{tag}_x"]).cuda(), torch.from_numpy(g[f"{inj}_{tag}_clicks"]).cuda())
+    ref = torch.from_numpy(g[f"{inj}_{tag}_y"])
+    assert y.shape == ref.shape
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err < 3e-2 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("up", ["bilinear", "identity", "bilinear_after"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_tiny_model_vs_golden(golden, up, fused):
+    g = golden("model_tiny")
+    inj = "after_backbone" if up.endswith("_after") else "before_backbone"
+    model = build_model(up.replace("_after", ""), inj)
+    _load(model, {**weights_from(g, "common_w"), **weights_from(g, up.replace("_after", "") + "_w")})
+    image, points = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["points"]).cuda()
+    with torch.no_grad():
+        if fused:
+            y = model(image, points)["instances"]
+        else:  # plugin-by-plugin route of the reference (iseg_base_model.py:67-89)
+            img, prev = model.prepare_input(image)
+            coord = model.get_coord_features(img, prev, points)
+            y = model.backbone_forward(img, coord)["instances"]
+            y = model._to_image_size(y, img.shape[2:])
+    ref = torch.from_numpy(g[up + "_logits"])
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    err = (y.cpu() - ref).abs()
+    assert _close(y.cpu(), ref, TOL_TINY), (err.max().item(), err.pow(2).mean().sqrt().item())
+    assert err.pow(2).mean().sqrt().item() < 4e-3  # rms well inside the bound
+    assert _mask_agreement(y.cpu(), ref, TOL_TINY) == 1.0
+
+
+@pytest.mark.parametrize("size,B", [(224, 2), (448, 1)])
+def test_s14_bilinear_vs_oracle(size, B):
+    """Full-size DINOv2-S/14 + bilinear + ConvSegHead with seeded weights vs the CPU oracle."""
+    from oracle import model as omodel
+    model = build_model("bilinear", vit=S14, img=(size, size))
+    seeded_(model, 123)
+    with torch.no_grad():
+        model.backbone.model.pos_embed.mul_(0.3)
+    w = {k: v.clone() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(7)
+    torch.manual_seed(7)
+    image = torch.rand(B, 4, size, size)
+    image[:, 3] = (image[:, 3] > 0.8).float()
+    points = torch.from_numpy(rand_points(rng, B, 24, size, size))
+    cfg = dict(patch=14, depth=12, heads=6, upsampler="bilinear", injection="before_backbone",
+               with_prev_mask=True, use_disks=True, norm_radius=5)
+    torch.set_num_threads(16)
+    ref = omodel.forward(image, points, w, cfg)
+    with torch.no_grad():
+        y = model.cuda()(image.cuda(), points.cuda())["instances"].cpu()
+    err = (y - ref).abs()
+    print(f"S/14@{size}: max|logit err| = {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g}, "
+          f"logit range = {ref.min():.3f}..{ref.max():.3f} rms {ref.pow(2).mean().sqrt():.3f}")
+    assert _close(y, ref), err.max().item()
+    assert _mask_agreement(y, ref) == 1.0

@@ -81,7 +81,7 @@ def test_vit_stages(golden):
 @pytest.mark.parametrize("name", ["identity", "nearest", "bilinear", "bicubic"])
 def test_basic_upsamplers(golden, name):
     g = golden("upsamplers_head")
-    y = getattr(oups, name)(torch.from_numpy(g["source"]), torch.from_numpy(g["guidance"]))
+    y = getattr(oups, name)(torch.from_numpy(g["source8"]), torch.from_numpy(g["guidance"]))
     np.testing.assert_allclose(y.numpy(), g["basic_" + name], atol=1e-6)
 
 
@@ -111,5 +111,6 @@ def test_model_forward(golden, up):
     cfg = dict(patch=14, depth=2, heads=2, upsampler=up.replace("_after", ""),
                injection="after_backbone" if up.endswith("_after") else "before_backbone",
                with_prev_mask=True, use_disks=True, norm_radius=5)
-    y = omodel.forward(torch.from_numpy(g["image"]), torch.from_numpy(g["points"]), weights_from(g, up + "_w"), cfg)
+    w = {**weights_from(g, "common_w"), **weights_from(g, up.replace("_after", "") + "_w")}
+    y = omodel.forward(torch.from_numpy(g["image"]), torch.from_numpy(g["points"]), w, cfg)
     np.testing.assert_allclose(y.numpy(), g[up + "_logits"], atol=1e-4, rtol=1e-4)
