@@ -62,6 +62,7 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
 #define ISP_EP_BIAS_F32 3       /* out f32  = v + bias                                   */
 #define ISP_EP_RESIDUAL_F32 4   /* out f32 += gamma * (v + bias)    LayerScale + residual, block.py:92-117 */
 #define ISP_EP_TOKENS_F32 5     /* out f32 [b*(T+1)+1+t] = v + bias + pos[1+t]   DINOv2.py:523-528 */
+#define ISP_EP_AXPY_RES_BF16 6  /* out bf16 = res + alpha * (v + bias)   FeatUp JBUStack fix-up  */
 
 typedef struct isp_epilogue {
     int kind;             /* ISP_EP_* */
@@ -71,6 +72,8 @@ typedef struct isp_epilogue {
     const float* gamma;   /* [N] LayerScale or NULL (RESIDUAL) */
     const float* pos;     /* [(T+1), ldo] interpolated pos-embed or NULL (TOKENS) */
     int tokens_per_image; /* T (TOKENS) */
+    const void* res;      /* bf16 [M, ldo] residual (AXPY_RES) */
+    float alpha;          /* (AXPY_RES) */
 } isp_epilogue;
 
 /* ---- C = A . Wt^T with a fused epilogue.  A [M, lda>=K] bf16, Wt [N,K] bf16, K % 64 == 0,
@@ -115,6 +118,18 @@ int isp_resize_nhwc_bf16(const void* in, void* out, int B, int h, int w, int H, 
 /* ---- click-token injection x[b,(cls)+t,:] += add[b,t,:]: DINOv2.py:516,523. */
 int isp_token_add_fwd(void* x, int x_dtype, const void* add, int add_dtype, long B, int T, int D, int x_has_cls,
                       void* stream);
+
+/* ---- FeatUp JBU stage (third-party algorithm, see jbu.hip header; call site
+ * core/model/upsamplers/JBUFeatUp.py:18-19).  guidance/proj/kernels are fp32; feature maps
+ * NHWC bf16.  fix3_wT is the second fix-up layer's weight TRANSPOSED ([in][out]). */
+int isp_adaptive_avg_pool_nchw_f32(const float* in, float* out, long planes, int H, int W, int OH, int OW, void* stream);
+int isp_jbu_range_proj(const float* guidance, float* proj, const float* w0, const float* b0, const float* w3,
+                       const float* b3, int B, int GH, int GW, void* stream);
+int isp_jbu_kernels(const float* proj, const float* guidance, float* kernels, const float* fix0_w, const float* fix0_b,
+                    const float* fix3_wT, const float* fix3_b, float range_temp, float sigma_spatial, int B, int GH,
+                    int GW, void* stream);
+int isp_jbu_adaptive_conv(const void* hr_nhwc_bf16, const float* kernels, void* out_nhwc_bf16, int B, int GH, int GW,
+                          int C, void* stream);
 
 /* ---- BaseClassifierHead.classifier (1x1 conv C->1), heads/base_head.py:15.
  * x [M,C] NHWC bf16, weight [C] f32 -> out [M] f32. */

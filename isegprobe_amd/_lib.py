@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libisegprobe_hip.so")
 ABI_VERSION = 1
 
 ISP_F32, ISP_BF16 = 0, 1
-EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32 = range(6)
+EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16 = range(7)
 
 _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed"}
 
@@ -30,6 +30,8 @@ class Epilogue(ctypes.Structure):
         ("gamma", ctypes.c_void_p),
         ("pos", ctypes.c_void_p),
         ("tokens_per_image", ctypes.c_int),
+        ("res", ctypes.c_void_p),
+        ("alpha", ctypes.c_float),
     ]
 
 
@@ -50,6 +52,10 @@ SIGNATURES = {
     "isp_resize_bilinear_ac_nchw_f32": [_vp, _vp, _l, _i, _i, _i, _i, _l, _vp],
     "isp_resize_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "isp_token_add_fwd": [_vp, _i, _vp, _i, _l, _i, _i, _i, _vp],
+    "isp_adaptive_avg_pool_nchw_f32": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
+    "isp_jbu_range_proj": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "isp_jbu_kernels": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp],
+    "isp_jbu_adaptive_conv": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "isp_classifier_fwd": [_vp, _vp, _f, _vp, _l, _i, _vp],
     "isp_nhwc_bf16_to_nchw_f32": [_vp, _vp, _i, _i, _l, _vp],
     "isp_nchw_f32_to_nhwc_bf16": [_vp, _vp, _i, _i, _l, _l, _l, _l, _vp],

@@ -79,14 +79,16 @@ class iSegProbeModel(iSegBaseModel):
     def _after_backbone(self, image, backbone_features):
         if self.architecture == "backbone_upsampler_head":
             backbone_features = self.upsampler(source=backbone_features, guidance=image)
-            if self.upsampler_type != "identity" and image.size()[2:] != backbone_features.size()[2:]:
-                # iseg_probe_model.py:120-129: bilinear(align_corners=True) to the image size
-                backbone_features = nchw_view(ops.resize_nhwc(to_nhwc_bf16(backbone_features),
-                                                              image.shape[2], image.shape[3], "bilinear"))
-        elif self.architecture == "backbone_neck_head":
-            backbone_features = self.neck(backbone_features, guidance=image)
-        output = self.head(backbone_features)
-        return {"instances": output, "instances_aux": None}
+            return {"instances": self._resize_and_head(image, backbone_features), "instances_aux": None}
+        backbone_features = self.neck(backbone_features, guidance=image)
+        return {"instances": self.head(backbone_features), "instances_aux": None}
+
+    def _resize_and_head(self, image, hr_features):
+        if self.upsampler_type != "identity" and image.size()[2:] != hr_features.size()[2:]:
+            # iseg_probe_model.py:120-129: bilinear(align_corners=True) to the image size
+            hr_features = nchw_view(ops.resize_nhwc(to_nhwc_bf16(hr_features), image.shape[2], image.shape[3],
+                                                    "bilinear"))
+        return self.head(hr_features)
 
     def get_lowres_highres_feats(self, image: torch.Tensor, points: torch.Tensor) -> Tuple:
         """Low / high resolution features for PCA dumps (iseg_probe_model.py:136-174)."""

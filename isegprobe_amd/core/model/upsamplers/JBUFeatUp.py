@@ -1,11 +1,102 @@
-"""Placeholder so the registry imports; replaced below."""
+"""FeatUp JBU upsampler (reference core/model/upsamplers/JBUFeatUp.py:9-32), x16.
+
+The reference obtains the module with ``torch.hub.load("mhamilton723/FeatUp", backbone_type,
+use_norm=...).upsampler`` -- a third-party ``JBUStack`` whose source is not part of the
+reference tree and cannot be fetched here.  ``JBUStack`` / ``JBULearnedRange`` below are
+parameter containers with FeatUp's state-dict layout (``up{1..4}.{range_temp, range_proj.{0,3},
+fixup_proj.{0,3}, sigma_spatial}``, ``fixup_proj.1``); the arithmetic is the HIP stage kernels
+of csrc/jbu.hip.  Weights: ``weights=`` (state dict / path in FeatUp's upsampler key layout)
+or ``$ISEGPROBE_JBU_WEIGHTS``; otherwise FeatUp's default init is kept.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .... import hip_ops as ops
+from ...utils.log import logger
+from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16
 from . import BaseUpsampler
+
+FEAT_DIMS = {"dinov2": 384, "dino16": 384, "vit": 384, "maskclip": 512, "clip": 512, "resnet50": 2048}
+
+
+class JBULearnedRange(nn.Module):
+    def __init__(self, guidance_dim, feat_dim, key_dim, scale=2, radius=3):
+        super().__init__()
+        if (guidance_dim, key_dim, scale, radius) != (3, 32, 2, 3):
+            raise NotImplementedError("the JBU kernels are built for guidance 3, key 32, x2, radius 3")
+        d2 = (2 * radius + 1) ** 2
+        self.range_temp = nn.Parameter(torch.tensor(0.0))
+        self.range_proj = nn.Sequential(nn.Conv2d(guidance_dim, key_dim, 1, 1), nn.GELU(), nn.Dropout2d(0.1),
+                                        nn.Conv2d(key_dim, key_dim, 1, 1))
+        self.fixup_proj = nn.Sequential(nn.Conv2d(guidance_dim + d2, d2, 1, 1), nn.GELU(), nn.Dropout2d(0.1),
+                                        nn.Conv2d(d2, d2, 1, 1))
+        self.sigma_spatial = nn.Parameter(torch.tensor(1.0))
+        self._packed = PackedCache()
+
+    def packed(self):
+        def build():
+            f = lambda t: t.detach().float().contiguous()
+            return dict(w0=f(self.range_proj[0].weight.flatten(1)), b0=f(self.range_proj[0].bias),
+                        w3=f(self.range_proj[3].weight.flatten(1)), b3=f(self.range_proj[3].bias),
+                        f0w=f(self.fixup_proj[0].weight.flatten(1)), f0b=f(self.fixup_proj[0].bias),
+                        f3wT=f(self.fixup_proj[3].weight.flatten(1).t()), f3b=f(self.fixup_proj[3].bias),
+                        temp=float(self.range_temp.item()), sigma=float(self.sigma_spatial.item()))
+        return self._packed.get(list(self.parameters()), build)
+
+    def run(self, source_nhwc, guidance_small):
+        P = self.packed()
+        B, GH, GW = guidance_small.shape[0], guidance_small.shape[2], guidance_small.shape[3]
+        proj = ops.jbu_range_proj(guidance_small, P["w0"], P["b0"], P["w3"], P["b3"])
+        kern = ops.jbu_kernels(proj, guidance_small, P["f0w"], P["f0b"], P["f3wT"], P["f3b"], P["temp"], P["sigma"])
+        hr = ops.resize_nhwc(source_nhwc, GH, GW, "bicubic")
+        return ops.jbu_adaptive_conv(hr, kern)
+
+
+class JBUStack(nn.Module):
+    def __init__(self, feat_dim):
+        super().__init__()
+        self.up1 = JBULearnedRange(3, feat_dim, 32, radius=3)
+        self.up2 = JBULearnedRange(3, feat_dim, 32, radius=3)
+        self.up3 = JBULearnedRange(3, feat_dim, 32, radius=3)
+        self.up4 = JBULearnedRange(3, feat_dim, 32, radius=3)
+        self.fixup_proj = nn.Sequential(nn.Dropout2d(0.2), nn.Conv2d(feat_dim, feat_dim, kernel_size=1))
+        self._packed = PackedCache()
+
+    def forward(self, source, guidance):
+        # NB: the frozen upsampler's Dropout2d layers are never applied (the reference's
+        # net.train() would switch them on, trainer.py:214 -- a stochastic quirk we do not mirror)
+        x = to_nhwc_bf16(source)
+        guidance = guidance.float().contiguous()
+        for up in (self.up1, self.up2, self.up3, self.up4):
+            small = ops.adaptive_avg_pool(guidance, x.shape[1] * 2, x.shape[2] * 2)
+            x = up.run(x, small)
+        conv = self.fixup_proj[1]
+        w, b = self._packed.get((conv.weight, conv.bias),
+                                lambda: (conv.weight.detach().flatten(1).to(BF16).contiguous(),
+                                         conv.bias.detach().float().contiguous()))
+        B, H, W, C = x.shape
+        y = ops.linear_axpy_res(x.view(-1, C), w, b, x.view(-1, C), 0.1)
+        return nchw_view(y.view(B, H, W, C))
 
 
 class JBUFeatUpUpsampler(BaseUpsampler):
-    def __init__(self, *a, **k):
-        super().__init__()
-        raise NotImplementedError("JBUFeatUpUpsampler: HIP path not built yet")
+    """Learned JBU upsampler from FeatUp. Performs x16 upsampling."""
 
-    def forward(self, source, guidance):
-        raise NotImplementedError
+    def __init__(self, backbone_type: str = None, use_norm: bool = True, weights=None, feat_dim: int = None) -> None:
+        super().__init__()
+        self.backbone_type = backbone_type
+        self.use_norm = use_norm
+        assert self.backbone_type in FEAT_DIMS, f"Invalid model type: {self.backbone_type}"
+        self.upsampler = JBUStack(feat_dim or FEAT_DIMS[backbone_type])
+        weights = weights or os.environ.get("ISEGPROBE_JBU_WEIGHTS")
+        if weights is not None:
+            sd = torch.load(weights, map_location="cpu") if isinstance(weights, (str, os.PathLike)) else weights
+            self.upsampler.load_state_dict(sd)
+        else:
+            logger.info("JBUFeatUpUpsampler: no weights given, keeping default init (no network for torch.hub)")
+        self.eval()
+
+    def forward(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
+        return self.upsampler(source, guidance)

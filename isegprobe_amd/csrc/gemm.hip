@@ -124,6 +124,23 @@ struct EpResidual {  // x[m][n] += gamma[n] * (v + bias[n])   (LayerScale + resi
     }
 };
 
+struct EpAxpyResBf16 {  // out = res + alpha * (v + bias), bf16 in/out (FeatUp JBUStack final fix-up)
+    bf16_t* out;
+    const bf16_t* res;
+    const float* bias;
+    float alpha;
+    long ldo;
+    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
+        float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
+        const uint2 u = *reinterpret_cast<const uint2*>(res + (size_t)m * ldo + n);
+        const float r0 = __uint_as_float(u.x << 16) + alpha * (v[0] + b.x);
+        const float r1 = __uint_as_float(u.x & 0xffff0000u) + alpha * (v[1] + b.y);
+        const float r2 = __uint_as_float(u.y << 16) + alpha * (v[2] + b.z);
+        const float r3 = __uint_as_float(u.y & 0xffff0000u) + alpha * (v[3] + b.w);
+        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = make_uint2(pack2bf(r0, r1), pack2bf(r2, r3));
+    }
+};
+
 struct EpTokens {  // patch-embed: token row b*(T+1)+1+t gets v + bias[n] + pos[1+t][n]
     float* x;
     const float* bias;  // b_img + b_click, pre-summed
@@ -281,6 +298,10 @@ int dispatch_epilogue(AL al, const void* Wt, long M, int N, int K, const isp_epi
         case ISP_EP_TOKENS_F32:
             if (e->tokens_per_image <= 0 || !e->bias) return ISP_ERR_INVALID;
             return launch_gemm(al, Wt, M, N, K, EpTokens{(float*)e->out, e->bias, e->pos, e->tokens_per_image, ldo}, s);
+        case ISP_EP_AXPY_RES_BF16:
+            if (!e->res) return ISP_ERR_INVALID;
+            return launch_gemm(al, Wt, M, N, K,
+                               EpAxpyResBf16{(bf16_t*)e->out, (const bf16_t*)e->res, e->bias, e->alpha, ldo}, s);
         default:
             return ISP_ERR_UNSUPPORTED;
     }

@@ -74,7 +74,7 @@ def patchify(image, prev, maps, patch, Kpad):
     return A
 
 
-def _epilogue(kind, out, ldo=0, bias=None, gamma=None, pos=None, tokens=0):
+def _epilogue(kind, out, ldo=0, bias=None, gamma=None, pos=None, tokens=0, res=None, alpha=0.0):
     ep = Epilogue()
     ep.kind = kind
     ep.out = out.data_ptr()
@@ -83,6 +83,8 @@ def _epilogue(kind, out, ldo=0, bias=None, gamma=None, pos=None, tokens=0):
     ep.gamma = gamma.data_ptr() if gamma is not None else None
     ep.pos = pos.data_ptr() if pos is not None else None
     ep.tokens_per_image = tokens
+    ep.res = res.data_ptr() if res is not None else None
+    ep.alpha = alpha
     return ep
 
 
@@ -255,4 +257,52 @@ def nchw_f32_to_nhwc_bf16(x):
     out = torch.empty(B, H, W, C, device=x.device, dtype=BF16)
     check(_lib.lib().isp_nchw_f32_to_nhwc_bf16(_p(x), _p(out), B, C, H * W, x.stride(0), x.stride(1), x.stride(3),
                                                _stream()), "isp_nchw_f32_to_nhwc_bf16")
+    return out
+
+
+# ---------------------------------------------------------------------------------- JBU
+def adaptive_avg_pool(x, OH, OW):
+    """F.adaptive_avg_pool2d on contiguous fp32 [..., H, W]."""
+    _need(x, torch.float32, "x")
+    H, W = x.shape[-2:]
+    out = torch.empty(*x.shape[:-2], OH, OW, device=x.device, dtype=torch.float32)
+    check(_lib.lib().isp_adaptive_avg_pool_nchw_f32(_p(x), _p(out), x.numel() // (H * W), H, W, OH, OW, _stream()),
+          "isp_adaptive_avg_pool_nchw_f32")
+    return out
+
+
+def jbu_range_proj(g, w0, b0, w3, b3):
+    """g [B,3,GH,GW] f32 -> proj [B,GH,GW,32] f32."""
+    _need(g, torch.float32, "guidance")
+    B, _, GH, GW = g.shape
+    proj = torch.empty(B, GH, GW, 32, device=g.device, dtype=torch.float32)
+    check(_lib.lib().isp_jbu_range_proj(_p(g), _p(proj), _p(w0), _p(b0), _p(w3), _p(b3), B, GH, GW, _stream()),
+          "isp_jbu_range_proj")
+    return proj
+
+
+def jbu_kernels(proj, g, f0w, f0b, f3wT, f3b, range_temp, sigma_spatial):
+    B, GH, GW, _ = proj.shape
+    k = torch.empty(B, GH, GW, 49, device=proj.device, dtype=torch.float32)
+    check(_lib.lib().isp_jbu_kernels(_p(proj), _p(g), _p(k), _p(f0w), _p(f0b), _p(f3wT), _p(f3b), float(range_temp),
+                                     float(sigma_spatial), B, GH, GW, _stream()), "isp_jbu_kernels")
+    return k
+
+
+def jbu_adaptive_conv(hr, kernels):
+    _need(hr, BF16, "hr")
+    _need(kernels, torch.float32, "kernels")
+    B, GH, GW, C = hr.shape
+    out = torch.empty_like(hr)
+    check(_lib.lib().isp_jbu_adaptive_conv(_p(hr), _p(kernels), _p(out), B, GH, GW, C, _stream()),
+          "isp_jbu_adaptive_conv")
+    return out
+
+
+def linear_axpy_res(A, Wt, bias, res, alpha):
+    """bf16: res + alpha * (A Wt^T + bias)."""
+    _need(res, BF16, "res")
+    N = Wt.shape[0]
+    out = torch.empty(A.shape[0], N, device=A.device, dtype=BF16)
+    gemm(A, Wt, _epilogue(_lib.EP_AXPY_RES_BF16, out, N, bias, res=res, alpha=alpha))
     return out
