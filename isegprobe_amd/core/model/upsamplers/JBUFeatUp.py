@@ -5,7 +5,7 @@ use_norm=...).upsampler`` -- a third-party ``JBUStack`` whose source is not part
 reference tree and cannot be fetched here.  ``JBUStack`` / ``JBULearnedRange`` below are
 parameter containers with FeatUp's state-dict layout (``up{1..4}.{range_temp, range_proj.{0,3},
 fixup_proj.{0,3}, sigma_spatial}``, ``fixup_proj.1``); the arithmetic is the HIP stage kernels
-of csrc/jbu.hip.  Weights: ``weights=`` (state dict / path in FeatUp's upsampler key layout)
+of csrc/jbu.hip (composite-kernel formulation, see its header).  Weights: ``weights=`` (state dict / path in FeatUp's upsampler key layout)
 or ``$ISEGPROBE_JBU_WEIGHTS``; otherwise FeatUp's default init is kept.
 """
 import os
@@ -49,9 +49,9 @@ class JBULearnedRange(nn.Module):
         P = self.packed()
         B, GH, GW = guidance_small.shape[0], guidance_small.shape[2], guidance_small.shape[3]
         proj = ops.jbu_range_proj(guidance_small, P["w0"], P["b0"], P["w3"], P["b3"])
-        kern = ops.jbu_kernels(proj, guidance_small, P["f0w"], P["f0b"], P["f3wT"], P["f3b"], P["temp"], P["sigma"])
-        hr = ops.resize_nhwc(source_nhwc, GH, GW, "bicubic")
-        return ops.jbu_adaptive_conv(hr, kern)
+        # composite (bicubic-x2 o 7x7) kernels on the low-res grid, applied by MFMA: no x2 map in HBM
+        kc = ops.jbu_kernels(proj, guidance_small, P["f0w"], P["f0b"], P["f3wT"], P["f3b"], P["temp"], P["sigma"])
+        return ops.jbu_apply(source_nhwc, kc)
 
 
 class JBUStack(nn.Module):

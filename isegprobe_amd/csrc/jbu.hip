@@ -7,11 +7,14 @@
 //   guidance (fp32 NCHW, 3 ch) --adaptive_avg_pool--> G [B,3,GH,GW]
 //   proj   = conv1x1(gelu(conv1x1(G)))                  [B,GH,GW,32]      (isp_jbu_range_proj)
 //   kernel = softmax_t(temp * <proj(nbr_t), proj>) * gauss_t, renormalised,
-//            += 0.1 * fixup_mlp([kernel, G])            [B,GH,GW,49] f32  (isp_jbu_kernels)
-//   hr     = bicubic_x2(source)                         (isp_resize_nhwc_bf16)
-//   out    = sum_t kernel_t * hr(reflect(p + t))        [B,GH,GW,C] bf16  (isp_jbu_adaptive_conv)
-// All of it is stencil / per-pixel work: LDS-tiled where a neighbourhood is shared,
-// coalesced 16-byte channel vectors on the feature maps.
+//            += 0.1 * fixup_mlp([kernel, G])            [49] per pixel
+//   out    = sum_t kernel_t * hr(reflect(p + t)),  hr = bicubic_x2(source)
+//
+// MI355X formulation: bicubic x2 and the 7x7 stencil are both linear in `source`, so their
+// composition is ONE 8x8 stencil on the LOW-RES source per output pixel.  isp_jbu_kernels
+// emits that composite kernel (bf16, [B,GH,GW,8 rows,16 circular column slots]); isp_jbu_apply
+// evaluates it with MFMA as banded GEMMs over 16-pixel strips.  The x2 feature map `hr` (6.4 GB
+// at 512^2 x 384 ch x 32 images) never exists, in HBM or anywhere else.
 #include "isp_common.h"
 
 namespace {
@@ -76,10 +79,16 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
 // in LDS (pixel stride padded to 36 floats against bank conflicts).
 constexpr int TS = 16, HALO = TS + 2 * R, PSTRIDE = 36;
 
+// Composite-kernel tables (host-built, depend only on the output size):
+//   bys[y][ty][ry]  : weight of window row ry (src row base_y(y)+ry) in hr row reflect(y+ty-3)
+//   bxs[x][tx][slot]: same for columns, indexed by the CIRCULAR slot (src col & 15)
+// base(y) = ((y-4)>>1) - 1;  an hr index q reads src rows ((q-1)>>1)-1 .. +2 with the cubic
+// (A=-0.75) weights at t = 0.75 (q even) / 0.25 (q odd).
 __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restrict__ proj, const float* __restrict__ G,
-                                                           float* __restrict__ kout, const float* __restrict__ f0w,
+                                                           bf16_t* __restrict__ kout, const float* __restrict__ f0w,
                                                            const float* __restrict__ f0b, const float* __restrict__ f3wT,
-                                                           const float* __restrict__ f3b, float temp, float inv2s2,
+                                                           const float* __restrict__ f3b, const float* __restrict__ bys,
+                                                           const float* __restrict__ bxs, float temp, float inv2s2,
                                                            int GH, int GW) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);
@@ -153,68 +162,167 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
 #pragma unroll
         for (int m = 0; m < TAPS; ++m) fix[m] += wc[m] * h;
     }
-    float* o = kout + ((size_t)b * HW + p) * TAPS;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) o[t] = k[t] + 0.1f * fix[t];
+    for (int t = 0; t < TAPS; ++t) k[t] += 0.1f * fix[t];
+    // composite 8x8 kernel on the source grid: rows first (hrow[ry][tx] = sum_ty by[ty][ry] k[ty][tx],
+    // k is dead afterwards), then the two halves of the 16 circular column slots
+    const float* byp = bys + (size_t)y * (DIA * 8);
+    const float* bxp = bxs + (size_t)x * (DIA * 16);
+    bf16_t* o = kout + ((size_t)b * HW + p) * 128;
+    float hrow[8][DIA];
+#pragma unroll
+    for (int ry = 0; ry < 8; ++ry)
+#pragma unroll
+        for (int tx = 0; tx < DIA; ++tx) hrow[ry][tx] = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < DIA; ++ty) {
+        const float4 c0 = *reinterpret_cast<const float4*>(byp + ty * 8);
+        const float4 c1 = *reinterpret_cast<const float4*>(byp + ty * 8 + 4);
+        const float by[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int ry = 0; ry < 8; ++ry)
+#pragma unroll
+            for (int tx = 0; tx < DIA; ++tx) hrow[ry][tx] += by[ry] * k[ty * DIA + tx];
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        float bx[DIA][8];
+#pragma unroll
+        for (int tx = 0; tx < DIA; ++tx) {
+            const float4 b0 = *reinterpret_cast<const float4*>(bxp + tx * 16 + half * 8);
+            const float4 b1 = *reinterpret_cast<const float4*>(bxp + tx * 16 + half * 8 + 4);
+            bx[tx][0] = b0.x, bx[tx][1] = b0.y, bx[tx][2] = b0.z, bx[tx][3] = b0.w;
+            bx[tx][4] = b1.x, bx[tx][5] = b1.y, bx[tx][6] = b1.z, bx[tx][7] = b1.w;
+        }
+#pragma unroll
+        for (int ry = 0; ry < 8; ++ry) {
+            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tx = 0; tx < DIA; ++tx)
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) r[s8] += hrow[ry][tx] * bx[tx][s8];
+            *reinterpret_cast<uint4*>(o + ry * 16 + half * 8) =
+                make_uint4(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]), pack2bf(r[4], r[5]), pack2bf(r[6], r[7]));
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------
-// Adaptive 7x7 convolution with reflect padding.  A thread owns 4 horizontally adjacent
-// output pixels x 8 channels: each row of the window costs 10 16-byte loads for 4 x 7 taps
-// (17.5 loads per output instead of 49); consecutive lanes are consecutive channel chunks of
-// the same pixels, so the per-pixel kernel weights are wave-broadcast loads.
-__global__ __launch_bounds__(256) void jbu_adaptive_conv_kernel(const bf16_t* __restrict__ hr,
-                                                                 const float* __restrict__ kern,
-                                                                 bf16_t* __restrict__ out, int GH, int GW, int C,
-                                                                 long total) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int cv = C >> 3, gx = (GW + 3) >> 2;
-    const int c8 = (int)(idx % cv);
-    long t = idx / cv;
-    const int x0 = (int)(t % gx) * 4;
-    t /= gx;
-    const int y = (int)(t % GH);
-    const int b = (int)(t / GH);
-    const bf16_t* base = hr + (size_t)b * GH * GW * C + c8 * 8;
-    const float* kbase = kern + ((size_t)b * GH * GW + (size_t)y * GW) * TAPS;
-    float acc[4][8];
+// Apply the composite kernels: out[b,y,x,:] = sum_{ry,rx} kc[b,y,x][ry][rx] * src[b, clamp(base_y+ry),
+// clamp(base_x+rx), :].  Block = 8 rows x 16 cols of output pixels, all channels (looped in
+// chunks of 64).  Per 16-pixel strip and window row ry the 16 per-pixel kernels form a banded
+// [32 src cols x 16 px] matrix (k = src column inside the tile, 24 used) that is the B operand
+// of v_mfma_f32_16x16x32_bf16; the A operand is the transposed source row ([16 ch x 32 cols])
+// read from the [pixel][channel] LDS tile with ds_read_b64_tr_b16.  D[ch][px] lands with 4
+// consecutive channels per lane (8-byte stores).
+//   LDS: source tile 11 rows x 24 cols x 64 ch bf16 (33 KiB, 16-B chunks XOR-swizzled so the
+//        transposed reads are conflict-free) + kernel tile [8 strips][8 ry][16 px][16 slots]
+//        bf16 (32 KiB)  -> 2 blocks per CU.
+//   The band fragments (8 per strip) live in registers across the channel loop.
+constexpr int ATH = 8, ATW = 16, ACC = 64;
+constexpr int SROWS = 11, SCOLS = 24, SPIX = SROWS * SCOLS;                   // 264 source pixels
+constexpr int SRC_TILE_BYTES = ((SPIX + 7) / 8) * 8 * ACC * 2;                // padded to whole 1 KiB pieces
+constexpr int KC_TILE_BYTES = ATH * 8 * ATW * 32;
+constexpr int APPLY_LDS = SRC_TILE_BYTES + KC_TILE_BYTES;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ int src_swz(int pix, int chunk) {  // 16-B chunk swizzle of the source tile
+    return chunk ^ ((((pix >> 1) & 1) << 2) | (((pix >> 3) & 1) << 1));
+}
+
+__global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ kc,
+                                                           bf16_t* __restrict__ out, int h, int w, int C, int tiles_x,
+                                                           int tiles_y, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_src = smem;
+    char* s_kc = smem + SRC_TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int GH = 2 * h, GW = 2 * w;
+    int wg = xcd_remap(blockIdx.x, nwg);
+    const int tx = wg % tiles_x;
+    wg /= tiles_x;
+    const int ty = wg % tiles_y, b = wg / tiles_y;
+    const int y0 = ty * ATH, x0 = tx * ATW;
+    const int tile_y0 = ((y0 - 4) >> 1) - 1;                 // base_y(y0)
+    const int tile_x0 = (((x0 - 4) >> 1) - 1) & ~7;          // base_x(x0) rounded down to a multiple of 8
+
+    // ---- stage the kernel tile: global [pixel][8 ry][16 slots] -> LDS [strip][ry][px][16 slots]
+    for (int i = tid; i < ATH * ATW * 16; i += 256) {   // one 16-byte half-row per item
+        const int half = i & 1, ry = (i >> 1) & 7, px = (i >> 4) & 15, strip = i >> 8;
+        const int gy = min(y0 + strip, GH - 1), gx = min(x0 + px, GW - 1);
+        const uint4 v = *reinterpret_cast<const uint4*>(kc + (((size_t)b * GH + gy) * GW + gx) * 128 + ry * 16 + half * 8);
+        *reinterpret_cast<uint4*>(s_kc + ((strip * 8 + ry) * ATW + px) * 32 + half * 16) = v;
+    }
+    __syncthreads();
+    // ---- band fragments: lane (px = lane&15, g = lane>>4) holds, per ry, the 8 slots of src cols
+    // tile_x0 + 8g .. +7; zero unless that chunk overlaps the pixel's window [base_x, base_x+8)
+    const int px = lane & 15, g = lane >> 4;
+    bf16x8 band[2][8];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int si = 0; si < 2; ++si) {
+        const int strip = wid * 2 + si;
+        const int gx = min(x0 + px, GW - 1);
+        const int bx = ((gx - 4) >> 1) - 1;
+        const int X = tile_x0 + 8 * g;
+        const bool live = g < 3 && X > bx - 8 && X < bx + 8;
+        const int half = (X >> 3) & 1;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[p][c] = 0.f;
-#pragma unroll 1
-    for (int i = 0; i < DIA; ++i) {
-        const bf16_t* rowp = base + (size_t)reflect(y + i - R, GH) * GW * C;
-        float v[10][8];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) {
-            const int xs = reflect(min(x0 + q - R, GW - 1 + R), GW);
-            const uint4 u = *reinterpret_cast<const uint4*>(rowp + (size_t)xs * C);
-            const unsigned* w = &u.x;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[q][2 * e] = __uint_as_float(w[e] << 16);
-                v[q][2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const float* kp = kbase + (size_t)min(x0 + p, GW - 1) * TAPS + i * DIA;
-#pragma unroll
-            for (int j = 0; j < DIA; ++j) {
-                const float wgt = kp[j];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[p][c] += wgt * v[p + j][c];
-            }
+        for (int ry = 0; ry < 8; ++ry) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(s_kc + ((strip * 8 + ry) * ATW + px) * 32 + half * 16);
+            if (!live) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            band[si][ry] = v;
         }
     }
+    // ---- per-lane transposed-read geometry: 16-lane group reads 4 src cols x 16 channels
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+    const int gk = (g < 3 ? g : 2) * 8;  // group 3 multiplies a zero band: any finite data will do
+    const size_t src_img = (size_t)b * h * w * C;
+
+    for (int c0 = 0; c0 < C; c0 += ACC) {
+        __syncthreads();  // previous chunk's reads done before the tile is overwritten
+        // stage the source tile: 1 KiB pieces of 8 pixels x 128 B by LDS-DMA, swizzle on the source
+        for (int piece = wid; piece < (SPIX + 7) / 8; piece += 4) {
+            const int pix = piece * 8 + (lane >> 3);
+            const int pr = pix / SCOLS, pc = pix - pr * SCOLS;
+            const int sy = min(max(tile_y0 + pr, 0), h - 1), sx = min(max(tile_x0 + pc, 0), w - 1);
+            const int chunk = src_swz(pix, lane & 7);
+            glds16(src + src_img + ((size_t)sy * w + sx) * C + c0 + chunk * 8, s_src + piece * 1024);
+        }
+        __syncthreads();  // (emits vmcnt(0): the DMA has landed)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (x0 + p >= GW) break;
-        *reinterpret_cast<uint4*>(out + (((size_t)b * GH + y) * GW + x0 + p) * C + c8 * 8) =
-            make_uint4(pack2bf(acc[p][0], acc[p][1]), pack2bf(acc[p][2], acc[p][3]), pack2bf(acc[p][4], acc[p][5]),
-                       pack2bf(acc[p][6], acc[p][7]));
+        for (int si = 0; si < 2; ++si) {
+            const int strip = wid * 2 + si;
+            const int gy = min(y0 + strip, GH - 1);
+            const int r0 = (((gy - 4) >> 1) - 1) - tile_y0;  // first window row inside the tile
+            f32x4 acc[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ry = 0; ry < 8; ++ry) {
+                const int rowpix = (r0 + ry) * SCOLS + gk;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const int pa = rowpix + gq, pb = rowpix + 4 + gq;
+                    const int ch = cb * 2 + (gp >> 1);
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (ISP_LDS s16x4_t*)(s_src + pa * 128 + src_swz(pa, ch) * 16 + (gp & 1) * 8));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (ISP_LDS s16x4_t*)(s_src + pb * 128 + src_swz(pb, ch) * 16 + (gp & 1) * 8));
+                    const bf16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, band[si][ry], acc[cb], 0, 0, 0);
+                }
+            }
+            // D[ch = 4*(lane>>4)+j][px = lane&15]
+            if (y0 + strip < GH && x0 + px < GW) {
+                bf16_t* op = out + (((size_t)b * GH + y0 + strip) * GW + x0 + px) * C + c0 + 4 * g;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    *reinterpret_cast<uint2*>(op + cb * 16) =
+                        make_uint2(pack2bf(acc[cb][0], acc[cb][1]), pack2bf(acc[cb][2], acc[cb][3]));
+            }
+        }
     }
 }
 
@@ -238,11 +346,12 @@ extern "C" int isp_jbu_range_proj(const float* guidance, float* proj, const floa
     return isp_launch_status();
 }
 
-extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, float* kernels, const float* fix0_w,
-                               const float* fix0_b, const float* fix3_wT, const float* fix3_b, float range_temp,
-                               float sigma_spatial, int B, int GH, int GW, void* stream) {
-    ISP_CHECK_ARG(proj && guidance && kernels && fix0_w && fix0_b && fix3_wT && fix3_b && B > 0 && GH >= 4 && GW >= 4);
-    ISP_CHECK_ARG(B <= 65535 && sigma_spatial != 0.f);
+extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const float* fix0_w,
+                               const float* fix0_b, const float* fix3_wT, const float* fix3_b, const float* bys,
+                               const float* bxs, float range_temp, float sigma_spatial, int B, int GH, int GW,
+                               void* stream) {
+    ISP_CHECK_ARG(proj && guidance && kc_bf16 && fix0_w && fix0_b && fix3_wT && fix3_b && bys && bxs);
+    ISP_CHECK_ARG(B > 0 && GH >= 4 && GW >= 4 && GH % 2 == 0 && GW % 2 == 0 && B <= 65535 && sigma_spatial != 0.f);
     const float temp = fminf(fmaxf(expf(range_temp), 1e-4f), 1e4f);
     const float inv2s2 = 1.0f / (2.f * sigma_spatial * sigma_spatial);
     const int lds = HALO * HALO * PSTRIDE * 4;
@@ -254,16 +363,25 @@ extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, float* 
         attr_done = true;
     }
     dim3 grid((GW + TS - 1) / TS, (GH + TS - 1) / TS, B);
-    jbu_kernels_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, kernels, fix0_w, fix0_b, fix3_wT,
-                                                                fix3_b, temp, inv2s2, GH, GW);
+    jbu_kernels_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, (bf16_t*)kc_bf16, fix0_w, fix0_b,
+                                                                fix3_wT, fix3_b, bys, bxs, temp, inv2s2, GH, GW);
     return isp_launch_status();
 }
 
-extern "C" int isp_jbu_adaptive_conv(const void* hr_nhwc_bf16, const float* kernels, void* out_nhwc_bf16, int B,
-                                     int GH, int GW, int C, void* stream) {
-    ISP_CHECK_ARG(hr_nhwc_bf16 && kernels && out_nhwc_bf16 && B > 0 && GH >= 4 && GW >= 4 && C > 0 && C % 8 == 0);
-    const long total = (long)B * GH * ((GW + 3) / 4) * (C / 8);
-    jbu_adaptive_conv_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        (const bf16_t*)hr_nhwc_bf16, kernels, (bf16_t*)out_nhwc_bf16, GH, GW, C, total);
+extern "C" int isp_jbu_apply(const void* src_nhwc_bf16, const void* kc_bf16, void* out_nhwc_bf16, int B, int h, int w,
+                             int C, void* stream) {
+    ISP_CHECK_ARG(src_nhwc_bf16 && kc_bf16 && out_nhwc_bf16 && B > 0 && h >= 2 && w >= 2 && C > 0 && C % ACC == 0);
+    const int tiles_x = (2 * w + ATW - 1) / ATW, tiles_y = (2 * h + ATH - 1) / ATH;
+    const long nwg = (long)tiles_x * tiles_y * B;
+    ISP_CHECK_ARG(nwg <= 0x7fffffffL);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)jbu_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, APPLY_LDS) !=
+            hipSuccess)
+            return ISP_ERR_LAUNCH;
+        attr_done = true;
+    }
+    jbu_apply_kernel<<<(unsigned)nwg, 256, APPLY_LDS, (hipStream_t)stream>>>(
+        (const bf16_t*)src_nhwc_bf16, (const bf16_t*)kc_bf16, (bf16_t*)out_nhwc_bf16, h, w, C, tiles_x, tiles_y, (int)nwg);
     return isp_launch_status();
 }

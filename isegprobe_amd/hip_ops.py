@@ -281,21 +281,56 @@ def jbu_range_proj(g, w0, b0, w3, b3):
     return proj
 
 
+_JBU_TABLES = {}
+
+
+def _cubic(t, A=-0.75):
+    x0, x1, x2, x3 = t + 1.0, t, 1.0 - t, 2.0 - t
+    return (((A * x0 - 5 * A) * x0 + 8 * A) * x0 - 4 * A, ((A + 2) * x1 - (A + 3)) * x1 * x1 + 1,
+            ((A + 2) * x2 - (A + 3)) * x2 * x2 + 1, ((A * x3 - 5 * A) * x3 + 8 * A) * x3 - 4 * A)
+
+
+def jbu_tables(G, device):
+    """Size-only tables of the composite (reflect-pad o bicubic-x2) operator for an output extent G:
+    rows [G,7,8] (window-relative) and cols [G,7,16] (circular slot = src col & 15).  See jbu.hip."""
+    key = (G, str(device))
+    if key not in _JBU_TABLES:
+        import numpy as np
+        rows = np.zeros((G, 7, 8), np.float32)
+        cols = np.zeros((G, 7, 16), np.float32)
+        for y in range(G):
+            base = ((y - 4) >> 1) - 1
+            for t in range(7):
+                q = y + t - 3
+                q = -q if q < 0 else q
+                q = 2 * (G - 1) - q if q >= G else q          # F.pad(mode="reflect")
+                i0 = ((q - 1) >> 1) - 1                       # first of the 4 bicubic source rows
+                w4 = _cubic(0.75 if q % 2 == 0 else 0.25)
+                for a in range(4):
+                    rows[y, t, i0 + a - base] += w4[a]
+                    cols[y, t, (i0 + a) & 15] += w4[a]
+        _JBU_TABLES[key] = (torch.from_numpy(rows).to(device), torch.from_numpy(cols).to(device))
+    return _JBU_TABLES[key]
+
+
 def jbu_kernels(proj, g, f0w, f0b, f3wT, f3b, range_temp, sigma_spatial):
+    """-> composite kernels kc [B,GH,GW,8,16] bf16 (see include/isegprobe_hip.h)."""
     B, GH, GW, _ = proj.shape
-    k = torch.empty(B, GH, GW, 49, device=proj.device, dtype=torch.float32)
-    check(_lib.lib().isp_jbu_kernels(_p(proj), _p(g), _p(k), _p(f0w), _p(f0b), _p(f3wT), _p(f3b), float(range_temp),
-                                     float(sigma_spatial), B, GH, GW, _stream()), "isp_jbu_kernels")
-    return k
+    bys = jbu_tables(GH, proj.device)[0]
+    bxs = jbu_tables(GW, proj.device)[1]
+    kc = torch.empty(B, GH, GW, 8, 16, device=proj.device, dtype=BF16)
+    check(_lib.lib().isp_jbu_kernels(_p(proj), _p(g), _p(kc), _p(f0w), _p(f0b), _p(f3wT), _p(f3b), _p(bys), _p(bxs),
+                                     float(range_temp), float(sigma_spatial), B, GH, GW, _stream()), "isp_jbu_kernels")
+    return kc
 
 
-def jbu_adaptive_conv(hr, kernels):
-    _need(hr, BF16, "hr")
-    _need(kernels, torch.float32, "kernels")
-    B, GH, GW, C = hr.shape
-    out = torch.empty_like(hr)
-    check(_lib.lib().isp_jbu_adaptive_conv(_p(hr), _p(kernels), _p(out), B, GH, GW, C, _stream()),
-          "isp_jbu_adaptive_conv")
+def jbu_apply(src, kc):
+    """src [B,h,w,C] bf16 NHWC, kc [B,2h,2w,8,16] bf16 -> [B,2h,2w,C] bf16."""
+    _need(src, BF16, "src")
+    _need(kc, BF16, "kc")
+    B, h, w, C = src.shape
+    out = torch.empty(B, 2 * h, 2 * w, C, device=src.device, dtype=BF16)
+    check(_lib.lib().isp_jbu_apply(_p(src), _p(kc), _p(out), B, h, w, C, _stream()), "isp_jbu_apply")
     return out
 
 
