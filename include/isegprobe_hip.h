@@ -63,6 +63,8 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
 #define ISP_EP_RESIDUAL_F32 4   /* out f32 += gamma * (v + bias)    LayerScale + residual, block.py:92-117 */
 #define ISP_EP_TOKENS_F32 5     /* out f32 [b*(T+1)+1+t] = v + bias + pos[1+t]   DINOv2.py:523-528 */
 #define ISP_EP_AXPY_RES_BF16 6  /* out bf16 = res + alpha * (v + bias)   FeatUp JBUStack fix-up  */
+#define ISP_EP_BIAS_TAPS_RELU_BF16 7 /* conv3x3 only: relu(v + bias - sum_{taps outside the image} pos[t][n]);
+                                        a per-pixel affine map folded into the conv (see gemm.hip) */
 
 typedef struct isp_epilogue {
     int kind;             /* ISP_EP_* */
@@ -70,10 +72,11 @@ typedef struct isp_epilogue {
     long ldo;             /* row stride of out in elements (0 = N) */
     const float* bias;    /* [N] or NULL */
     const float* gamma;   /* [N] LayerScale or NULL (RESIDUAL) */
-    const float* pos;     /* [(T+1), ldo] interpolated pos-embed or NULL (TOKENS) */
+    const float* pos;     /* [(T+1), ldo] interpolated pos-embed or NULL (TOKENS); [9, N] tap table (BIAS_TAPS) */
     int tokens_per_image; /* T (TOKENS) */
     const void* res;      /* bf16 [M, ldo] residual (AXPY_RES) */
     float alpha;          /* (AXPY_RES) */
+    int img_h, img_w;     /* image extent (BIAS_TAPS) */
 } isp_epilogue;
 
 /* ---- C = A . Wt^T with a fused epilogue.  A [M, lda>=K] bf16, Wt [N,K] bf16, K % 64 == 0,

@@ -7,12 +7,12 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libisegprobe_hip.so")
+LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "libisegprobe_hip.so")  # env override: kernel A/B experiments
 
 ABI_VERSION = 1
 
 ISP_F32, ISP_BF16 = 0, 1
-EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16 = range(7)
+EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16 = range(8)
 
 _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed"}
 
@@ -32,6 +32,8 @@ class Epilogue(ctypes.Structure):
         ("tokens_per_image", ctypes.c_int),
         ("res", ctypes.c_void_p),
         ("alpha", ctypes.c_float),
+        ("img_h", ctypes.c_int),
+        ("img_w", ctypes.c_int),
     ]
 
 

@@ -64,6 +64,32 @@ class _StackedHead(BaseClassifierHead):
         return self._classify(y)
 
 
+    def forward_folded_affine(self, x, Wf, bf, alpha):
+        """forward(z) for z = x + alpha*(Wf x + bf) (per pixel) without materialising z: the map is
+        folded into the first 3x3 conv's weights; its constant part becomes a tap table applied in
+        the conv epilogue (exact at the zero-padded borders)."""
+        first = self.convs[0]
+        if first.conv.kernel_size != (3, 3):
+            raise ValueError("folding needs a 3x3 first layer")
+
+        def build():
+            w = first.conv.weight.detach().float()                       # [N, C, 3, 3]
+            n, c = w.shape[:2]
+            wt = w.permute(0, 2, 3, 1).reshape(n, 9, c)                  # [N, tap, C]
+            folded = wt + alpha * torch.matmul(wt, Wf.float())           # W1_t (I + a Wf)
+            taps = alpha * torch.matmul(wt, bf.float())                  # [N, 9]
+            bias_full = first.conv.bias.detach().float() + taps.sum(1)
+            return (folded.reshape(n, 9 * c).to(BF16).contiguous(), bias_full.contiguous(),
+                    taps.t().contiguous())
+        if not hasattr(self, "_fold_packed"):
+            self._fold_packed = PackedCache()
+        wfold, bias_full, taps = self._fold_packed.get((first.conv.weight, first.conv.bias, Wf, bf), build)
+        y = ops.conv3x3_folded_affine(to_nhwc_bf16(x), wfold, bias_full, taps)
+        for layer in list(self.convs)[1:]:
+            y = layer.run(y)
+        return self._classify(y)
+
+
 class SimpleConvSegHead(_StackedHead):
     """Several 1x1 conv layers."""
 

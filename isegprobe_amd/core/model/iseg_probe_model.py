@@ -13,6 +13,8 @@ from ..utils.serialization import serialize
 from ._tensor import nchw_view, to_nhwc_bf16
 from .featurizers import DINOv2Featurizer
 from .featurizers.utils import PatchEmbed
+from .heads import ConvSegHead
+from .upsamplers import JBUFeatUpUpsampler
 from .iseg_base_model import iSegBaseModel
 
 
@@ -26,6 +28,7 @@ class iSegProbeModel(iSegBaseModel):
                  **kwargs) -> None:
         super().__init__(**kwargs)
         self.save_cfg = save_cfg
+        self.fold_upsampler_affine = True  # cross-plugin weight folding (JBU fix-up -> head conv1); exact algebra
         self.architecture = architecture
         assert backbone_cfg is not None and head_cfg is not None and embed_coords_cfg is not None, \
             "backbone, head and embed_coords configurations must be provided"
@@ -78,6 +81,15 @@ class iSegProbeModel(iSegBaseModel):
 
     def _after_backbone(self, image, backbone_features):
         if self.architecture == "backbone_upsampler_head":
+            if (self.fold_upsampler_affine and isinstance(self.upsampler, JBUFeatUpUpsampler)
+                    and isinstance(self.head, ConvSegHead) and self.head.num_layers >= 1):
+                # JBUStack ends with z = x + 0.1*conv1x1(x); that affine map commutes with the bilinear
+                # resize and folds into the head's first conv: the 2.5 TFLOP 1x1 GEMM disappears
+                hr = self.upsampler.upsampler.forward_stages(backbone_features, image)
+                if image.size()[2:] != hr.size()[2:]:
+                    hr = nchw_view(ops.resize_nhwc(to_nhwc_bf16(hr), image.shape[2], image.shape[3], "bilinear"))
+                Wf, bf, alpha = self.upsampler.upsampler.fixup_affine()
+                return {"instances": self.head.forward_folded_affine(hr, Wf, bf, alpha), "instances_aux": None}
             backbone_features = self.upsampler(source=backbone_features, guidance=image)
             return {"instances": self._resize_and_head(image, backbone_features), "instances_aux": None}
         backbone_features = self.neck(backbone_features, guidance=image)

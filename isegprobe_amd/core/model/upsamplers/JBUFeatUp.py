@@ -64,6 +64,21 @@ class JBUStack(nn.Module):
         self.fixup_proj = nn.Sequential(nn.Dropout2d(0.2), nn.Conv2d(feat_dim, feat_dim, kernel_size=1))
         self._packed = PackedCache()
 
+    def forward_stages(self, source, guidance):
+        """The four x2 stages WITHOUT the final fix-up  x + 0.1*conv1x1(x).  The fix-up is a per-pixel
+        affine map; iSegProbeModel folds it (through the linear resize) into the seg head's first conv."""
+        x = to_nhwc_bf16(source)
+        guidance = guidance.float().contiguous()
+        for up in (self.up1, self.up2, self.up3, self.up4):
+            small = ops.adaptive_avg_pool(guidance, x.shape[1] * 2, x.shape[2] * 2)
+            x = up.run(x, small)
+        return nchw_view(x)
+
+    def fixup_affine(self):
+        """(W [C,C], b [C], alpha): z = x + alpha * (W x + b)."""
+        conv = self.fixup_proj[1]
+        return conv.weight.detach().flatten(1), conv.bias.detach(), 0.1
+
     def forward(self, source, guidance):
         # NB: the frozen upsampler's Dropout2d layers are never applied (the reference's
         # net.train() would switch them on, trainer.py:214 -- a stochastic quirk we do not mirror)

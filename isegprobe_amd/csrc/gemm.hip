@@ -22,48 +22,86 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + W
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;     // double buffered: 64 KiB -> 2 blocks / CU
+constexpr int BK = 64;  // K per step (one 128-byte LDS row of bf16)
+
+// Tile configuration: block tile BM x BN, WM x WN waves; each wave owns (BM/WM) x (BN/WN) as
+// TM x TN MFMA 16x16 tiles.  LDS = 2 stages x (BM + BN) x 128 B.
+template <int BM_, int BN_, int WM_, int WN_, int MINW_>
+struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, MINW = MINW_;
+    static constexpr int NW = WM * WN, THREADS = 64 * NW;
+    static constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    static constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW;  // 1 KiB DMA pieces per wave per stage
+    static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES, LDS = 2 * STAGE;
+    static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile");
+};
+using Cfg128 = TileCfg<128, 128, 2, 2, 2>;    // 4 waves, 64 KiB LDS, 2 blocks / CU   (short-K dense layers)
+// large-K implicit conv: 8 waves, 1 block / CU.  Measured on the seg-head conv (B=8, 448^2, C=N=384):
+// 128x128 1050, 256x128 1050, 128x384 1127, 256x192 1161 TFLOP/s.
+using CfgConv192 = TileCfg<256, 192, 4, 2, 2>;  // 112 KiB LDS; N % 192 == 0
+using CfgConv128 = TileCfg<256, 128, 4, 2, 2>;  // 96 KiB LDS
 
 // ------------------------------------------------------------------------------ A loaders
-// A loader contract: init(row_slot i, global row m) once per lane for its 4 DMA rows;
-// src(i, kstep, logical 16-B chunk) -> per-lane global address of 8 bf16.
+// Contract: init(slot i, global row m, 16-B source chunk) once per lane per DMA row slot;
+// ptr(i) = current per-lane source address (8 bf16); advance() steps every slot one K-step on.
+template <int NS>
 struct DenseA {
     const bf16_t* A;
     long lda;
-    int M;
-    const bf16_t* rowp[4];
-    __device__ __forceinline__ void init(int i, long m) { rowp[i] = A + (size_t)(m < M ? m : M - 1) * lda; }
-    __device__ __forceinline__ const void* src(int i, int kstep, int chunk) const {
-        return rowp[i] + kstep * BK + chunk * 8;
+    long M;
+    const bf16_t* cur[NS];
+    __device__ __forceinline__ void init(int i, long m, int chunk) {
+        cur[i] = A + (size_t)(m < M ? m : M - 1) * lda + chunk * 8;
+    }
+    __device__ __forceinline__ const void* ptr(int i) const { return cur[i]; }
+    __device__ __forceinline__ void advance() {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) cur[i] += BK;
     }
 };
 
 // Implicit GEMM for a 3x3, stride 1, pad 1 convolution on an NHWC bf16 map with C % 64 == 0:
-// row m = flat output pixel, K index = tap*C + c, tap = (dy+1)*3 + (dx+1).
+// row m = flat output pixel, K index = tap*C + c, tap = (dy+1)*3 + (dx+1).  Addresses are
+// incremental: within a tap a slot advances by 64 channels (or stays on the zero constant when
+// the tap is outside the image); the tap change recomputes the slot bases.
+template <int NS>
 struct Conv3x3A {
     const bf16_t* in;
     int H, W, C;
     long M;
     int cblocks;  // C / 64
-    const bf16_t* pix[4];
-    int yy[4], xx[4];
-    __device__ __forceinline__ void init(int i, long m) {
+    int tap, cb;  // wave-uniform iteration state
+    const bf16_t* pix[NS];
+    const bf16_t* cur[NS];
+    int yy[NS], xx[NS], inc[NS];
+    __device__ __forceinline__ void set_tap(int i) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const bool ok = (unsigned)(yy[i] + dy) < (unsigned)H && (unsigned)(xx[i] + dx) < (unsigned)W;
+        cur[i] = ok ? pix[i] + ((long)dy * W + dx) * C : reinterpret_cast<const bf16_t*>(g_isp_zero16);
+        inc[i] = ok ? BK : 0;
+    }
+    __device__ __forceinline__ void init(int i, long m, int chunk) {
         if (m >= M) m = M - 1;
         const unsigned hw = (unsigned)H * (unsigned)W;  // M < 2^31 is checked on the host
         const unsigned rem = (unsigned)m % hw;
         yy[i] = (int)(rem / (unsigned)W);
         xx[i] = (int)(rem % (unsigned)W);
-        pix[i] = in + (size_t)m * C;
+        pix[i] = in + (size_t)m * C + chunk * 8;
+        tap = 0;
+        cb = 0;
+        set_tap(i);
     }
-    __device__ __forceinline__ const void* src(int i, int kstep, int chunk) const {
-        const int tap = kstep / cblocks, cb = kstep - tap * cblocks;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const bool ok = (unsigned)(yy[i] + dy) < (unsigned)H && (unsigned)(xx[i] + dx) < (unsigned)W;
-        const bf16_t* p = pix[i] + ((long)dy * W + dx) * C + cb * BK + chunk * 8;
-        return ok ? (const void*)p : (const void*)g_isp_zero16;
+    __device__ __forceinline__ const void* ptr(int i) const { return cur[i]; }
+    __device__ __forceinline__ void advance() {
+        if (++cb == cblocks) {  // uniform branch
+            cb = 0;
+            ++tap;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) set_tap(i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) cur[i] += inc[i];
+        }
     }
 };
 
@@ -141,6 +179,36 @@ struct EpAxpyResBf16 {  // out = res + alpha * (v + bias), bf16 in/out (FeatUp J
     }
 };
 
+// relu(v + bias[n] - sum over the 3x3 taps that fall OUTSIDE the image of taps[t][n]), bf16 out.
+// Used when a per-pixel affine map z = (I + aW)x + a*b in front of a zero-padded 3x3 conv is folded
+// into the conv weights: the constant part a*b only contributes through taps inside the image.
+// `bias` already holds b_conv + sum_t taps[t]; border pixels subtract their missing taps.
+struct EpBiasTapsReluBf16 {
+    bf16_t* out;
+    const float* bias;
+    const float* taps;  // [9][ldo]
+    int H, W;
+    long ldo;
+    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
+        float4 b = *reinterpret_cast<const float4*>(bias + n);
+        const unsigned rem = (unsigned)m % ((unsigned)H * (unsigned)W);
+        const int y = (int)(rem / (unsigned)W), x = (int)(rem % (unsigned)W);
+        if (y == 0 || y == H - 1 || x == 0 || x == W - 1) {
+#pragma unroll 1
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) {
+                    const float4 tv = *reinterpret_cast<const float4*>(taps + (size_t)t * ldo + n);
+                    b.x -= tv.x, b.y -= tv.y, b.z -= tv.z, b.w -= tv.w;
+                }
+            }
+        }
+        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) =
+            make_uint2(pack2bf(fmaxf(v[0] + b.x, 0.f), fmaxf(v[1] + b.y, 0.f)),
+                       pack2bf(fmaxf(v[2] + b.z, 0.f), fmaxf(v[3] + b.w, 0.f)));
+    }
+};
+
 struct EpTokens {  // patch-embed: token row b*(T+1)+1+t gets v + bias[n] + pos[1+t][n]
     float* x;
     const float* bias;  // b_img + b_click, pre-summed
@@ -160,9 +228,10 @@ struct EpTokens {  // patch-embed: token row b*(T+1)+1+t gets v + bias[n] + pos[
 // ------------------------------------------------------------------------------ the engine
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-template <class AL, class EP>
-__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(AL al, const bf16_t* __restrict__ Wt, long M, int N, int K,
-                                                           int tiles_n, int nwg, EP ep) {
+template <class CFG, class AL, class EP>
+__global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL al, const bf16_t* __restrict__ Wt, long M,
+                                                                          int N, int K, int tiles_n, int nwg, EP ep) {
+    constexpr int BM = CFG::BM, BN = CFG::BN, NW = CFG::NW, TM = CFG::TM, TN = CFG::TN, PA = CFG::PA, PW = CFG::PW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,75 +241,83 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(AL al, const bf16_t* 
     const long m0 = tm * BM;
     const int n0 = tn * BN;
 
-    // --- staging assignment: wave `wid` issues DMA pieces 4*wid .. 4*wid+3 of each operand
-    // tile; piece q covers tile rows 8q..8q+7 (1 KiB).  Lane -> (row = 8q + lane/8, phys
-    // chunk = lane%8), source chunk = swz(row, phys).
+    // --- staging assignment: wave `wid` issues DMA pieces wid, wid+NW, ... of each operand tile;
+    // piece q covers tile rows 8q..8q+7 (1 KiB).  Lane -> (row = 8q + lane/8, phys chunk =
+    // lane%8), source chunk = swz(row, phys).
     const int lrow = lane >> 3, pchunk = lane & 7;
-    int a_chunk[4];
-    const bf16_t* w_src[4];
+    const bf16_t* w_src[PW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wid * 4 + i) * 8 + lrow;
-        a_chunk[i] = swz(row, pchunk);
-        al.init(i, m0 + row);
-        const int n = n0 + row;
-        w_src[i] = Wt + (size_t)(n < N ? n : N - 1) * K + a_chunk[i] * 8;
+    for (int i = 0; i < PA; ++i) {
+        const int row = (wid + i * NW) * 8 + lrow;
+        al.init(i, m0 + row, swz(row, pchunk));
     }
-    auto stage = [&](int kstep, char* buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(al.src(i, kstep, a_chunk[i]), buf + (wid * 4 + i) * 1024);
+    for (int i = 0; i < PW; ++i) {
+        const int row = (wid + i * NW) * 8 + lrow;
+        const int n = n0 + row;
+        w_src[i] = Wt + (size_t)(n < N ? n : N - 1) * K + swz(row, pchunk) * 8;
+    }
+    auto stage = [&](char* buf) {  // issues the DMA of the NEXT un-staged K-step and moves the cursors on
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(w_src[i] + (size_t)kstep * BK, buf + TILE_BYTES + (wid * 4 + i) * 1024);
+        for (int i = 0; i < PA; ++i) glds16(al.ptr(i), buf + (wid + i * NW) * 1024);
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            glds16(w_src[i], buf + CFG::A_BYTES + (wid + i * NW) * 1024);
+            w_src[i] += BK;
+        }
+        al.advance();
     };
 
-    // --- fragment read addresses (bytes inside an operand tile)
-    const int wm = wid >> 1, wn = wid & 1;
+    // --- fragment read addresses (bytes inside a stage)
+    const int wm = wid / CFG::WN, wn = wid % CFG::WN;
     const int fr = lane & 15, fq = lane >> 4;
-    int a_off[4][2], w_off[4][2];
+    int a_off[TM][2], w_off[TN][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int ra = wm * 64 + t * 16 + fr, rw = wn * 64 + t * 16 + fr;
+    for (int t = 0; t < TM; ++t) {
+        const int ra = wm * (TM * 16) + t * 16 + fr;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            a_off[t][ks] = ra * 128 + swz(ra, ks * 4 + fq) * 16;
-            w_off[t][ks] = TILE_BYTES + rw * 128 + swz(rw, ks * 4 + fq) * 16;
-        }
+        for (int ks = 0; ks < 2; ++ks) a_off[t][ks] = ra * 128 + swz(ra, ks * 4 + fq) * 16;
+    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int rw = wn * (TN * 16) + t * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) w_off[t][ks] = CFG::A_BYTES + rw * 128 + swz(rw, ks * 4 + fq) * 16;
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](const char* buf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fw[4];
+            bf16x8 fa[TM], fw[TN];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                fa[t] = *reinterpret_cast<const bf16x8*>(buf + a_off[t][ks]);
-                fw[t] = *reinterpret_cast<const bf16x8*>(buf + w_off[t][ks]);
-            }
+            for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const bf16x8*>(buf + a_off[t][ks]);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int t = 0; t < TN; ++t) fw[t] = *reinterpret_cast<const bf16x8*>(buf + w_off[t][ks]);
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][ni], 0, 0, 0);
         }
     };
 
     const int nk = K / BK;
     char* buf0 = smem;
-    char* buf1 = smem + STAGE_BYTES;
-    stage(0, buf0);
+    char* buf1 = smem + CFG::STAGE;
+    stage(buf0);
     __syncthreads();
     int kt = 0;
     for (; kt + 2 <= nk; kt += 2) {  // unrolled by 2 so both LDS buffers are compile-time constants
-        stage(kt + 1, buf1);
+        stage(buf1);
         compute(buf0);
         __syncthreads();
-        if (kt + 2 < nk) stage(kt + 2, buf0);
+        if (kt + 2 < nk) stage(buf0);
         compute(buf1);
         __syncthreads();
     }
@@ -248,12 +325,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(AL al, const bf16_t* 
 
     // --- epilogue: lane holds, for mi/ni, row m = .. + fr and 4 consecutive n = .. + 4*fq + j
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const long m = m0 + wm * 64 + mi * 16 + fr;
+    for (int mi = 0; mi < TM; ++mi) {
+        const long m = m0 + wm * (TM * 16) + mi * 16 + fr;
         if (m >= M) continue;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = n0 + wn * 64 + ni * 16 + fq * 4;
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * (TN * 16) + ni * 16 + fq * 4;
             if (n >= N) continue;
             const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
             ep(m, n, v);
@@ -261,47 +338,68 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(AL al, const bf16_t* 
     }
 }
 
-template <class AL, class EP>
+template <class CFG, class AL, class EP>
 int launch_gemm(AL al, const void* Wt, long M, int N, int K, EP ep, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 4 != 0) return ISP_ERR_INVALID;
-    const long tiles_m = (M + BM - 1) / BM;
-    const int tiles_n = (N + BN - 1) / BN;
+    const long tiles_m = (M + CFG::BM - 1) / CFG::BM;
+    const int tiles_n = (N + CFG::BN - 1) / CFG::BN;
     const long nwg = tiles_m * tiles_n;
     if (nwg > 0x7fffffffL) return ISP_ERR_INVALID;
     static bool attr_done = false;  // per instantiation; raising the dynamic-LDS cap is idempotent
-    auto kern = gemm_tile_kernel<AL, EP>;
+    auto kern = gemm_tile_kernel<CFG, AL, EP>;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS) != hipSuccess)
             return ISP_ERR_LAUNCH;
         attr_done = true;
     }
-    kern<<<(unsigned)nwg, 256, LDS_BYTES, s>>>(al, (const bf16_t*)Wt, M, N, K, tiles_n, (int)nwg, ep);
+    kern<<<(unsigned)nwg, CFG::THREADS, CFG::LDS, s>>>(al, (const bf16_t*)Wt, M, N, K, tiles_n, (int)nwg, ep);
     return isp_launch_status();
 }
 
-template <class AL>
+template <class CFG, class AL, unsigned KINDS = 0xffffffffu>  // KINDS: bit mask of epilogue kinds to instantiate
 int dispatch_epilogue(AL al, const void* Wt, long M, int N, int K, const isp_epilogue* e, hipStream_t s) {
     if (!e || !e->out) return ISP_ERR_INVALID;
+    if (e->kind < 0 || e->kind > 31 || !((KINDS >> e->kind) & 1u)) return ISP_ERR_UNSUPPORTED;
     const long ldo = e->ldo > 0 ? e->ldo : N;
     if (ldo % 4 != 0) return ISP_ERR_INVALID;
     switch (e->kind) {
         case ISP_EP_BIAS_BF16:
-            return launch_gemm(al, Wt, M, N, K, EpBiasActBf16<ACT_NONE>{(bf16_t*)e->out, e->bias, ldo}, s);
+            if constexpr (!((KINDS >> ISP_EP_BIAS_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpBiasActBf16<ACT_NONE>{(bf16_t*)e->out, e->bias, ldo}, s);
+            }
         case ISP_EP_BIAS_RELU_BF16:
-            return launch_gemm(al, Wt, M, N, K, EpBiasActBf16<ACT_RELU>{(bf16_t*)e->out, e->bias, ldo}, s);
+            if constexpr (!((KINDS >> ISP_EP_BIAS_RELU_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpBiasActBf16<ACT_RELU>{(bf16_t*)e->out, e->bias, ldo}, s);
+            }
         case ISP_EP_BIAS_GELU_BF16:
-            return launch_gemm(al, Wt, M, N, K, EpBiasActBf16<ACT_GELU>{(bf16_t*)e->out, e->bias, ldo}, s);
+            if constexpr (!((KINDS >> ISP_EP_BIAS_GELU_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpBiasActBf16<ACT_GELU>{(bf16_t*)e->out, e->bias, ldo}, s);
+            }
         case ISP_EP_BIAS_F32:
-            return launch_gemm(al, Wt, M, N, K, EpBiasActF32<ACT_NONE>{(float*)e->out, e->bias, ldo}, s);
+            if constexpr (!((KINDS >> ISP_EP_BIAS_F32) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpBiasActF32<ACT_NONE>{(float*)e->out, e->bias, ldo}, s);
+            }
         case ISP_EP_RESIDUAL_F32:
-            return launch_gemm(al, Wt, M, N, K, EpResidual{(float*)e->out, e->bias, e->gamma, ldo}, s);
+            if constexpr (!((KINDS >> ISP_EP_RESIDUAL_F32) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpResidual{(float*)e->out, e->bias, e->gamma, ldo}, s);
+            }
         case ISP_EP_TOKENS_F32:
+            if constexpr (!((KINDS >> ISP_EP_TOKENS_F32) & 1u)) return ISP_ERR_UNSUPPORTED; else {
             if (e->tokens_per_image <= 0 || !e->bias) return ISP_ERR_INVALID;
-            return launch_gemm(al, Wt, M, N, K, EpTokens{(float*)e->out, e->bias, e->pos, e->tokens_per_image, ldo}, s);
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpTokens{(float*)e->out, e->bias, e->pos, e->tokens_per_image, ldo}, s);
+            }
         case ISP_EP_AXPY_RES_BF16:
+            if constexpr (!((KINDS >> ISP_EP_AXPY_RES_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
             if (!e->res) return ISP_ERR_INVALID;
-            return launch_gemm(al, Wt, M, N, K,
+            return launch_gemm<CFG>(al, Wt, M, N, K,
                                EpAxpyResBf16{(bf16_t*)e->out, (const bf16_t*)e->res, e->bias, e->alpha, ldo}, s);
+            }
+        case ISP_EP_BIAS_TAPS_RELU_BF16:
+            if constexpr (!((KINDS >> ISP_EP_BIAS_TAPS_RELU_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            if (!e->bias || !e->pos || e->img_h <= 0 || e->img_w <= 0 || ldo != N) return ISP_ERR_INVALID;
+            return launch_gemm<CFG>(al, Wt, M, N, K,
+                               EpBiasTapsReluBf16{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
+            }
         default:
             return ISP_ERR_UNSUPPORTED;
     }
@@ -312,24 +410,32 @@ int dispatch_epilogue(AL al, const void* Wt, long M, int N, int K, const isp_epi
 extern "C" int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* ep,
                              void* stream) {
     ISP_CHECK_ARG(A && Wt && lda >= K && lda % 8 == 0);
-    DenseA al;
+    DenseA<Cfg128::PA> al;
     al.A = (const bf16_t*)A;
     al.lda = lda;
-    al.M = (int)M;
-    ISP_CHECK_ARG(M <= 0x7fffffffL);
-    return dispatch_epilogue(al, Wt, M, N, K, ep, (hipStream_t)stream);
+    al.M = M;
+    return dispatch_epilogue<Cfg128, DenseA<Cfg128::PA>, 0x7fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
 }
 
 extern "C" int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int H, int W, int C, int N,
                                      const isp_epilogue* ep, void* stream) {
     ISP_CHECK_ARG(in && Wt && B > 0 && H > 0 && W > 0 && C > 0 && C % BK == 0);
-    Conv3x3A al;
-    al.in = (const bf16_t*)in;
-    al.H = H;
-    al.W = W;
-    al.C = C;
-    al.M = (long)B * H * W;
-    ISP_CHECK_ARG(al.M <= 0x7fffffffL);
-    al.cblocks = C / BK;
-    return dispatch_epilogue(al, Wt, al.M, N, 9 * C, ep, (hipStream_t)stream);
+    const long M = (long)B * H * W;
+    ISP_CHECK_ARG(M <= 0x7fffffffL);
+    constexpr unsigned CONV_KINDS = (1u << ISP_EP_BIAS_BF16) | (1u << ISP_EP_BIAS_RELU_BF16) | (1u << ISP_EP_BIAS_F32) |
+                                    (1u << ISP_EP_BIAS_TAPS_RELU_BF16);
+    auto run = [&](auto cfg) {
+        using CFG = decltype(cfg);
+        Conv3x3A<CFG::PA> al;
+        al.in = (const bf16_t*)in;
+        al.H = H;
+        al.W = W;
+        al.C = C;
+        al.M = M;
+        al.cblocks = C / BK;
+        return dispatch_epilogue<CFG, Conv3x3A<CFG::PA>, CONV_KINDS>(al, Wt, M, N, 9 * C, ep, (hipStream_t)stream);
+    };
+    if (N % 192 == 0) return run(CfgConv192{});
+    if (N > 64) return run(CfgConv128{});
+    return run(Cfg128{});
 }

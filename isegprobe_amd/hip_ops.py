@@ -139,6 +139,23 @@ def conv3x3(x, Wt, bias=None, act="relu", out_dtype=BF16):
     return out
 
 
+def conv3x3_folded_affine(x, Wt, bias_full, taps):
+    """conv3x3 + ReLU whose input carries a folded per-pixel affine map: `bias_full` = conv bias +
+    sum of the 9 tap constants `taps` [9,N]; border pixels drop the taps outside the image."""
+    _need(x, BF16, "x")
+    _need(Wt, BF16, "Wt")
+    _need(bias_full, torch.float32, "bias_full")
+    _need(taps, torch.float32, "taps")
+    B, H, W, C = x.shape
+    N = Wt.shape[0]
+    out = torch.empty(B, H, W, N, device=x.device, dtype=BF16)
+    ep = _epilogue(_lib.EP_BIAS_TAPS_RELU_BF16, out, N, bias_full, pos=taps)
+    ep.img_h, ep.img_w = H, W
+    check(_lib.lib().isp_conv3x3_nhwc_bf16(_p(x), _p(Wt), B, H, W, C, N, ctypes.byref(ep), _stream()),
+          "isp_conv3x3_nhwc_bf16")
+    return out
+
+
 def layernorm(x, gamma, beta, eps, out_dtype=BF16, group_out=0, skip=0, rows_out=None):
     """LayerNorm over the last dim of a [rows, D] f32/bf16 tensor."""
     if x.dtype not in (torch.float32, BF16):

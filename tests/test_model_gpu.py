@@ -100,3 +100,28 @@ def test_s14_bilinear_vs_oracle(size, B):
           f"logit range = {ref.min():.3f}..{ref.max():.3f} rms {ref.pow(2).mean().sqrt():.3f}")
     assert _close(y, ref), err.max().item()
     assert _mask_agreement(y, ref) == 1.0
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_tiny_jbu_model_vs_oracle(fold):
+    """DINOv2(tiny) + FeatUp JBU + ConvSegHead vs the oracle, with and without folding the JBU
+    fix-up affine into the head's first conv (border pixels exercise the tap table)."""
+    from oracle import model as omodel
+    model = build_model("jbu_featup", upsampler_params={"backbone_type": "dinov2", "feat_dim": 128})
+    seeded_(model, 5)
+    model.fold_upsampler_affine = fold
+    w = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(1)
+    image = torch.rand(2, 4, 56, 56)
+    image[:, 3] = (image[:, 3] > 0.7).float()
+    points = torch.from_numpy(rand_points(np.random.default_rng(3), 2, 3, 56, 56))
+    cfg = dict(patch=14, depth=2, heads=2, upsampler="jbu_featup", injection="before_backbone",
+               with_prev_mask=True, use_disks=True, norm_radius=5)
+    ref = omodel.forward(image, points, w, cfg)
+    with torch.no_grad():
+        y = model.cuda()(image.cuda(), points.cuda())["instances"].cpu()
+    err = (y - ref).abs()
+    print(f"jbu fold={fold}: max {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g} border max "
+          f"{max(err[..., 0, :].max(), err[..., -1, :].max(), err[..., :, 0].max(), err[..., :, -1].max()):.4g}")
+    assert _close(y, ref, TOL_TINY), err.max().item()
+    assert _mask_agreement(y, ref, TOL_TINY) == 1.0
