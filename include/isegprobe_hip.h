@@ -143,6 +143,11 @@ int isp_jbu_apply(const void* src_nhwc_bf16, const void* kc_bf16, void* out_nhwc
 int isp_classifier_fwd(const void* x_nhwc_bf16, const float* weight, float bias, float* out, long M, int C,
                        void* stream);
 
+/* ---- predictor fusion: AddHorizontalFlip.inv_transform + SigmoidForPred.inv_transform
+ * (core/inference/transforms/flip.py:32-36, base_transform.py:39).  logits [2n,1,H,W] (or [n,..]
+ * when with_flip=0) f32 -> probs [n,1,H,W] f32. */
+int isp_fuse_flip_sigmoid(const float* logits, float* probs, long n, int H, int W, int with_flip, void* stream);
+
 /* ---- layout converters between the plugin API (NCHW f32) and the kernels (NHWC bf16).
  * The f32 source is addressed in[b*sb + c*sc + p*sp] so permuted views need no copy. */
 int isp_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int C, long HW, void* stream);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "isp_jbu_range_proj": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "isp_jbu_kernels": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp],
     "isp_jbu_apply": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "isp_fuse_flip_sigmoid": [_vp, _vp, _l, _i, _i, _i, _vp],
     "isp_classifier_fwd": [_vp, _vp, _f, _vp, _l, _i, _vp],
     "isp_nhwc_bf16_to_nchw_f32": [_vp, _vp, _i, _i, _l, _vp],
     "isp_nchw_f32_to_nhwc_bf16": [_vp, _vp, _i, _i, _l, _l, _l, _l, _vp],

@@ -408,3 +408,32 @@ extern "C" int isp_resize_nhwc_bf16(const void* in, void* out, int B, int h, int
         return ISP_ERR_UNSUPPORTED;
     return isp_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------
+// Click-map fusion epilogue of the predictor (reference core/inference/transforms/flip.py:32-36
+// then base_transform.py:39): logits [2n,1,H,W] (second half = predictions on the mirrored
+// image) -> probs [n,1,H,W] = sigmoid(0.5 * (a + flip_w(b))).  with_flip=0: probs = sigmoid(a).
+__global__ __launch_bounds__(256) void fuse_flip_sigmoid_kernel(const float* __restrict__ logits,
+                                                                 float* __restrict__ probs, int W, long plane,
+                                                                 long total, int with_flip) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    float v = logits[idx];
+    if (with_flip) {
+        const long n = idx / plane, p = idx - n * plane;
+        const long row = p / W;
+        const int x = (int)(p - row * W);
+        const float m = logits[total + n * plane + row * W + (W - 1 - x)];
+        v = __fmul_rn(0.5f, __fadd_rn(v, m));  // 0.5 * (prob_map + flipped), as the reference orders it
+    }
+    probs[idx] = 1.0f / (1.0f + expf(-v));
+}
+
+extern "C" int isp_fuse_flip_sigmoid(const float* logits, float* probs, long n, int H, int W, int with_flip,
+                                     void* stream) {
+    ISP_CHECK_ARG(logits && probs && n > 0 && H > 0 && W > 0);
+    const long plane = (long)H * W, total = n * plane;
+    fuse_flip_sigmoid_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(logits, probs, W, plane,
+                                                                                               total, with_flip);
+    return isp_launch_status();
+}

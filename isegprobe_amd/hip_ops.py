@@ -358,3 +358,17 @@ def linear_axpy_res(A, Wt, bias, res, alpha):
     out = torch.empty(A.shape[0], N, device=A.device, dtype=BF16)
     gemm(A, Wt, _epilogue(_lib.EP_AXPY_RES_BF16, out, N, bias, res=res, alpha=alpha))
     return out
+
+
+def fuse_flip_sigmoid(logits, with_flip):
+    """logits [2n,1,H,W] (second half: mirrored image) -> sigmoid(0.5*(a + flip(b))) [n,1,H,W];
+    with_flip=False: sigmoid(logits)."""
+    logits = _need(logits.contiguous(), torch.float32, "logits")
+    N, C, H, W = logits.shape
+    if with_flip and N % 2:
+        raise IspError("flip fusion needs an even batch")
+    n = N // 2 if with_flip else N
+    out = torch.empty(n, C, H, W, device=logits.device, dtype=torch.float32)
+    check(_lib.lib().isp_fuse_flip_sigmoid(_p(logits), _p(out), n * C, H, W, int(with_flip), _stream()),
+          "isp_fuse_flip_sigmoid")
+    return out
