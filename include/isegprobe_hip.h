@@ -93,14 +93,17 @@ int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int H, int W, i
 
 /* ---- LayerNorm over the last dim (fp32 statistics), nn.LayerNorm(eps) of DINOv2.py:98 and
  * loftup/layers.py.  group_out>0 drops `skip` leading rows of every (group_out+skip)-row
- * group of the input (cls-token drop, DINOv2.py:533-534). */
+ * group of the input (cls-token drop, DINOv2.py:533-534).  ld_in / ld_out: row strides in
+ * elements (0 = D); output columns [D, ld_out) are zero-filled (channel padding for the GEMMs). */
 int isp_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, long rows, int D, float eps,
-                      int in_dtype, int out_dtype, int group_out, int skip, void* stream);
+                      int in_dtype, int out_dtype, int group_out, int skip, long ld_in, long ld_out, void* stream);
 
-/* ---- softmax(Q K^T * scale) V, head_dim 64, bf16 in/out, fp32 online softmax; never
+/* ---- softmax(Q K^T * scale) V, head_dim 64 or 128, bf16 in/out, fp32 online softmax; never
  * materialises the score matrix.  Element strides are explicit so the packed qkv tensor of
- * attention.py:56-60 is consumed in place.  Q [B,Lq,H,64], K/V [B,Lk,H,64], O [B,Lq,H,64]. */
-int isp_attention_fwd(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
+ * attention.py:56-60 is consumed in place.  Q [B,Lq,H,hd], K/V [B,Lk,H,hd], O [B,Lq,H,hd].
+ * Also replaces nn.MultiheadAttention in LoftUp's CrossAttentionLayer (loftup/layers.py:182-198),
+ * head_dim 101 zero-padded to 128. */
+int isp_attention_fwd(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, int head_dim,
                       long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
                       long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
 
@@ -137,6 +140,15 @@ int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, con
                     float sigma_spatial, int B, int GH, int GW, void* stream);
 int isp_jbu_apply(const void* src_nhwc_bf16, const void* kc_bf16, void* out_nhwc_bf16, int B, int h, int w, int C,
                   void* stream);
+
+/* ---- LoftUp front end: MinMaxScaler statistics (batch-global per-channel min/max,
+ * loftup/layers.py:61-71; workspace >= C*B*64*2 floats) and the fused ImplicitFeaturizer
+ * (layers.py:107-158, learn_bias, colour feats) + ChannelNorm (layers.py:26-35) producer:
+ * image [B,3,H,W] f32 -> out [B,H,W,ldo] bf16, channels [sin(5F) | cos(5F) | colour(3) | 0...]. */
+int isp_minmax_nchw_f32(const float* x, float* out_c2, float* workspace, int B, int C, long HW, void* stream);
+int isp_loftup_fourier_cn(const float* image, const float* minmax_c2, const float* freqs, const float* bias_sin,
+                          const float* bias_cos, const float* gamma, const float* beta, void* out_bf16, int B, int H,
+                          int W, int n_freqs, int ldo, float eps, void* stream);
 
 /* ---- BaseClassifierHead.classifier (1x1 conv C->1), heads/base_head.py:15.
  * x [M,C] NHWC bf16, weight [C] f32 -> out [M] f32. */

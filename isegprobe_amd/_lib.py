@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "libisegprobe_hip.so")  # env override: kernel A/B experiments
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ISP_F32, ISP_BF16 = 0, 1
 EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16 = range(8)
@@ -48,8 +48,8 @@ SIGNATURES = {
     "isp_patchify_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "isp_gemm_bf16": [_vp, _l, _vp, _l, _i, _i, _EP, _vp],
     "isp_conv3x3_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _EP, _vp],
-    "isp_layernorm_fwd": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _vp],
-    "isp_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
+    "isp_layernorm_fwd": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _l, _l, _vp],
+    "isp_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
     "isp_resize_bilinear_ac_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_resize_bilinear_ac_nchw_f32": [_vp, _vp, _l, _i, _i, _i, _i, _l, _vp],
     "isp_resize_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -59,6 +59,8 @@ SIGNATURES = {
     "isp_jbu_kernels": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp],
     "isp_jbu_apply": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "isp_fuse_flip_sigmoid": [_vp, _vp, _l, _i, _i, _i, _vp],
+    "isp_minmax_nchw_f32": [_vp, _vp, _vp, _i, _i, _l, _vp],
+    "isp_loftup_fourier_cn": [_vp] * 8 + [_i, _i, _i, _i, _i, _f, _vp],
     "isp_classifier_fwd": [_vp, _vp, _f, _vp, _l, _i, _vp],
     "isp_nhwc_bf16_to_nchw_f32": [_vp, _vp, _i, _i, _l, _vp],
     "isp_nchw_f32_to_nhwc_bf16": [_vp, _vp, _i, _i, _l, _l, _l, _l, _vp],

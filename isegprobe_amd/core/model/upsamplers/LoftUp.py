@@ -1,11 +1,264 @@
-"""Placeholder so the registry imports; replaced below."""
+"""LoftUp upsampler (reference core/model/upsamplers/LoftUp.py + loftup/loftup.py:16-177,
+loftup/layers.py): Fourier image features -> 2 x (3x3 conv + BN + ReLU) at full resolution ->
+2-layer cross-attention transformer (queries = every pixel, keys/values = LR tokens + sine PE)
+-> 1x1 conv + channel LayerNorm.
+
+``LoftUp`` / ``ChannelNorm`` / ``UpsamplerwithChannelNorm`` below are parameter containers with
+the reference's state-dict layout (``upsampler.upsampler.*``, ``upsampler.channelnorm.norm.*``
+under ``LoftUpUpsampler``).  The forward pass is HIP launches only:
+
+  * channel dims are zero-padded to multiples of 64 (203 -> 256, 404 -> 448) and the 4 heads'
+    dim 101 to 128, so every projection is a bf16 MFMA GEMM and the padding is exact;
+  * eval-mode BatchNorm is folded into the 3x3 conv weights at pack time;
+  * the cross-attention is the fused flash-style kernel (csrc/attention.hip, head_dim 128): the
+    reference's nn.MultiheadAttention materialises a [B*4, H*W, h*w] weight tensor (3.3 GB per
+    image and layer at 448^2, layers.py:182-198) -- here it never exists;
+  * MinMaxScaler statistics are batch-global (per-shard under data parallelism, as in the
+    reference's DDP).
+Train-mode BatchNorm statistics (the reference's ``net.train()`` quirk, trainer.py:214) are not
+mirrored: the frozen upsampler always uses its running statistics.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from .... import hip_ops as ops
+from ...utils.log import logger
+from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16
 from . import BaseUpsampler
 
 
-class LoftUpUpsampler(BaseUpsampler):
-    def __init__(self, *a, **k):
-        super().__init__()
-        raise NotImplementedError("LoftUpUpsampler: HIP path not built yet")
+def _pad64(n):
+    return (n + 63) // 64 * 64
 
-    def forward(self, source, guidance):
-        raise NotImplementedError
+
+# ------------------------------------------------------------------ parameter containers
+class ChannelNorm(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+
+
+class _ChannelLN(nn.Module):  # loftup/layers.py:38-58 (eps 1e-6)
+    def __init__(self, dim, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+        self.eps = eps
+
+
+class _Implicit(nn.Module):  # ImplicitFeaturizer with learn_bias=True
+    def __init__(self, color_feats, n_freqs):
+        super().__init__()
+        self.n_freqs = n_freqs
+        self.dim_multiplier = 5 if color_feats else 2
+        self.biases = nn.Parameter(torch.randn(2, self.dim_multiplier, n_freqs))
+
+
+class _CrossAttn(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.norm_q = nn.LayerNorm(dim)
+        self.norm_kv = nn.LayerNorm(dim)
+        self.attention = nn.MultiheadAttention(embed_dim=dim, num_heads=heads)
+
+
+class _FeedForward(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.net = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, hidden), nn.GELU(), nn.Identity(),
+                                 nn.Linear(hidden, dim), nn.Identity())
+
+
+class _CATransformer(nn.Module):
+    def __init__(self, dim, depth, heads, mlp_dim):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.layers = nn.ModuleList([nn.ModuleList([_CrossAttn(dim, heads), _FeedForward(dim, mlp_dim)])
+                                     for _ in range(depth)])
+
+
+class LoftUp(nn.Module):
+    def __init__(self, dim, color_feats=True, n_freqs=20, num_heads=4, num_layers=2, num_conv_layers=1, lr_size=16,
+                 lr_pe_type="sine"):
+        super().__init__()
+        if not color_feats or lr_pe_type != "sine":
+            raise NotImplementedError("only the reference's configuration (colour feats, sine LR PE) is built")
+        self.dim, self.n_freqs, self.num_heads, self.num_layers = dim, n_freqs, num_heads, num_layers
+        start_dim = 5 * n_freqs * 2 + 3
+        self.lr_pe_type = lr_pe_type
+        self.lr_pe = _Implicit(False, 5)
+        self.lr_pe_dim = 2 * 5 * 2
+        c = dim + self.lr_pe_dim
+        self.fourier_feat = nn.Sequential(nn.Identity(), _Implicit(True, n_freqs))
+        self.first_conv = nn.Sequential(ChannelNorm(start_dim), nn.Conv2d(start_dim, c, 3, padding=1),
+                                        nn.BatchNorm2d(c), nn.ReLU(inplace=True), nn.Conv2d(c, c, 3, padding=1),
+                                        nn.BatchNorm2d(c), nn.ReLU(inplace=True))
+        self.final_conv = nn.Sequential(nn.Conv2d(c, dim, kernel_size=1), _ChannelLN(dim))
+        self.ca_transformer = _CATransformer(c, num_layers, num_heads, dim)
+
+
+class UpsamplerwithChannelNorm(nn.Module):
+    def __init__(self, upsampler, channelnorm):
+        super().__init__()
+        self.upsampler = upsampler
+        self.channelnorm = channelnorm
+
+
+def load_loftup_checkpoint(upsampler_path, n_dim, lr_pe_type="sine", lr_size=16):
+    """loftup.py:152-177: split a LoftUp checkpoint into the ChannelNorm (``model.1.*``) and the
+    upsampler (``upsampler.*``) parts.  With no readable path the random init is kept."""
+    module = UpsamplerwithChannelNorm(LoftUp(n_dim, lr_pe_type=lr_pe_type, lr_size=16), ChannelNorm(n_dim))
+    if upsampler_path and os.path.exists(str(upsampler_path)):
+        ckpt = torch.load(upsampler_path, map_location="cpu")["state_dict"]
+        module.channelnorm.load_state_dict({k.replace("model.1.", ""): v for k, v in ckpt.items() if "model.1" in k})
+        module.upsampler.load_state_dict({k.replace("upsampler.", "", 1): v for k, v in ckpt.items()
+                                          if k.startswith("upsampler")})
+        logger.info(f"Loaded LoftUp checkpoint: {upsampler_path}")
+    else:
+        logger.info("LoftUpUpsampler: no checkpoint at upsampler_path, keeping random init")
+    for p in module.parameters():
+        p.requires_grad = False
+    return module
+
+
+# ------------------------------------------------------------------ the plugin
+class LoftUpUpsampler(BaseUpsampler):
+    def __init__(self, upsampler_path: str = None, n_dim: int = 384, lr_pe_type: str = "sine", lr_size: int = 16) -> None:
+        super().__init__()
+        self.upsampler = load_loftup_checkpoint(upsampler_path, n_dim, lr_pe_type, lr_size)
+        self._packed = PackedCache()
+        self._pe_cache = {}
+
+    # ---- weight packing (bf16, padded, BN folded)
+    def packed(self):
+        def build():
+            lu, cn = self.upsampler.upsampler, self.upsampler.channelnorm
+            dev = cn.norm.weight.device
+            C, heads = lu.dim, lu.num_heads
+            c = C + lu.lr_pe_dim
+            cp, fin, fin_p = _pad64(c), 10 * lu.n_freqs + 3, _pad64(10 * lu.n_freqs + 3)
+            hd = c // heads
+            hdp = 64 if hd <= 64 else 128
+            if c % heads or hd > 128:
+                raise NotImplementedError("head dim > 128")
+            f32 = lambda t: t.detach().float().contiguous()
+
+            def padded(w, rows, cols):  # [r, k] -> zero-padded bf16 [rows, cols]
+                out = torch.zeros(rows, cols, device=dev, dtype=torch.float32)
+                out[:w.shape[0], :w.shape[1]] = w
+                return out.to(BF16).contiguous()
+
+            def padvec(v, n):
+                out = torch.zeros(n, device=dev, dtype=torch.float32)
+                out[:v.shape[0]] = v
+                return out
+
+            def conv_bn(conv, bn, cin_p, cout_p):  # fold eval BatchNorm, [N,C,3,3] -> [Np, 9*Cp]
+                s = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+                w = conv.weight.detach().float() * s[:, None, None, None]
+                b = (conv.bias.detach().float() - bn.running_mean.float()) * s + bn.bias.detach().float()
+                wt = torch.zeros(cout_p, 3, 3, cin_p, device=dev)
+                wt[:w.shape[0], :, :, :w.shape[1]] = w.permute(0, 2, 3, 1)
+                return wt.reshape(cout_p, 9 * cin_p).to(BF16).contiguous(), padvec(b, cout_p)
+
+            def head_rows(w, b):  # [heads*hd, k] rows -> [heads*hdp, cp]; bias likewise
+                wo = torch.zeros(heads, hdp, cp, device=dev)
+                wo[:, :hd, :c] = w.detach().float().reshape(heads, hd, c)
+                bo = torch.zeros(heads, hdp, device=dev)
+                bo[:, :hd] = b.detach().float().reshape(heads, hd)
+                return wo.reshape(heads * hdp, cp).to(BF16).contiguous(), bo.reshape(-1).contiguous()
+
+            P = dict(C=C, c=c, cp=cp, fin=fin, fin_p=fin_p, heads=heads, hd=hd, hdp=hdp,
+                     cn_w=f32(cn.norm.weight), cn_b=f32(cn.norm.bias), cn_eps=cn.norm.eps,
+                     freqs=torch.exp(torch.linspace(-2, 10, lu.n_freqs)).to(dev),
+                     bias_sin=f32(lu.fourier_feat[1].biases[0].reshape(-1)),
+                     bias_cos=f32(lu.fourier_feat[1].biases[1].reshape(-1)),
+                     fc_cn_w=f32(lu.first_conv[0].norm.weight), fc_cn_b=f32(lu.first_conv[0].norm.bias),
+                     fc_cn_eps=lu.first_conv[0].norm.eps)
+            P["conv1_w"], P["conv1_b"] = conv_bn(lu.first_conv[1], lu.first_conv[2], fin_p, cp)
+            P["conv2_w"], P["conv2_b"] = conv_bn(lu.first_conv[4], lu.first_conv[5], cp, cp)
+            layers = []
+            for ca, ff in lu.ca_transformer.layers:
+                E = c
+                ipw, ipb = ca.attention.in_proj_weight, ca.attention.in_proj_bias
+                L = dict(nq_w=f32(ca.norm_q.weight), nq_b=f32(ca.norm_q.bias), nq_eps=ca.norm_q.eps,
+                         nkv_w=f32(ca.norm_kv.weight), nkv_b=f32(ca.norm_kv.bias), nkv_eps=ca.norm_kv.eps)
+                L["wq"], L["bq"] = head_rows(ipw[:E], ipb[:E])
+                L["wk"], L["bk"] = head_rows(ipw[E:2 * E], ipb[E:2 * E])
+                L["wv"], L["bv"] = head_rows(ipw[2 * E:], ipb[2 * E:])
+                wo = torch.zeros(cp, heads, hdp, device=dev)  # out_proj: input index = head*hd + d
+                wo[:c, :, :hd] = ca.attention.out_proj.weight.detach().float().reshape(c, heads, hd)
+                L["wo"], L["bo"] = wo.reshape(cp, heads * hdp).to(BF16).contiguous(), padvec(f32(ca.attention.out_proj.bias), cp)
+                L["ff_nw"], L["ff_nb"], L["ff_eps"] = f32(ff.net[0].weight), f32(ff.net[0].bias), ff.net[0].eps
+                hid = ff.net[1].weight.shape[0]
+                hid_p = _pad64(hid)
+                L["ff1_w"], L["ff1_b"] = padded(ff.net[1].weight.detach().float(), hid_p, cp), padvec(f32(ff.net[1].bias), hid_p)
+                L["ff2_w"], L["ff2_b"] = padded(ff.net[4].weight.detach().float(), cp, hid_p), padvec(f32(ff.net[4].bias), cp)
+                layers.append(L)
+            P["layers"] = layers
+            nrm = lu.ca_transformer.norm
+            P["tn_w"], P["tn_b"], P["tn_eps"] = f32(nrm.weight), f32(nrm.bias), nrm.eps
+            fc = lu.final_conv[0]
+            P["fin_w"], P["fin_b"] = padded(fc.weight.detach().float().flatten(1), _pad64(C), cp), padvec(f32(fc.bias), _pad64(C))
+            P["fln_w"], P["fln_b"], P["fln_eps"] = f32(lu.final_conv[1].weight), f32(lu.final_conv[1].bias), lu.final_conv[1].eps
+            self._pe_cache.clear()
+            return P
+        params = list(self.upsampler.parameters()) + [b for n, b in self.upsampler.named_buffers() if "running" in n]
+        return self._packed.get(params, build)
+
+    def _lr_pe(self, h, w, device):
+        """Sine PE of the LR grid (ImplicitFeaturizer(color_feats=False, n_freqs=5), layers.py:107-158):
+        depends only on (h, w) and the learnt biases -> a [h*w, 20] table, cached."""
+        key = (h, w, str(device))
+        if key not in self._pe_cache:
+            with torch.no_grad():
+                lu = self.upsampler.upsampler
+                gh, gw = torch.linspace(-1, 1, h, device=device), torch.linspace(-1, 1, w, device=device)
+                grid = torch.stack(torch.meshgrid(gh, gw, indexing="ij"))  # [2,h,w]
+                freqs = torch.exp(torch.linspace(-2, 10, 5, device=device)).reshape(5, 1, 1, 1)
+                feats = grid.unsqueeze(0) * freqs  # [F,2,h,w]
+                bias = lu.lr_pe.biases.detach().float().to(device)
+                s = torch.sin(feats + bias[0].reshape(5, 2, 1, 1)).reshape(10, h, w)
+                c = torch.cos(feats + bias[1].reshape(5, 2, 1, 1)).reshape(10, h, w)
+                self._pe_cache[key] = torch.cat([s, c], 0).permute(1, 2, 0).reshape(h * w, 20).to(BF16).contiguous()
+        return self._pe_cache[key]
+
+    def forward(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
+        P = self.packed()
+        src = to_nhwc_bf16(source)
+        B, h, w, C = src.shape
+        guidance = guidance.float().contiguous()
+        H, W = guidance.shape[2:]
+        c, cp, heads, hdp = P["c"], P["cp"], P["heads"], P["hdp"]
+        M, T = B * H * W, h * w
+        # ---- LR tokens: ChannelNorm(source) ++ sine PE, zero-padded to cp
+        kv = torch.zeros(B, T, cp, device=src.device, dtype=BF16)
+        kv[:, :, :C] = ops.layernorm(src.view(-1, C), P["cn_w"], P["cn_b"], P["cn_eps"]).view(B, T, C)
+        kv[:, :, C:c] = self._lr_pe(h, w, src.device)
+        kv = kv.view(B * T, cp)
+        # ---- queries: Fourier features -> ChannelNorm -> 2 x (conv3x3 + folded BN + ReLU)
+        mm = ops.minmax_nchw(guidance)
+        x = ops.loftup_fourier_cn(guidance, mm, P["freqs"], P["bias_sin"], P["bias_cos"], P["fc_cn_w"], P["fc_cn_b"],
+                                  P["fin_p"], P["fc_cn_eps"])
+        x = ops.conv3x3(x, P["conv1_w"], P["conv1_b"], "relu")
+        x = ops.conv3x3(x, P["conv2_w"], P["conv2_b"], "relu").view(M, cp)
+        scale = P["hd"] ** -0.5
+        for L in P["layers"]:
+            qn = ops.layernorm(x, L["nq_w"], L["nq_b"], L["nq_eps"], D=c, ld_out=cp)
+            kn = ops.layernorm(kv, L["nkv_w"], L["nkv_b"], L["nkv_eps"], D=c, ld_out=cp)
+            q = ops.linear(qn, L["wq"], L["bq"]).view(B, H * W, heads, hdp)
+            k = ops.linear(kn, L["wk"], L["bk"]).view(B, T, heads, hdp)
+            v = ops.linear(kn, L["wv"], L["bv"]).view(B, T, heads, hdp)
+            a = ops.attention(q, k, v, scale).view(M, heads * hdp)
+            x = ops.linear_axpy_res(a, L["wo"], L["bo"], x, 1.0)            # cross-attention + residual
+            f = ops.layernorm(x, L["ff_nw"], L["ff_nb"], L["ff_eps"], D=c, ld_out=cp)
+            f = ops.linear(f, L["ff1_w"], L["ff1_b"], "gelu")
+            x = ops.linear_axpy_res(f, L["ff2_w"], L["ff2_b"], x, 1.0)      # feed-forward + residual
+        x = ops.layernorm(x, P["tn_w"], P["tn_b"], P["tn_eps"], D=c, ld_out=cp)
+        y = ops.linear(x, P["fin_w"], P["fin_b"])                            # 1x1 conv c -> C
+        Cp = y.shape[1]
+        out = ops.layernorm(y, P["fln_w"], P["fln_b"], P["fln_eps"], D=C, ld_out=C)  # channel LayerNorm
+        return nchw_view(out.view(B, H, W, C))

@@ -12,12 +12,12 @@ template <typename TIN, typename TOUT, int MAXV>  // MAXV: float4 chunks per lan
 __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ x, TOUT* __restrict__ y,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, long rows, int D, float eps,
-                                                         int group_out, int skip) {
+                                                         int group_out, int skip, long ld_in, long ld_out) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const long rin = group_out > 0 ? r + (r / group_out + 1) * skip : r;
-    const TIN* xr = x + rin * D;
+    const TIN* xr = x + rin * ld_in;
     const int nchunk = D >> 2;
     float4 v[MAXV];
     float sum = 0.f;
@@ -52,7 +52,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     const float rstd = 1.0f / sqrtf(sq / (float)D + eps);
-    TOUT* yr = y + r * D;
+    TOUT* yr = y + r * ld_out;
+    for (int c = nchunk + lane; c < (int)(ld_out >> 2); c += 64) {  // zero the padding columns [D, ld_out)
+        if constexpr (sizeof(TOUT) == 4) *reinterpret_cast<float4*>(yr + c * 4) = make_float4(0, 0, 0, 0);
+        else *reinterpret_cast<uint2*>(yr + c * 4) = make_uint2(0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
@@ -75,11 +79,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
 
 template <typename TIN, typename TOUT>
 static int launch_ln(const void* x, void* y, const float* g, const float* b, long rows, int D, float eps, int group_out,
-                     int skip, hipStream_t s) {
+                     int skip, long ld_in, long ld_out, hipStream_t s) {
     const int nchunk = D / 4;
     dim3 grid((unsigned)((rows + 3) / 4));
 #define LN_CASE(MV)                                                                                                  \
-    layernorm_kernel<TIN, TOUT, MV><<<grid, 256, 0, s>>>((const TIN*)x, (TOUT*)y, g, b, rows, D, eps, group_out, skip)
+    layernorm_kernel<TIN, TOUT, MV><<<grid, 256, 0, s>>>((const TIN*)x, (TOUT*)y, g, b, rows, D, eps, group_out, skip, \
+                                                         ld_in, ld_out)
     if (nchunk <= 64) LN_CASE(1);
     else if (nchunk <= 128) LN_CASE(2);
     else if (nchunk <= 256) LN_CASE(4);
@@ -90,13 +95,17 @@ static int launch_ln(const void* x, void* y, const float* g, const float* b, lon
 }
 
 extern "C" int isp_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, long rows, int D,
-                                 float eps, int in_dtype, int out_dtype, int group_out, int skip, void* stream) {
+                                 float eps, int in_dtype, int out_dtype, int group_out, int skip, long ld_in,
+                                 long ld_out, void* stream) {
     ISP_CHECK_ARG(x && y && gamma && beta && rows > 0 && D > 0 && D % 4 == 0 && group_out >= 0 && skip >= 0);
+    if (ld_in <= 0) ld_in = D;
+    if (ld_out <= 0) ld_out = D;
+    ISP_CHECK_ARG(ld_in >= D && ld_out >= D && ld_in % 4 == 0 && ld_out % 4 == 0);
     hipStream_t s = (hipStream_t)stream;
-    if (in_dtype == ISP_F32 && out_dtype == ISP_BF16) return launch_ln<float, bf16_t>(x, y, gamma, beta, rows, D, eps, group_out, skip, s);
-    if (in_dtype == ISP_F32 && out_dtype == ISP_F32) return launch_ln<float, float>(x, y, gamma, beta, rows, D, eps, group_out, skip, s);
-    if (in_dtype == ISP_BF16 && out_dtype == ISP_BF16) return launch_ln<bf16_t, bf16_t>(x, y, gamma, beta, rows, D, eps, group_out, skip, s);
-    if (in_dtype == ISP_BF16 && out_dtype == ISP_F32) return launch_ln<bf16_t, float>(x, y, gamma, beta, rows, D, eps, group_out, skip, s);
+    if (in_dtype == ISP_F32 && out_dtype == ISP_BF16) return launch_ln<float, bf16_t>(x, y, gamma, beta, rows, D, eps, group_out, skip, ld_in, ld_out, s);
+    if (in_dtype == ISP_F32 && out_dtype == ISP_F32) return launch_ln<float, float>(x, y, gamma, beta, rows, D, eps, group_out, skip, ld_in, ld_out, s);
+    if (in_dtype == ISP_BF16 && out_dtype == ISP_BF16) return launch_ln<bf16_t, bf16_t>(x, y, gamma, beta, rows, D, eps, group_out, skip, ld_in, ld_out, s);
+    if (in_dtype == ISP_BF16 && out_dtype == ISP_F32) return launch_ln<bf16_t, float>(x, y, gamma, beta, rows, D, eps, group_out, skip, ld_in, ld_out, s);
     return ISP_ERR_UNSUPPORTED;
 }
 

@@ -156,18 +156,21 @@ def conv3x3_folded_affine(x, Wt, bias_full, taps):
     return out
 
 
-def layernorm(x, gamma, beta, eps, out_dtype=BF16, group_out=0, skip=0, rows_out=None):
-    """LayerNorm over the last dim of a [rows, D] f32/bf16 tensor."""
+def layernorm(x, gamma, beta, eps, out_dtype=BF16, group_out=0, skip=0, rows_out=None, D=None, ld_out=None):
+    """LayerNorm over the first D columns of a [rows, ld] f32/bf16 tensor (D defaults to ld); the
+    output has row stride ld_out (default D) with columns [D, ld_out) zero-filled."""
     if x.dtype not in (torch.float32, BF16):
         raise IspError("layernorm input must be f32 or bf16")
     _need(x, x.dtype, "x")
-    D = x.shape[-1]
-    rows = x.numel() // D if rows_out is None else rows_out
-    out = torch.empty(rows, D, device=x.device, dtype=out_dtype)
+    ld_in = x.shape[-1]
+    D = ld_in if D is None else D
+    ld_out = D if ld_out is None else ld_out
+    rows = x.numel() // ld_in if rows_out is None else rows_out
+    out = torch.empty(rows, ld_out, device=x.device, dtype=out_dtype)
     check(_lib.lib().isp_layernorm_fwd(_p(x), _p(out), _p(gamma), _p(beta), rows, D, float(eps),
                                        _lib.ISP_F32 if x.dtype == torch.float32 else _lib.ISP_BF16,
                                        _lib.ISP_F32 if out_dtype == torch.float32 else _lib.ISP_BF16,
-                                       group_out, skip, _stream()), "isp_layernorm_fwd")
+                                       group_out, skip, ld_in, ld_out, _stream()), "isp_layernorm_fwd")
     return out
 
 
@@ -178,36 +181,28 @@ def attention_packed_qkv(qkv, B, L, heads, scale):
     out = torch.empty(B * L, D, device=qkv.device, dtype=BF16)
     base = qkv.data_ptr()
     q, k, v = (ctypes.c_void_p(base + i * D * 2) for i in range(3))
-    check(_lib.lib().isp_attention_fwd(q, k, v, _p(out), B, heads, L, L,
+    check(_lib.lib().isp_attention_fwd(q, k, v, _p(out), B, heads, L, L, 64,
                                        L * 3 * D, 3 * D, 64, L * 3 * D, 3 * D, 64, L * D, D, 64,
                                        float(scale), _stream()), "isp_attention_fwd")
     return out
 
 
 def attention(q, k, v, scale):
-    """q [B,Lq,H,64], k/v [B,Lk,H,64] bf16 (any strides with unit last-dim stride)."""
+    """q [B,Lq,H,hd], k/v [B,Lk,H,hd] bf16, hd in {64,128} (any strides with unit last-dim stride)."""
+    hd = q.shape[3]
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _need(t, BF16, n, contiguous=False)
-        if t.stride(3) != 1 or t.shape[3] != 64:
-            raise IspError(f"{n}: head_dim must be 64 with unit stride")
+        if t.stride(3) != 1 or t.shape[3] != hd or hd not in (64, 128):
+            raise IspError(f"{n}: head_dim must be 64 or 128 with unit stride")
     if k.stride() != v.stride():
         raise IspError("k and v must share strides")
     B, Lq, H, _ = q.shape
     Lk = k.shape[1]
-    out = torch.empty(B, Lq, H, 64, device=q.device, dtype=BF16)
-    check(_lib.lib().isp_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, Lq, Lk,
+    out = torch.empty(B, Lq, H, hd, device=q.device, dtype=BF16)
+    check(_lib.lib().isp_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, Lq, Lk, hd,
                                        q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                                        out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()),
           "isp_attention_fwd")
-    return out
-
-
-def resize_bilinear_nhwc(x, H, W):
-    _need(x, BF16, "x")
-    B, h, w, C = x.shape
-    out = torch.empty(B, H, W, C, device=x.device, dtype=BF16)
-    check(_lib.lib().isp_resize_bilinear_ac_nhwc_bf16(_p(x), _p(out), B, h, w, H, W, C, _stream()),
-          "isp_resize_bilinear_ac_nhwc_bf16")
     return out
 
 
@@ -222,6 +217,10 @@ def resize_nhwc(x, H, W, mode):
     check(_lib.lib().isp_resize_nhwc_bf16(_p(x), _p(out), B, h, w, H, W, C, RESIZE_MODES[mode], _stream()),
           "isp_resize_nhwc_bf16")
     return out
+
+
+def resize_bilinear_nhwc(x, H, W):
+    return resize_nhwc(x, H, W, "bilinear")
 
 
 def token_add_(x, add, B, T, has_cls):
@@ -371,4 +370,26 @@ def fuse_flip_sigmoid(logits, with_flip):
     out = torch.empty(n, C, H, W, device=logits.device, dtype=torch.float32)
     check(_lib.lib().isp_fuse_flip_sigmoid(_p(logits), _p(out), n * C, H, W, int(with_flip), _stream()),
           "isp_fuse_flip_sigmoid")
+    return out
+
+
+# ---------------------------------------------------------------------------------- LoftUp
+def minmax_nchw(x):
+    """Per-channel (min, max) over batch and space of an NCHW f32 tensor -> [C,2] f32."""
+    _need(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    out = torch.empty(C, 2, device=x.device, dtype=torch.float32)
+    ws = torch.empty(C * B * 64 * 2, device=x.device, dtype=torch.float32)
+    check(_lib.lib().isp_minmax_nchw_f32(_p(x), _p(out), _p(ws), B, C, H * W, _stream()), "isp_minmax_nchw_f32")
+    return out
+
+
+def loftup_fourier_cn(image, mm, freqs, bias_sin, bias_cos, gamma, beta, ldo, eps=1e-5):
+    """image [B,3,H,W] f32 -> ChannelNorm(Fourier features) [B,H,W,ldo] bf16 (zero-padded channels)."""
+    _need(image, torch.float32, "image")
+    B, _, H, W = image.shape
+    out = torch.empty(B, H, W, ldo, device=image.device, dtype=BF16)
+    check(_lib.lib().isp_loftup_fourier_cn(_p(image), _p(mm), _p(freqs), _p(bias_sin), _p(bias_cos), _p(gamma),
+                                           _p(beta), _p(out), B, H, W, freqs.numel(), ldo, float(eps), _stream()),
+          "isp_loftup_fourier_cn")
     return out

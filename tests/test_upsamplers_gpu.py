@@ -70,3 +70,52 @@ def test_jbu_stages_and_stack_vs_oracle():
     print("jbu max err", err.max().item(), "rms", err.pow(2).mean().sqrt().item(), "ref rms", ref.pow(2).mean().sqrt().item())
     assert err.max().item() < 3e-2 * max(1.0, ref.abs().max().item())
     assert err.pow(2).mean().sqrt().item() < 5e-3 * max(1.0, ref.pow(2).mean().sqrt().item())
+
+
+def test_attention_hd128():
+    from isegprobe_amd import hip_ops as ops
+    torch.manual_seed(3)
+    B, Lq, Lk, H = 2, 300, 200, 4
+    q = torch.randn(B, Lq, H, 128, device="cuda").to(torch.bfloat16)
+    k = torch.randn(B, Lk, H, 128, device="cuda").to(torch.bfloat16)
+    v = torch.randn(B, Lk, H, 128, device="cuda").to(torch.bfloat16)
+    out = ops.attention(q, k, v, 101 ** -0.5)
+    p = ((q.float().permute(0, 2, 1, 3) * 101 ** -0.5) @ k.float().permute(0, 2, 3, 1)).softmax(-1)
+    ref = (p @ v.float().permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+    assert (out.float() - ref).abs().max().item() < 2e-2
+
+
+def test_loftup_fourier_minmax_kernels():
+    from isegprobe_amd import hip_ops as ops
+    from oracle import upsamplers as oups
+    torch.manual_seed(5)
+    img = torch.randn(2, 3, 20, 28)
+    mm = ops.minmax_nchw(img.cuda()).cpu()
+    assert torch.equal(mm[:, 0], img.amin(dim=(0, 2, 3))) and torch.equal(mm[:, 1], img.amax(dim=(0, 2, 3)))
+    biases = torch.randn(2, 5, 20)
+    gamma, beta = 1 + 0.2 * torch.randn(203), 0.2 * torch.randn(203)
+    feats = oups._implicit_feats(oups._minmax(img), biases, 20, True)
+    ref = oups._channel_ln(feats, gamma, beta)
+    freqs = torch.exp(torch.linspace(-2, 10, 20))
+    out = ops.loftup_fourier_cn(img.cuda(), mm.cuda(), freqs.cuda(), biases[0].reshape(-1).cuda().contiguous(),
+                                biases[1].reshape(-1).cuda().contiguous(), gamma.cuda(), beta.cuda(), 256)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert got[:, 203:].abs().max().item() == 0
+    # sin/cos at frequencies up to e^10: fp32 argument rounding alone is ~1e-3 rad; bf16 output
+    assert (got[:, :203] - ref).abs().max().item() < 3e-2
+
+
+def test_loftup_vs_golden(golden):
+    from isegprobe_amd.core.model.upsamplers import LoftUpUpsampler
+    g = golden("upsamplers_head")
+    up = LoftUpUpsampler(None, n_dim=128)
+    missing, unexpected = up.load_state_dict(weights_from(g, "loftup_w"), strict=False)
+    assert not unexpected and all("num_batches_tracked" in k for k in missing), (missing, unexpected)
+    src = torch.from_numpy(g["source"])[:, :, :2, :3].contiguous().cuda()
+    y = _f32(up.cuda().eval()(src, torch.from_numpy(g["loftup_guidance"]).cuda()))
+    ref = torch.from_numpy(g["loftup_y"])
+    assert y.shape == ref.shape
+    err = (y - ref).abs()
+    print("loftup max err", err.max().item(), "rms", err.pow(2).mean().sqrt().item(), "ref rms", ref.pow(2).mean().sqrt().item())
+    assert err.max().item() < 6e-2 * max(1.0, ref.abs().max().item())
+    assert err.pow(2).mean().sqrt().item() < 1e-2 * max(1.0, ref.pow(2).mean().sqrt().item())
