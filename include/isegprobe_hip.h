@@ -150,6 +150,13 @@ int isp_loftup_fourier_cn(const float* image, const float* minmax_c2, const floa
                           const float* bias_cos, const float* gamma, const float* beta, void* out_bf16, int B, int H,
                           int W, int n_freqs, int ldo, float eps, void* stream);
 
+/* ---- LiFT image pyramid (LiFT.py:70-91,106-112): 3x3 / stride 2 / pad 1 conv to 32 channels with
+ * folded eval-BatchNorm + ReLU (input NCHW f32 with 3 channels, or NHWC bf16 with 32), weights
+ * w [32][3][3][cin] f32; and F.adaptive_max_pool2d on NHWC bf16. */
+int isp_conv3x3_s2_c32(const void* in, int in_is_nchw_f32, int cin, const float* w, const float* bias,
+                       void* out_nhwc_bf16, int B, int H, int W, void* stream);
+int isp_adaptive_max_pool_nhwc_bf16(const void* in, void* out, int B, int H, int W, int OH, int OW, int C, void* stream);
+
 /* ---- BaseClassifierHead.classifier (1x1 conv C->1), heads/base_head.py:15.
  * x [M,C] NHWC bf16, weight [C] f32 -> out [M] f32. */
 int isp_classifier_fwd(const void* x_nhwc_bf16, const float* weight, float bias, float* out, long M, int C,

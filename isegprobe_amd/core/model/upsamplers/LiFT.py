@@ -1,11 +1,137 @@
-"""Placeholder so the registry imports; replaced below."""
+"""LiFT x2 learned upsampler (reference core/model/upsamplers/LiFT.py:12-146).
+
+``LiFT`` below is a parameter container with the reference's state-dict layout
+(``lift.{image_convs_1, image_convs_2, up1.up, up1.conv_1.double_conv, outc}.*`` under
+``LiFTUpsampler``).  Forward (eval-mode BatchNorm folded into the conv weights at pack time):
+  image pyramid   3->32 s2, 32->32 s2 (+BN+ReLU), adaptive max pool to (2h,2w), 32->32 s2   csrc/lift.hip
+  ConvTranspose2d(C+32 -> (C+32)/2, k2, s2)   ONE bf16 GEMM with the four (dy,dx) taps as output
+                                              column blocks, then a pixel shuffle (a strided copy)
+  DoubleConv      2 x (3x3 conv + BN + ReLU)  implicit-GEMM conv engine (channels padded to x64)
+  outc            1x1 conv                    GEMM
+The reference's loader does ``torch.load(lift_path)`` then ``.to("cuda")`` (LiFT.py:125-136); with
+no readable path the random init is kept."""
+import os
+
+import torch
+import torch.nn as nn
+
+from .... import hip_ops as ops
+from ...utils.log import logger
+from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16
 from . import BaseUpsampler
 
 
-class LiFTUpsampler(BaseUpsampler):
-    def __init__(self, *a, **k):
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class _DoubleConv(nn.Module):
+    def __init__(self, cin, cout):
         super().__init__()
-        raise NotImplementedError("LiFTUpsampler: HIP path not built yet")
+        self.double_conv = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False), nn.BatchNorm2d(cout),
+                                         nn.ReLU(inplace=True), nn.Conv2d(cout, cout, 3, padding=1, bias=False),
+                                         nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class _Up(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(cin, cin // 2, kernel_size=2, stride=2)
+        self.conv_1 = _DoubleConv(cin // 2 + 32, cout // 2)
+
+
+class LiFT(nn.Module):
+    def __init__(self, in_channels, patch_size, pre_shape=False, post_shape=False):
+        super().__init__()
+        if pre_shape or post_shape:
+            raise NotImplementedError("token-shaped LiFT I/O is not used by the probe")
+        if patch_size not in (8, 14, 16):
+            raise ValueError(f"patch size {patch_size} not currently supported")
+        self.patch_size = patch_size
+        self.up1 = _Up(in_channels + 32, in_channels)
+        self.outc = nn.Conv2d(in_channels // 2, in_channels, kernel_size=1)
+        self.image_convs_1 = nn.Sequential(nn.Conv2d(3, 32, 3, padding=1, stride=2), nn.BatchNorm2d(32), nn.ReLU(inplace=True),
+                                           nn.Conv2d(32, 32, 3, padding=1, stride=2), nn.BatchNorm2d(32), nn.ReLU(inplace=True))
+        self.image_convs_2 = nn.Sequential(nn.Conv2d(32, 32, 3, padding=1, stride=2), nn.BatchNorm2d(32), nn.ReLU(inplace=True))
+
+
+def _fold(conv, bn):
+    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+    w = conv.weight.detach().float() * s[:, None, None, None]
+    b0 = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(s)
+    return w, (b0 - bn.running_mean.float()) * s + bn.bias.detach().float()
+
+
+class LiFTUpsampler(BaseUpsampler):
+    def __init__(self, lift_path: str = None, n_dim: int = 384, patch: int = 14):
+        super().__init__()
+        self.lift = LiFT(n_dim, patch)
+        if lift_path and os.path.exists(str(lift_path)):
+            sd = torch.load(lift_path, map_location="cpu")
+            self.lift.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()})
+            logger.info("Loaded LiFT module from: " + str(lift_path))
+        else:
+            logger.info("LiFTUpsampler: no checkpoint at lift_path, keeping random init")
+        self._packed = PackedCache()
+
+    def packed(self):
+        def build():
+            L = self.lift
+            dev = L.outc.weight.device
+            C = L.outc.weight.shape[0]
+            cu_in, cu_out = C + 32, (C + 32) // 2
+            cat_c = cu_out + 32
+            half = C // 2
+            P = dict(C=C, cu_out=cu_out, cat_p=_pad64(cat_c), half_p=_pad64(half), cu_in_p=_pad64(cu_in))
+            for name, conv, bn in (("ic1a", L.image_convs_1[0], L.image_convs_1[1]),
+                                   ("ic1b", L.image_convs_1[3], L.image_convs_1[4]),
+                                   ("ic2", L.image_convs_2[0], L.image_convs_2[1])):
+                w, b = _fold(conv, bn)
+                P[name + "_w"], P[name + "_b"] = w.permute(0, 2, 3, 1).contiguous(), b.contiguous()
+            # ConvTranspose2d weight [cin, cout, 2, 2] -> GEMM Wt [4*cout_p4, cin_p], row = (dy*2+dx)*cout + n
+            wt = L.up1.up.weight.detach().float()
+            g = torch.zeros(4 * cu_out, P["cu_in_p"], device=dev)
+            g[:, :cu_in] = wt.permute(2, 3, 1, 0).reshape(4 * cu_out, cu_in)
+            P["up_w"], P["up_b"] = g.to(BF16).contiguous(), L.up1.up.bias.detach().float().repeat(4).contiguous()
+            dc = L.up1.conv_1.double_conv
+
+            def conv_pack(conv, bn, cin_p, cout_p):
+                w, b = _fold(conv, bn)
+                o = torch.zeros(cout_p, 3, 3, cin_p, device=dev)
+                o[:w.shape[0], :, :, :w.shape[1]] = w.permute(0, 2, 3, 1)
+                bo = torch.zeros(cout_p, device=dev)
+                bo[:b.shape[0]] = b
+                return o.reshape(cout_p, 9 * cin_p).to(BF16).contiguous(), bo
+            P["dc1_w"], P["dc1_b"] = conv_pack(dc[0], dc[1], P["cat_p"], P["half_p"])
+            P["dc2_w"], P["dc2_b"] = conv_pack(dc[3], dc[4], P["half_p"], P["half_p"])
+            ow = torch.zeros(_pad64(C), P["half_p"], device=dev)
+            ow[:C, :half] = L.outc.weight.detach().float().flatten(1)
+            ob = torch.zeros(_pad64(C), device=dev)
+            ob[:C] = L.outc.bias.detach().float()
+            P["out_w"], P["out_b"] = ow.to(BF16).contiguous(), ob
+            return P
+        params = list(self.lift.parameters()) + [b for n, b in self.lift.named_buffers() if "running" in n]
+        return self._packed.get(params, build)
 
     def forward(self, source, guidance):
-        raise NotImplementedError
+        """LiFT(imgs=guidance, x=source) (LiFT.py:106-122, :145-146) -> [B, C, 2h, 2w]."""
+        P = self.packed()
+        x = to_nhwc_bf16(source)
+        B, h, w, C = x.shape
+        g = guidance.float().contiguous()
+        i1 = ops.conv3x3_s2_c32(g, P["ic1a_w"], P["ic1a_b"])
+        i1 = ops.conv3x3_s2_c32(i1, P["ic1b_w"], P["ic1b_b"])
+        i1 = ops.adaptive_max_pool_nhwc(i1, 2 * h, 2 * w)                    # [B,2h,2w,32]
+        i2 = ops.conv3x3_s2_c32(i1, P["ic2_w"], P["ic2_b"])                   # [B,h,w,32]
+        xin = torch.zeros(B, h, w, P["cu_in_p"], device=x.device, dtype=BF16)  # cat([x, imgs_2]) + zero pad
+        xin[..., :C] = x
+        xin[..., C:C + 32] = i2
+        n = P["cu_out"]
+        up = ops.linear(xin.view(-1, P["cu_in_p"]), P["up_w"], P["up_b"])     # [B*h*w, 4*n]: taps as column blocks
+        cat = torch.zeros(B, 2 * h, 2 * w, P["cat_p"], device=x.device, dtype=BF16)
+        cat.view(B, h, 2, w, 2, P["cat_p"])[..., :n] = up.view(B, h, w, 2, 2, n).permute(0, 1, 3, 2, 4, 5)  # pixel shuffle
+        cat[..., n:n + 32] = i1
+        y = ops.conv3x3(cat, P["dc1_w"], P["dc1_b"], "relu")
+        y = ops.conv3x3(y, P["dc2_w"], P["dc2_b"], "relu")
+        out = ops.linear(y.view(-1, P["half_p"]), P["out_w"], P["out_b"])
+        return nchw_view(out.view(B, 2 * h, 2 * w, -1)[..., :C])

@@ -393,3 +393,28 @@ def loftup_fourier_cn(image, mm, freqs, bias_sin, bias_cos, gamma, beta, ldo, ep
                                            _p(beta), _p(out), B, H, W, freqs.numel(), ldo, float(eps), _stream()),
           "isp_loftup_fourier_cn")
     return out
+
+
+# ---------------------------------------------------------------------------------- LiFT
+def conv3x3_s2_c32(x, w, bias):
+    """3x3 stride-2 pad-1 conv to 32 channels + ReLU.  x: NCHW f32 [B,3,H,W] or NHWC bf16 [B,H,W,32];
+    w [32,3,3,cin] f32 -> NHWC bf16 [B,ceil(H/2),ceil(W/2),32]."""
+    nchw = x.dtype == torch.float32
+    _need(x, torch.float32 if nchw else BF16, "x")
+    if nchw:
+        B, cin, H, W = x.shape
+    else:
+        B, H, W, cin = x.shape
+    out = torch.empty(B, (H + 1) // 2, (W + 1) // 2, 32, device=x.device, dtype=BF16)
+    check(_lib.lib().isp_conv3x3_s2_c32(_p(x), int(nchw), cin, _p(w), _p(bias), _p(out), B, H, W, _stream()),
+          "isp_conv3x3_s2_c32")
+    return out
+
+
+def adaptive_max_pool_nhwc(x, OH, OW):
+    _need(x, BF16, "x")
+    B, H, W, C = x.shape
+    out = torch.empty(B, OH, OW, C, device=x.device, dtype=BF16)
+    check(_lib.lib().isp_adaptive_max_pool_nhwc_bf16(_p(x), _p(out), B, H, W, OH, OW, C, _stream()),
+          "isp_adaptive_max_pool_nhwc_bf16")
+    return out

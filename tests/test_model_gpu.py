@@ -139,3 +139,17 @@ def test_tiny_loftup_model_vs_golden(golden):
     print(f"loftup model: max {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g} ref rms {ref.pow(2).mean().sqrt():.3f}")
     assert _close(y, ref, TOL_TINY), err.max().item()
     assert _mask_agreement(y, ref, TOL_TINY) == 1.0
+
+
+def test_tiny_lift_model_vs_golden(golden):
+    g = golden("model_tiny")
+    model = build_model("lift", upsampler_params={"lift_path": None, "n_dim": 128, "patch": 14})
+    missing, unexpected = model.load_state_dict({**weights_from(g, "common_w"), **weights_from(g, "lift_w")}, strict=False)
+    assert not unexpected and all(("mask_token" in k or "num_batches_tracked" in k) for k in missing), missing
+    with torch.no_grad():
+        y = model.cuda()(torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["points"]).cuda())["instances"].cpu()
+    ref = torch.from_numpy(g["lift_logits"])
+    err = (y - ref).abs()
+    print(f"lift model: max {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g} ref rms {ref.pow(2).mean().sqrt():.3f}")
+    assert _close(y, ref, TOL_TINY), err.max().item()
+    assert _mask_agreement(y, ref, TOL_TINY) == 1.0

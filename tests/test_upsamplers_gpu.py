@@ -119,3 +119,17 @@ def test_loftup_vs_golden(golden):
     print("loftup max err", err.max().item(), "rms", err.pow(2).mean().sqrt().item(), "ref rms", ref.pow(2).mean().sqrt().item())
     assert err.max().item() < 6e-2 * max(1.0, ref.abs().max().item())
     assert err.pow(2).mean().sqrt().item() < 1e-2 * max(1.0, ref.pow(2).mean().sqrt().item())
+
+
+def test_lift_vs_golden(golden):
+    from isegprobe_amd.core.model.upsamplers import LiFTUpsampler
+    g = golden("upsamplers_head")
+    up = LiFTUpsampler(None, n_dim=128, patch=14)
+    missing, unexpected = up.load_state_dict(weights_from(g, "lift_w"), strict=False)
+    assert not unexpected and all("num_batches_tracked" in k for k in missing), (missing, unexpected)
+    y = _f32(up.cuda().eval()(torch.from_numpy(g["source"]).cuda(), torch.from_numpy(g["guidance"]).cuda()))
+    ref = torch.from_numpy(g["lift_y"])
+    assert y.shape == ref.shape
+    err = (y - ref).abs()
+    print("lift max err", err.max().item(), "rms", err.pow(2).mean().sqrt().item(), "ref rms", ref.pow(2).mean().sqrt().item())
+    assert err.max().item() < 3e-2 * max(1.0, ref.abs().max().item())
