@@ -130,13 +130,14 @@ int isp_token_add_fwd(void* x, int x_dtype, const void* add, int add_dtype, long
  * isp_jbu_kernels writes, per output pixel, the COMPOSITE (bicubic-x2 o 7x7 stencil) 8x8 kernel
  * on the low-res source grid: kc [B,GH,GW,8,16] bf16, columns in circular slots (src col & 15).
  * bys [GH,7,8] / bxs [GW,7,16] are the size-only interpolation tables (see jbu.hip);
- * fix3_wT is the second fix-up layer's weight TRANSPOSED ([in][out]).
+ * fix0_w / fix3_w are the fix-up MLP weights zero-padded to [64][64] bf16 ([out][in], inputs ordered
+ * [kernel(49), guidance(3)]), fix0_b / fix3_b zero-padded to 64 f32 (the MLP runs on MFMA).
  * isp_jbu_apply: out [B,2h,2w,C] = composite kernels applied to src [B,h,w,C] (C % 64 == 0). */
 int isp_adaptive_avg_pool_nchw_f32(const float* in, float* out, long planes, int H, int W, int OH, int OW, void* stream);
 int isp_jbu_range_proj(const float* guidance, float* proj, const float* w0, const float* b0, const float* w3,
                        const float* b3, int B, int GH, int GW, void* stream);
-int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const float* fix0_w, const float* fix0_b,
-                    const float* fix3_wT, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
+int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const void* fix0_w, const float* fix0_b,
+                    const void* fix3_w, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
                     float sigma_spatial, int B, int GH, int GW, void* stream);
 int isp_jbu_apply(const void* src_nhwc_bf16, const void* kc_bf16, void* out_nhwc_bf16, int B, int h, int w, int C,
                   void* stream);

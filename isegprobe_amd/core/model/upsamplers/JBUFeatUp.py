@@ -38,10 +38,18 @@ class JBULearnedRange(nn.Module):
     def packed(self):
         def build():
             f = lambda t: t.detach().float().contiguous()
+
+            def pad64(w, b):  # fix-up MLP layer -> zero-padded [64,64] bf16 + [64] f32 (MFMA operands)
+                wp = torch.zeros(64, 64, device=w.device)
+                wp[:w.shape[0], :w.shape[1]] = w.detach().float().flatten(1)
+                bp = torch.zeros(64, device=w.device)
+                bp[:b.shape[0]] = b.detach().float()
+                return wp.to(BF16).contiguous(), bp
+            f0w, f0b = pad64(self.fixup_proj[0].weight, self.fixup_proj[0].bias)
+            f3w, f3b = pad64(self.fixup_proj[3].weight, self.fixup_proj[3].bias)
             return dict(w0=f(self.range_proj[0].weight.flatten(1)), b0=f(self.range_proj[0].bias),
                         w3=f(self.range_proj[3].weight.flatten(1)), b3=f(self.range_proj[3].bias),
-                        f0w=f(self.fixup_proj[0].weight.flatten(1)), f0b=f(self.fixup_proj[0].bias),
-                        f3wT=f(self.fixup_proj[3].weight.flatten(1).t()), f3b=f(self.fixup_proj[3].bias),
+                        f0w=f0w, f0b=f0b, f3w=f3w, f3b=f3b,
                         temp=float(self.range_temp.item()), sigma=float(self.sigma_spatial.item()))
         return self._packed.get(list(self.parameters()), build)
 
@@ -50,7 +58,7 @@ class JBULearnedRange(nn.Module):
         B, GH, GW = guidance_small.shape[0], guidance_small.shape[2], guidance_small.shape[3]
         proj = ops.jbu_range_proj(guidance_small, P["w0"], P["b0"], P["w3"], P["b3"])
         # composite (bicubic-x2 o 7x7) kernels on the low-res grid, applied by MFMA: no x2 map in HBM
-        kc = ops.jbu_kernels(proj, guidance_small, P["f0w"], P["f0b"], P["f3wT"], P["f3b"], P["temp"], P["sigma"])
+        kc = ops.jbu_kernels(proj, guidance_small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"])
         return ops.jbu_apply(source_nhwc, kc)
 
 

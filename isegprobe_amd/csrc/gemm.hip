@@ -26,20 +26,24 @@ constexpr int BK = 64;  // K per step (one 128-byte LDS row of bf16)
 
 // Tile configuration: block tile BM x BN, WM x WN waves; each wave owns (BM/WM) x (BN/WN) as
 // TM x TN MFMA 16x16 tiles.  LDS = 2 stages x (BM + BN) x 128 B.
-template <int BM_, int BN_, int WM_, int WN_, int MINW_>
+template <int BM_, int BN_, int WM_, int WN_, int MINW_, int NST_ = 2>
 struct TileCfg {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, MINW = MINW_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, MINW = MINW_, NST = NST_;  // NST: LDS ring depth
     static constexpr int NW = WM * WN, THREADS = 64 * NW;
     static constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     static constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW;  // 1 KiB DMA pieces per wave per stage
-    static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES, LDS = 2 * STAGE;
+    static constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES, LDS = NST * STAGE;
     static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && (BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile");
+    static_assert(NST == 2 || NST == 3, "ring depth");
 };
 using Cfg128 = TileCfg<128, 128, 2, 2, 2>;    // 4 waves, 64 KiB LDS, 2 blocks / CU   (short-K dense layers)
 // large-K implicit conv: 8 waves, 1 block / CU.  Measured on the seg-head conv (B=8, 448^2, C=N=384):
 // 128x128 1050, 256x128 1050, 128x384 1127, 256x192 1161 TFLOP/s.
-using CfgConv192 = TileCfg<256, 192, 4, 2, 2>;  // 112 KiB LDS; N % 192 == 0
-using CfgConv128 = TileCfg<256, 128, 4, 2, 2>;  // 96 KiB LDS
+#ifndef ISP_CONV192
+#define ISP_CONV192 TileCfg<256, 192, 4, 2, 2, 2>
+#endif
+using CfgConv192 = ISP_CONV192;                    // N % 192 == 0
+using CfgConv128 = TileCfg<256, 128, 4, 2, 2, 2>;  // 96 KiB LDS
 
 // ------------------------------------------------------------------------------ A loaders
 // Contract: init(slot i, global row m, 16-B source chunk) once per lane per DMA row slot;
@@ -307,21 +311,43 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
         }
     };
 
+    // --- K loop: NST-deep LDS ring, ONE barrier per K-step, LDS-DMA kept in flight across it.
+    //   step t:  wait until only the newest (NST-2) stages of this wave's DMA are outstanding
+    //            (=> stage t has landed), retire own LDS reads, barrier (=> everyone's pieces of
+    //            stage t landed AND everyone finished reading stage t-1, whose buffer is the one
+    //            refilled next), issue the DMA of stage t+NST-1, then MFMA on stage t.
+    // Raw s_barrier + counted vmcnt: __syncthreads() would drain the DMA (vmcnt(0)) every step.
     const int nk = K / BK;
-    char* buf0 = smem;
-    char* buf1 = smem + CFG::STAGE;
-    stage(buf0);
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 2 <= nk; kt += 2) {  // unrolled by 2 so both LDS buffers are compile-time constants
-        stage(buf1);
-        compute(buf0);
-        __syncthreads();
-        if (kt + 2 < nk) stage(buf0);
-        compute(buf1);
-        __syncthreads();
+    constexpr int NST = CFG::NST, PIECES = PA + PW;
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+        if (s0 < nk) stage(smem + s0 * CFG::STAGE);
+    auto step = [&](int t, char* cur, char* refill) {
+        if (NST == 3 && t + 1 < nk)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PIECES) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NST - 1 < nk) stage(refill);
+        compute(cur);
+    };
+    int t = 0;
+    if constexpr (NST == 2) {
+        for (; t + 2 <= nk; t += 2) {  // unrolled by the ring depth: LDS buffers are compile-time constants
+            step(t, smem, smem + CFG::STAGE);
+            step(t + 1, smem + CFG::STAGE, smem);
+        }
+        if (t < nk) step(t, smem, smem + CFG::STAGE);
+    } else {
+        for (; t + 3 <= nk; t += 3) {
+            step(t, smem, smem + 2 * CFG::STAGE);
+            step(t + 1, smem + CFG::STAGE, smem);
+            step(t + 2, smem + 2 * CFG::STAGE, smem + CFG::STAGE);
+        }
+        if (t < nk) step(t, smem, smem + 2 * CFG::STAGE);
+        if (t + 1 < nk) step(t + 1, smem + CFG::STAGE, smem);
     }
-    if (kt < nk) compute(buf0);  // odd tail (its tile was staged by the last loop iteration / prologue)
 
     // --- epilogue: lane holds, for mi/ni, row m = .. + fr and 4 consecutive n = .. + 4*fq + j
 #pragma unroll

@@ -84,9 +84,15 @@ constexpr int TS = 16, HALO = TS + 2 * R, PSTRIDE = 36;
 //   bxs[x][tx][slot]: same for columns, indexed by the CIRCULAR slot (src col & 15)
 // base(y) = ((y-4)>>1) - 1;  an hr index q reads src rows ((q-1)>>1)-1 .. +2 with the cubic
 // (A=-0.75) weights at t = 0.75 (q even) / 0.25 (q odd).
+// The fix-up MLP ([k(49), G(3)] -> 49 GELU -> 49) runs on MFMA: the block's 256 pixels form the
+// N dimension of two 64x64 (zero-padded) GEMMs, D[unit][pixel] = W . X^T, with X / hidden / result
+// staged as bf16 rows in the LDS region the proj tile no longer needs.  Wave w owns pixels
+// 64w..64w+63 end to end, so only wave-local LDS ordering is involved after the one barrier.
+__device__ __forceinline__ int mlp_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
 __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restrict__ proj, const float* __restrict__ G,
-                                                           bf16_t* __restrict__ kout, const float* __restrict__ f0w,
-                                                           const float* __restrict__ f0b, const float* __restrict__ f3wT,
+                                                           bf16_t* __restrict__ kout, const bf16_t* __restrict__ f0w,
+                                                           const float* __restrict__ f0b, const bf16_t* __restrict__ f3w,
                                                            const float* __restrict__ f3b, const float* __restrict__ bys,
                                                            const float* __restrict__ bxs, float temp, float inv2s2,
                                                            int GH, int GW) {
@@ -104,8 +110,8 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
     }
     __syncthreads();
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int y = ty0 + ly, x = tx0 + lx;
-    if (y >= GH || x >= GW) return;
+    const bool in_image = (ty0 + ly) < GH && (tx0 + lx) < GW;
+    const int y = min(ty0 + ly, GH - 1), x = min(tx0 + lx, GW - 1);  // out-of-image lanes compute a clamped pixel
 
     float4 ctr[KEY / 4];
     const float* cp = tile + ((ly + R) * HALO + lx + R) * PSTRIDE;
@@ -145,29 +151,81 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
     const float inv2 = 1.f / fmaxf(sum2, 1e-7f);
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) k[t] *= inv2;
-    // fixup MLP on [k(49), G(3)]: 52 -> 49 (GELU) -> 49, added with weight 0.1
+    // fixup MLP on [k(49), G(3)]: 52 -> 49 (GELU) -> 49, added with weight 0.1 -- on MFMA
     const long p = (long)y * GW + x;
-    const float g0 = G[((size_t)b * 3 + 0) * HW + p], g1 = G[((size_t)b * 3 + 1) * HW + p],
-                g2 = G[((size_t)b * 3 + 2) * HW + p];
-    float fix[TAPS];
+    __syncthreads();  // every wave is done with the proj tile: its LDS is reused below
+    char* s_x = smem;            // [256 px][64] bf16: X, later the result F
+    char* s_h = smem + 32768;    // [256 px][64] bf16: hidden
+    {
+        const float g0 = G[((size_t)b * 3 + 0) * HW + p], g1 = G[((size_t)b * 3 + 1) * HW + p],
+                    g2 = G[((size_t)b * 3 + 2) * HW + p];
+        const int row = threadIdx.x;
 #pragma unroll
-    for (int m = 0; m < TAPS; ++m) fix[m] = f3b[m];
-    for (int j = 0; j < TAPS; ++j) {  // hidden unit j (uniform loop: weights come through scalar loads)
-        const float* wr = f0w + j * (TAPS + 3);
-        float h = f0b[j] + wr[TAPS] * g0 + wr[TAPS + 1] * g1 + wr[TAPS + 2] * g2;
+        for (int c = 0; c < 8; ++c) {
+            float e[8];
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) h += wr[t] * k[t];
-        h = gelu_erf(h);
-        const float* wc = f3wT + j * TAPS;  // column j of the second layer, stored transposed
-#pragma unroll
-        for (int m = 0; m < TAPS; ++m) fix[m] += wc[m] * h;
+            for (int q = 0; q < 8; ++q) {
+                const int i = c * 8 + q;
+                e[q] = i < TAPS ? k[i < TAPS ? i : 0] : (i == TAPS ? g0 : (i == TAPS + 1 ? g1 : (i == TAPS + 2 ? g2 : 0.f)));
+            }
+            *reinterpret_cast<uint4*>(s_x + mlp_off(row, c)) =
+                make_uint4(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]), pack2bf(e[4], e[5]), pack2bf(e[6], e[7]));
+        }
     }
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll 1
+        for (int layer = 0; layer < 2; ++layer) {
+            const bf16_t* wsrc = layer == 0 ? f0w : f3w;
+            const float* bsrc = layer == 0 ? f0b : f3b;
+            const char* src = layer == 0 ? s_x : s_h;
+            char* dst = layer == 0 ? s_h : s_x;
+            bf16x8 wf[4][2];  // A operand: W[unit = 16*ot + fr][k = 32*ks + 8*fq + j]
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) k[t] += 0.1f * fix[t];
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    wf[ot][ks] = *reinterpret_cast<const bf16x8*>(wsrc + (ot * 16 + fr) * 64 + ks * 32 + fq * 8);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const int row = wv * 64 + pt * 16 + fr;  // B operand: X[pixel = row][k..k+7]
+                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(src + mlp_off(row, fq));
+                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(src + mlp_off(row, 4 + fq));
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ot][0], x0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ot][1], x1, acc, 0, 0, 0);
+                    // D[unit = 16*ot + 4*fq + j][pixel = row]
+                    const float4 bb = *reinterpret_cast<const float4*>(bsrc + ot * 16 + fq * 4);
+                    float r0 = acc[0] + bb.x, r1 = acc[1] + bb.y, r2 = acc[2] + bb.z, r3 = acc[3] + bb.w;
+                    if (layer == 0) r0 = gelu_erf(r0), r1 = gelu_erf(r1), r2 = gelu_erf(r2), r3 = gelu_erf(r3);
+                    *reinterpret_cast<uint2*>(dst + mlp_off(row, ot * 2 + (fq >> 1)) + (fq & 1) * 8) =
+                        make_uint2(pack2bf(r0, r1), pack2bf(r2, r3));
+                }
+            }
+        }
+    }
+    {
+        const int row = threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            const uint4 u = *reinterpret_cast<const uint4*>(s_x + mlp_off(row, c));
+            const unsigned* q = &u.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = c * 8 + 2 * e;
+                if (i < TAPS) k[i] += 0.1f * __uint_as_float(q[e] << 16);
+                if (i + 1 < TAPS) k[i + 1] += 0.1f * __uint_as_float(q[e] & 0xffff0000u);
+            }
+        }
+    }
     // composite 8x8 kernel on the source grid: rows first (hrow[ry][tx] = sum_ty by[ty][ry] k[ty][tx],
     // k is dead afterwards), then the two halves of the 16 circular column slots
     const float* byp = bys + (size_t)y * (DIA * 8);
     const float* bxp = bxs + (size_t)x * (DIA * 16);
+    if (!in_image) return;
     bf16_t* o = kout + ((size_t)b * HW + p) * 128;
     float hrow[8][DIA];
 #pragma unroll
@@ -346,11 +404,11 @@ extern "C" int isp_jbu_range_proj(const float* guidance, float* proj, const floa
     return isp_launch_status();
 }
 
-extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const float* fix0_w,
-                               const float* fix0_b, const float* fix3_wT, const float* fix3_b, const float* bys,
+extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const void* fix0_w,
+                               const float* fix0_b, const void* fix3_w, const float* fix3_b, const float* bys,
                                const float* bxs, float range_temp, float sigma_spatial, int B, int GH, int GW,
                                void* stream) {
-    ISP_CHECK_ARG(proj && guidance && kc_bf16 && fix0_w && fix0_b && fix3_wT && fix3_b && bys && bxs);
+    ISP_CHECK_ARG(proj && guidance && kc_bf16 && fix0_w && fix0_b && fix3_w && fix3_b && bys && bxs);
     ISP_CHECK_ARG(B > 0 && GH >= 4 && GW >= 4 && GH % 2 == 0 && GW % 2 == 0 && B <= 65535 && sigma_spatial != 0.f);
     const float temp = fminf(fmaxf(expf(range_temp), 1e-4f), 1e4f);
     const float inv2s2 = 1.0f / (2.f * sigma_spatial * sigma_spatial);
@@ -363,8 +421,9 @@ extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* k
         attr_done = true;
     }
     dim3 grid((GW + TS - 1) / TS, (GH + TS - 1) / TS, B);
-    jbu_kernels_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, (bf16_t*)kc_bf16, fix0_w, fix0_b,
-                                                                fix3_wT, fix3_b, bys, bxs, temp, inv2s2, GH, GW);
+    jbu_kernels_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
+                                                                fix0_b, (const bf16_t*)fix3_w, fix3_b, bys, bxs, temp,
+                                                                inv2s2, GH, GW);
     return isp_launch_status();
 }
 

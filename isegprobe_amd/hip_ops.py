@@ -329,13 +329,13 @@ def jbu_tables(G, device):
     return _JBU_TABLES[key]
 
 
-def jbu_kernels(proj, g, f0w, f0b, f3wT, f3b, range_temp, sigma_spatial):
+def jbu_kernels(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial):
     """-> composite kernels kc [B,GH,GW,8,16] bf16 (see include/isegprobe_hip.h)."""
     B, GH, GW, _ = proj.shape
     bys = jbu_tables(GH, proj.device)[0]
     bxs = jbu_tables(GW, proj.device)[1]
     kc = torch.empty(B, GH, GW, 8, 16, device=proj.device, dtype=BF16)
-    check(_lib.lib().isp_jbu_kernels(_p(proj), _p(g), _p(kc), _p(f0w), _p(f0b), _p(f3wT), _p(f3b), _p(bys), _p(bxs),
+    check(_lib.lib().isp_jbu_kernels(_p(proj), _p(g), _p(kc), _p(f0w), _p(f0b), _p(f3w), _p(f3b), _p(bys), _p(bxs),
                                      float(range_temp), float(sigma_spatial), B, GH, GW, _stream()), "isp_jbu_kernels")
     return kc
 
