@@ -59,26 +59,34 @@ def build(upsampler, size):
 
 
 class ConvTimer:
-    """HIP events around every conv3x3 launch of the timed steps (same stream as the launch)."""
+    """HIP events around every 3x3-conv launch of the timed steps (same stream as the launch).  The
+    seg head issues them through three wrappers (plain, folded-affine first layer, classifier-fused
+    last layer); all three run gemm_tile_kernel<Conv3x3A,...> with the same algorithmic FLOPs."""
+
+    NAMES = ("conv3x3", "conv3x3_folded_affine", "conv3x3_relu_classifier")
 
     def __init__(self, ops):
-        self.ops, self.orig, self.pairs, self.flops = ops, ops.conv3x3, [], 0.0
+        self.ops, self.orig, self.pairs, self.flops = ops, {n: getattr(ops, n) for n in self.NAMES}, [], 0.0
 
     def __enter__(self):
-        def timed(x, Wt, *a, **k):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            y = self.orig(x, Wt, *a, **k)
-            e.record()
-            self.pairs.append((s, e))
-            B, H, W, C = x.shape
-            self.flops = 2.0 * B * H * W * C * 9 * Wt.shape[0]  # algorithmic FLOPs of one launch
-            return y
-        self.ops.conv3x3 = timed
+        def make(fn):
+            def timed(x, Wt, *a, **k):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                y = fn(x, Wt, *a, **k)
+                e.record()
+                self.pairs.append((s, e))
+                B, H, W, C = x.shape
+                self.flops = 2.0 * B * H * W * C * 9 * Wt.shape[0]  # algorithmic FLOPs of one launch
+                return y
+            return timed
+        for n, fn in self.orig.items():
+            setattr(self.ops, n, make(fn))
         return self
 
     def __exit__(self, *exc):
-        self.ops.conv3x3 = self.orig
+        for n, fn in self.orig.items():
+            setattr(self.ops, n, fn)
 
     def mean_ms(self):
         return float(np.mean([s.elapsed_time(e) for s, e in self.pairs])) if self.pairs else None

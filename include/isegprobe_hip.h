@@ -66,6 +66,10 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
 #define ISP_EP_BIAS_TAPS_RELU_BF16 7 /* conv3x3 only: relu(v + bias - sum_{taps outside the image} pos[t][n]);
                                         a per-pixel affine map folded into the conv (see gemm.hip) */
 
+#define ISP_EP_RELU_DOT_PARTIAL_F32 8 /* conv/gemm + 1x1 classifier fused: out f32 partial[slot][M] =
+                                         sum_n relu(v + bias[n]) * gamma[n] over the slot's channels;
+                                         slots = isp_conv3x3_partial_slots(N); close with isp_sum_partials_f32 */
+
 typedef struct isp_epilogue {
     int kind;             /* ISP_EP_* */
     void* out;            /* bf16 or f32 per kind */
@@ -90,6 +94,9 @@ int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, int N, int K,
  * loftup/loftup.py:53-63 and LiFT.py:12-27. */
 int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int H, int W, int C, int N, const isp_epilogue* ep,
                           void* stream);
+
+int isp_conv3x3_partial_slots(int N);
+int isp_sum_partials_f32(const float* partial, float* out, long M, int slots, float bias, void* stream);
 
 /* ---- LayerNorm over the last dim (fp32 statistics), nn.LayerNorm(eps) of DINOv2.py:98 and
  * loftup/layers.py.  group_out>0 drops `skip` leading rows of every (group_out+skip)-row

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "l
 ABI_VERSION = 2
 
 ISP_F32, ISP_BF16 = 0, 1
-EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16 = range(8)
+EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32 = range(9)
 
 _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed"}
 
@@ -48,6 +48,8 @@ SIGNATURES = {
     "isp_patchify_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "isp_gemm_bf16": [_vp, _l, _vp, _l, _i, _i, _EP, _vp],
     "isp_conv3x3_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _EP, _vp],
+    "isp_conv3x3_partial_slots": [_i],
+    "isp_sum_partials_f32": [_vp, _vp, _l, _i, _f, _vp],
     "isp_layernorm_fwd": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _l, _l, _vp],
     "isp_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
     "isp_resize_bilinear_ac_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

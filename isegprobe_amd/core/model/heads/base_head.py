@@ -17,14 +17,17 @@ class BaseClassifierHead(nn.Module):
         self.classifier = nn.Conv2d(in_channels, num_classes, kernel_size=1)  # parameter holder
         self._cls_packed = PackedCache()
 
-    def _classify(self, x_nhwc):
-        """1x1 conv C -> num_classes on an NHWC bf16 map -> [B, num_classes, H, W] f32."""
+    def _cls_weights(self):
         if self.num_classes != 1:
             raise IspError("only num_classes == 1 (binary interactive segmentation) is built")
-        w, b = self._cls_packed.get(
+        return self._cls_packed.get(
             (self.classifier.weight, self.classifier.bias),
             lambda: (self.classifier.weight.detach().float().reshape(-1).contiguous(),
                      float(self.classifier.bias.detach().float().item())))
+
+    def _classify(self, x_nhwc):
+        """1x1 conv C -> num_classes on an NHWC bf16 map -> [B, num_classes, H, W] f32."""
+        w, b = self._cls_weights()
         B, H, W, _ = x_nhwc.shape
         return ops.classifier(x_nhwc, w, b).view(B, 1, H, W)
 

@@ -58,8 +58,19 @@ class _StackedHead(BaseClassifierHead):
             for _ in range(num_layers)])
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = to_nhwc_bf16(x)
-        for layer in self.convs:
+        return self._tail(to_nhwc_bf16(x), list(self.convs))
+
+    def _tail(self, y, layers):
+        """Remaining conv layers + classifier; a trailing 3x3 layer is fused with the 1x1 classifier
+        (its output map is never stored)."""
+        if layers and layers[-1].conv.kernel_size == (3, 3) and self.num_classes == 1 and (y.numel() // y.shape[-1]) % 4 == 0:
+            for layer in layers[:-1]:
+                y = layer.run(y)
+            w, b = layers[-1].packed()
+            wc, bc = self._cls_weights()
+            B, H, W, _ = y.shape
+            return ops.conv3x3_relu_classifier(y, w, b, wc, bc).view(B, 1, H, W)
+        for layer in layers:
             y = layer.run(y)
         return self._classify(y)
 
@@ -85,9 +96,7 @@ class _StackedHead(BaseClassifierHead):
             self._fold_packed = PackedCache()
         wfold, bias_full, taps = self._fold_packed.get((first.conv.weight, first.conv.bias, Wf, bf), build)
         y = ops.conv3x3_folded_affine(to_nhwc_bf16(x), wfold, bias_full, taps)
-        for layer in list(self.convs)[1:]:
-            y = layer.run(y)
-        return self._classify(y)
+        return self._tail(y, list(self.convs)[1:])
 
 
 class SimpleConvSegHead(_StackedHead):

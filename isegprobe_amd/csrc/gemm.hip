@@ -193,23 +193,50 @@ struct EpBiasTapsReluBf16 {
     const float* taps;  // [9][ldo]
     int H, W;
     long ldo;
-    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
-        float4 b = *reinterpret_cast<const float4*>(bias + n);
+    // row context: 9-bit mask of the taps that fall outside the image for output pixel m
+    __device__ __forceinline__ unsigned row_begin(long m) const {
         const unsigned rem = (unsigned)m % ((unsigned)H * (unsigned)W);
         const int y = (int)(rem / (unsigned)W), x = (int)(rem % (unsigned)W);
-        if (y == 0 || y == H - 1 || x == 0 || x == W - 1) {
+        unsigned mask = 0;
+        if (y == 0) mask |= 0x007u;
+        if (y == H - 1) mask |= 0x1c0u;
+        if (x == 0) mask |= 0x049u;
+        if (x == W - 1) mask |= 0x124u;
+        return mask;
+    }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, unsigned outside) const {
+        float4 b = *reinterpret_cast<const float4*>(bias + n);
+        if (outside) {
 #pragma unroll 1
             for (int t = 0; t < 9; ++t) {
-                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) {
+                if ((outside >> t) & 1u) {
+                {
                     const float4 tv = *reinterpret_cast<const float4*>(taps + (size_t)t * ldo + n);
                     b.x -= tv.x, b.y -= tv.y, b.z -= tv.z, b.w -= tv.w;
+                }
                 }
             }
         }
         *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) =
             make_uint2(pack2bf(fmaxf(v[0] + b.x, 0.f), fmaxf(v[1] + b.y, 0.f)),
                        pack2bf(fmaxf(v[2] + b.z, 0.f), fmaxf(v[3] + b.w, 0.f)));
+    }
+};
+
+// Second head conv fused with the 1x1 classifier (heads/base_head.py:15): the conv output is never
+// stored; each wave reduces relu(v + bias) . wcls over its own output channels and writes one fp32
+// partial per row: partial[slot][m], slot = n-tile * WN + n-wave.  A tiny kernel sums the slots.
+struct EpReluDotPartial {
+    static constexpr bool kRowReduce = true;
+    float* partial;      // [slots][M]
+    const float* bias;   // [N]
+    const float* wcls;   // [N]
+    long M;
+    __device__ __forceinline__ float term(int n, const float* v) const {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        const float4 w = *reinterpret_cast<const float4*>(wcls + n);
+        return fmaxf(v[0] + b.x, 0.f) * w.x + fmaxf(v[1] + b.y, 0.f) * w.y + fmaxf(v[2] + b.z, 0.f) * w.z +
+               fmaxf(v[3] + b.w, 0.f) * w.w;
     }
 };
 
@@ -350,16 +377,37 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
     }
 
     // --- epilogue: lane holds, for mi/ni, row m = .. + fr and 4 consecutive n = .. + 4*fq + j
+    if constexpr (requires { EP::kRowReduce; }) {
+        const int slot = tn * CFG::WN + wn;
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const long m = m0 + wm * (TM * 16) + mi * 16 + fr;
-        if (m >= M) continue;
+        for (int mi = 0; mi < TM; ++mi) {
+            const long m = m0 + wm * (TM * 16) + mi * 16 + fr;
+            float sum = 0.f;
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int n = n0 + wn * (TN * 16) + ni * 16 + fq * 4;
-            if (n >= N) continue;
-            const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-            ep(m, n, v);
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * (TN * 16) + ni * 16 + fq * 4;
+                const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                if (n < N) sum += ep.term(n, v);
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            if (fq == 0 && m < M) ep.partial[(size_t)slot * ep.M + m] = sum;
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const long m = m0 + wm * (TM * 16) + mi * 16 + fr;
+            if (m >= M) continue;
+            [[maybe_unused]] unsigned ctx = 0;
+            if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * (TN * 16) + ni * 16 + fq * 4;
+                if (n >= N) continue;
+                const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                if constexpr (requires { ep.row_begin(m); }) ep(m, n, v, ctx);
+                else ep(m, n, v);
+            }
         }
     }
 }
@@ -426,6 +474,11 @@ int dispatch_epilogue(AL al, const void* Wt, long M, int N, int K, const isp_epi
             return launch_gemm<CFG>(al, Wt, M, N, K,
                                EpBiasTapsReluBf16{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
             }
+        case ISP_EP_RELU_DOT_PARTIAL_F32:
+            if constexpr (!((KINDS >> ISP_EP_RELU_DOT_PARTIAL_F32) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpReluDotPartial{(float*)e->out, e->bias, e->gamma, M}, s);
+            }
         default:
             return ISP_ERR_UNSUPPORTED;
     }
@@ -443,13 +496,20 @@ extern "C" int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, in
     return dispatch_epilogue<Cfg128, DenseA<Cfg128::PA>, 0x7fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
 }
 
+// number of partial-sum slots isp_conv3x3_nhwc_bf16 writes with ISP_EP_RELU_DOT_PARTIAL_F32
+extern "C" int isp_conv3x3_partial_slots(int N) {
+    if (N % 192 == 0) return ((N + CfgConv192::BN - 1) / CfgConv192::BN) * CfgConv192::WN;
+    if (N > 64) return ((N + CfgConv128::BN - 1) / CfgConv128::BN) * CfgConv128::WN;
+    return ((N + Cfg128::BN - 1) / Cfg128::BN) * Cfg128::WN;
+}
+
 extern "C" int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int H, int W, int C, int N,
                                      const isp_epilogue* ep, void* stream) {
     ISP_CHECK_ARG(in && Wt && B > 0 && H > 0 && W > 0 && C > 0 && C % BK == 0);
     const long M = (long)B * H * W;
     ISP_CHECK_ARG(M <= 0x7fffffffL);
     constexpr unsigned CONV_KINDS = (1u << ISP_EP_BIAS_BF16) | (1u << ISP_EP_BIAS_RELU_BF16) | (1u << ISP_EP_BIAS_F32) |
-                                    (1u << ISP_EP_BIAS_TAPS_RELU_BF16);
+                                    (1u << ISP_EP_BIAS_TAPS_RELU_BF16) | (1u << ISP_EP_RELU_DOT_PARTIAL_F32);
     auto run = [&](auto cfg) {
         using CFG = decltype(cfg);
         Conv3x3A<CFG::PA> al;

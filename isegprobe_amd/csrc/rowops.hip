@@ -446,3 +446,32 @@ extern "C" int isp_fuse_flip_sigmoid(const float* logits, float* probs, long n, 
                                                                                                total, with_flip);
     return isp_launch_status();
 }
+
+
+// ---------------------------------------------------------------------------------------
+// out[m] = bias + sum_s partial[s][m]: closes the conv + classifier fusion (ISP_EP_RELU_DOT_PARTIAL_F32).
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            long M, int slots, float bias) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= M) return;
+    if (i + 3 < M) {
+        float4 acc = make_float4(bias, bias, bias, bias);
+        for (int s = 0; s < slots; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)s * M + i);
+            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = acc;
+    } else {
+        for (long j = i; j < M; ++j) {
+            float a = bias;
+            for (int s = 0; s < slots; ++s) a += partial[(size_t)s * M + j];
+            out[j] = a;
+        }
+    }
+}
+
+extern "C" int isp_sum_partials_f32(const float* partial, float* out, long M, int slots, float bias, void* stream) {
+    ISP_CHECK_ARG(partial && out && M > 0 && slots > 0 && M % 4 == 0);
+    sum_partials_kernel<<<(unsigned)((M / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(partial, out, M, slots, bias);
+    return isp_launch_status();
+}

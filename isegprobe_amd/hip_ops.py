@@ -156,6 +156,26 @@ def conv3x3_folded_affine(x, Wt, bias_full, taps):
     return out
 
 
+def conv3x3_relu_classifier(x, Wt, bias, wcls, bcls):
+    """relu(conv3x3(x) + bias) . wcls + bcls without storing the conv output: x [B,H,W,C] bf16 ->
+    logits [B,H,W] f32 (second head conv + BaseClassifierHead.classifier fused)."""
+    _need(x, BF16, "x")
+    _need(Wt, BF16, "Wt")
+    _need(bias, torch.float32, "bias")
+    _need(wcls, torch.float32, "wcls")
+    B, H, W, C = x.shape
+    N = Wt.shape[0]
+    M = B * H * W
+    slots = _lib.lib().isp_conv3x3_partial_slots(N)
+    partial = torch.empty(slots, M, device=x.device, dtype=torch.float32)
+    ep = _epilogue(_lib.EP_RELU_DOT_PARTIAL_F32, partial, N, bias, gamma=wcls)
+    check(_lib.lib().isp_conv3x3_nhwc_bf16(_p(x), _p(Wt), B, H, W, C, N, ctypes.byref(ep), _stream()),
+          "isp_conv3x3_nhwc_bf16")
+    out = torch.empty(B, H, W, device=x.device, dtype=torch.float32)
+    check(_lib.lib().isp_sum_partials_f32(_p(partial), _p(out), M, slots, float(bcls), _stream()), "isp_sum_partials_f32")
+    return out
+
+
 def layernorm(x, gamma, beta, eps, out_dtype=BF16, group_out=0, skip=0, rows_out=None, D=None, ld_out=None):
     """LayerNorm over the first D columns of a [rows, ld] f32/bf16 tensor (D defaults to ld); the
     output has row stride ld_out (default D) with columns [D, ld_out) zero-filled."""
