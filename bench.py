@@ -197,6 +197,13 @@ def main():
 
     if rank == 0:
         conv_ms = ct.mean_ms()
+        traffic = None  # PMC passes cannot run inside bench.py: use the committed measurement of this launch shape
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_pmc.json")))
+            if args.batch == 32 and args.size == 448:
+                traffic = pmc["derived"]["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         achieved = ct.flops / (conv_ms * 1e-3) / 1e12
         line = {
             "metric": "images/sec thru featurizer+upsampler @448^2 (whole per-click path: click maps, "
@@ -213,7 +220,8 @@ def main():
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"replicas x{world}"},
             "roofline": {"kernel": "gemm_tile_kernel<Conv3x3A, bias+ReLU> (seg-head 3x3 conv, implicit GEMM)",
                          "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "fabric bytes per launch from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_conv_pmc.json",
                          "launch_ms": conv_ms, "flops_per_launch": ct.flops},
         }
         if not args.no_stages:
