@@ -54,9 +54,18 @@ struct DenseA {
     long lda;
     long M;
     const bf16_t* cur[NS];
-    __device__ __forceinline__ void init(int i, long m, int chunk) {
+    template <int BM>
+    __device__ __forceinline__ void init(int i, long tm, int row, int chunk) {
+        const long m = tm * BM + row;
         cur[i] = A + (size_t)(m < M ? m : M - 1) * lda + chunk * 8;
     }
+    template <int BM>
+    __device__ __forceinline__ long out_row(long tm, int row) const {  // global output row or -1
+        const long m = tm * BM + row;
+        return m < M ? m : -1;
+    }
+    template <int BM>
+    long num_tiles() const { return (M + BM - 1) / BM; }
     __device__ __forceinline__ const void* ptr(int i) const { return cur[i]; }
     __device__ __forceinline__ void advance() {
 #pragma unroll
@@ -65,7 +74,10 @@ struct DenseA {
 };
 
 // Implicit GEMM for a 3x3, stride 1, pad 1 convolution on an NHWC bf16 map with C % 64 == 0:
-// row m = flat output pixel, K index = tap*C + c, tap = (dy+1)*3 + (dx+1).  Addresses are
+// K index = tap*C + c, tap = (dy+1)*3 + (dx+1).  An M-tile is a 2-D patch of (BM/16) x 16 output
+// pixels, not BM consecutive pixels of a row: its 9 taps touch an (BM/16+2) x 18 input patch
+// (1.27x the outputs for BM=256) instead of 3 x (BM+2) (3.0x), which is what the L2 has to hold
+// and what spills to the fabric.  Addresses are
 // incremental: within a tap a slot advances by 64 channels (or stays on the zero constant when
 // the tap is outside the image); the tap change recomputes the slot bases.
 template <int NS>
@@ -84,17 +96,36 @@ struct Conv3x3A {
         cur[i] = ok ? pix[i] + ((long)dy * W + dx) * C : reinterpret_cast<const bf16_t*>(g_isp_zero16);
         inc[i] = ok ? BK : 0;
     }
-    __device__ __forceinline__ void init(int i, long m, int chunk) {
-        if (m >= M) m = M - 1;
-        const unsigned hw = (unsigned)H * (unsigned)W;  // M < 2^31 is checked on the host
-        const unsigned rem = (unsigned)m % hw;
-        yy[i] = (int)(rem / (unsigned)W);
-        xx[i] = (int)(rem % (unsigned)W);
-        pix[i] = in + (size_t)m * C + chunk * 8;
+    int tiles_x, tiles_y;  // patches per image
+    template <int BM>
+    __device__ __forceinline__ void locate(long tm, int row, int& b, int& y, int& x) const {
+        const unsigned per_img = (unsigned)tiles_x * (unsigned)tiles_y;
+        b = (int)((unsigned long)tm / per_img);
+        const unsigned t = (unsigned)((unsigned long)tm - (unsigned long)b * per_img);
+        y = (int)(t / (unsigned)tiles_x) * (BM / 16) + (row >> 4);
+        x = (int)(t % (unsigned)tiles_x) * 16 + (row & 15);
+    }
+    template <int BM>
+    __device__ __forceinline__ void init(int i, long tm, int row, int chunk) {
+        int b, y, x;
+        locate<BM>(tm, row, b, y, x);
+        y = y < H ? y : H - 1;  // rows / columns past the image edge compute a clamped pixel, never stored
+        x = x < W ? x : W - 1;
+        yy[i] = y;
+        xx[i] = x;
+        pix[i] = in + (((size_t)b * H + y) * W + x) * C + chunk * 8;
         tap = 0;
         cb = 0;
         set_tap(i);
     }
+    template <int BM>
+    __device__ __forceinline__ long out_row(long tm, int row) const {
+        int b, y, x;
+        locate<BM>(tm, row, b, y, x);
+        return (y < H && x < W) ? ((long)b * H + y) * W + x : -1;
+    }
+    template <int BM>
+    long num_tiles() const { return (long)(M / ((long)H * W)) * tiles_x * tiles_y; }
     __device__ __forceinline__ const void* ptr(int i) const { return cur[i]; }
     __device__ __forceinline__ void advance() {
         if (++cb == cblocks) {  // uniform branch
@@ -269,7 +300,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
     const int wg = xcd_remap(blockIdx.x, nwg);
     const int tn = wg % tiles_n;
     const long tm = wg / tiles_n;
-    const long m0 = tm * BM;
     const int n0 = tn * BN;
 
     // --- staging assignment: wave `wid` issues DMA pieces wid, wid+NW, ... of each operand tile;
@@ -280,7 +310,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         const int row = (wid + i * NW) * 8 + lrow;
-        al.init(i, m0 + row, swz(row, pchunk));
+        al.template init<BM>(i, tm, row, swz(row, pchunk));
     }
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
@@ -381,7 +411,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
         const int slot = tn * CFG::WN + wn;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
-            const long m = m0 + wm * (TM * 16) + mi * 16 + fr;
+            const long m = al.template out_row<BM>(tm, wm * (TM * 16) + mi * 16 + fr);
             float sum = 0.f;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
@@ -391,13 +421,13 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
             }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
-            if (fq == 0 && m < M) ep.partial[(size_t)slot * ep.M + m] = sum;
+            if (fq == 0 && m >= 0) ep.partial[(size_t)slot * ep.M + m] = sum;
         }
     } else {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
-            const long m = m0 + wm * (TM * 16) + mi * 16 + fr;
-            if (m >= M) continue;
+            const long m = al.template out_row<BM>(tm, wm * (TM * 16) + mi * 16 + fr);
+            if (m < 0) continue;
             [[maybe_unused]] unsigned ctx = 0;
             if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
 #pragma unroll
@@ -415,7 +445,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
 template <class CFG, class AL, class EP>
 int launch_gemm(AL al, const void* Wt, long M, int N, int K, EP ep, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 4 != 0) return ISP_ERR_INVALID;
-    const long tiles_m = (M + CFG::BM - 1) / CFG::BM;
+    const long tiles_m = al.template num_tiles<CFG::BM>();
     const int tiles_n = (N + CFG::BN - 1) / CFG::BN;
     const long nwg = tiles_m * tiles_n;
     if (nwg > 0x7fffffffL) return ISP_ERR_INVALID;
@@ -519,6 +549,8 @@ extern "C" int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int 
         al.C = C;
         al.M = M;
         al.cblocks = C / BK;
+        al.tiles_x = (W + 15) / 16;
+        al.tiles_y = (H + CFG::BM / 16 - 1) / (CFG::BM / 16);
         return dispatch_epilogue<CFG, Conv3x3A<CFG::PA>, CONV_KINDS>(al, Wt, M, N, 9 * C, ep, (hipStream_t)stream);
     };
     if (N % 192 == 0) return run(CfgConv192{});
