@@ -1,0 +1,118 @@
+"""Data-parallel helpers (reference core/utils/distributed.py:8-78, core/utils/exp.py:33-36).
+
+One process per GPU over ``torch.distributed`` (backend "nccl" IS RCCL on ROCm; "gloo" for the
+CPU tests).  The reference wraps the net in DistributedDataParallel, whose bucketed all-reduce
+fires inside ``loss.backward()``; only ``embed_coords`` and ``head`` are trainable there (2.88 M
+fp32 = 11.5 MB for DINOv2-S/14), so here the gradients of the trainable parameters are flattened
+into ONE bucket and all-reduced once per step (``GradBucket``) -- on xGMI a ring all-reduce of
+11.5 MB is ~0.13 ms, far below a step, so no finer bucketing or tree algorithm is warranted.
+The rank's device comes from ``LOCAL_RANK`` (the reference reads it from YAML only)."""
+import os
+
+import torch
+from torch import distributed as dist
+from torch.utils import data
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_local_rank():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_distributed(backend=None):
+    """init_process_group from the torchrun environment (no-op for a single process)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world < 2 or (dist.is_available() and dist.is_initialized()):
+        return world > 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(get_local_rank())
+    dist.init_process_group(backend=backend, init_method="env://")
+    return True
+
+
+def synchronize():
+    if get_world_size() > 1:
+        dist.barrier()
+
+
+def reduce_loss_dict(loss_dict):
+    """Mean of scalar losses on rank 0 (distributed.py:31-53): one dist.reduce of the stacked scalars."""
+    world_size = get_world_size()
+    if world_size < 2:
+        return loss_dict
+    with torch.no_grad():
+        keys = list(loss_dict.keys())
+        losses = torch.stack([loss_dict[k] for k in keys], 0)
+        dist.reduce(losses, dst=0)
+        if dist.get_rank() == 0:
+            losses /= world_size
+        return {k: v for k, v in zip(keys, losses)}
+
+
+def get_sampler(dataset, shuffle, distributed, generator=None, seed=0):
+    if distributed:
+        return data.distributed.DistributedSampler(dataset, shuffle=shuffle, seed=seed)
+    return data.RandomSampler(dataset, generator=generator) if shuffle else data.SequentialSampler(dataset)
+
+
+def shard_indices(n, rank=None, world=None):
+    """Disjoint contiguous-stride shard of range(n) for this rank (DistributedSampler's layout without
+    shuffling: rank, rank+world, ...; the tail is padded by wrapping so every rank has equal work)."""
+    rank = get_rank() if rank is None else rank
+    world = get_world_size() if world is None else world
+    per = (n + world - 1) // world
+    idx = list(range(rank, per * world, world))
+    return [i % n for i in idx]
+
+
+class GradBucket:
+    """Flat bucket of the trainable parameters' gradients: one all-reduce(sum) per step, then /world.
+
+    ``params`` order is fixed at construction (must match on every rank).  The bucket is a single
+    contiguous tensor on the parameters' device; ``.grad`` of each parameter becomes a view into it, so
+    backward writes straight into the bucket and no copy precedes the collective."""
+
+    def __init__(self, params, dtype=torch.float32):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(sizes), device=dev, dtype=dtype)
+        off = 0
+        for p, n in zip(self.params, sizes):
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def nbytes(self):
+        return self.flat.numel() * self.flat.element_size()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, async_op=False):
+        """Average gradients across ranks (what DDP does); returns the work handle when async."""
+        world = get_world_size()
+        if world < 2:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            return work
+        self.flat.div_(world)
+        return None
+
+    def finish(self, work):
+        if work is not None:
+            work.wait()
+            self.flat.div_(get_world_size())

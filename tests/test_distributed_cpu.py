@@ -1,0 +1,83 @@
+"""CPU, world_size 2, gloo: the data-parallel plumbing (shards, gradient bucket all-reduce, loss
+reduce, max-over-ranks timing) that the multi-GPU runs use with backend "nccl" (= RCCL)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from isegprobe_amd.core.utils import distributed as D
+    assert D.init_distributed("gloo")
+    assert D.get_world_size() == world and D.get_rank() == rank
+    # 1) disjoint, equal-size shards covering the dataset
+    shard = D.shard_indices(11)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, shard)
+    # 2) gradient bucket: same model on both ranks, rank-dependent inputs
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 1, 1))
+    for p in model[0].parameters():
+        p.requires_grad = rank >= 0
+    bucket = D.GradBucket(model.parameters())
+    x = torch.full((2, 3, 5, 5), float(rank + 1))
+    bucket.zero()
+    model(x).sum().backward()
+    local = bucket.flat.clone()
+    work = bucket.all_reduce_mean(async_op=True)
+    bucket.finish(work)
+    both = [None] * world
+    dist.all_gather_object(both, local)
+    expected = sum(both) / world
+    assert torch.allclose(bucket.flat, expected)
+    assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in bucket.params)  # grads are views of the bucket
+    # 3) loss reduce to rank 0 and max-over-ranks timing
+    red = D.reduce_loss_dict({"a": torch.tensor(float(rank + 1)), "b": torch.tensor(10.0 * (rank + 1))})
+    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    D.synchronize()
+    if rank == 0:
+        out.put(dict(shards=gathered, red={k: float(v) for k, v in red.items()}, tmax=float(t), nbytes=bucket.nbytes()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s0, s1 = res["shards"]
+    assert len(s0) == len(s1) == 6 and set(s0) | set(s1) == set(range(11))
+    assert set(s0) & set(s1) <= {0}  # only the wrap-around pad may repeat
+    assert res["red"] == {"a": 1.5, "b": 15.0}
+    assert abs(res["tmax"] - 0.2) < 1e-12
+    assert res["nbytes"] == (3 * 4 * 9 + 4 + 4 + 1) * 4
+
+
+def test_single_process_noops():
+    from isegprobe_amd.core.utils import distributed as D
+    assert D.get_world_size() == 1 and D.get_rank() == 0
+    assert D.shard_indices(5) == [0, 1, 2, 3, 4]
+    d = {"x": torch.tensor(1.0)}
+    assert D.reduce_loss_dict(d) is d
+    p = torch.nn.Parameter(torch.ones(3))
+    b = D.GradBucket([p])
+    (p * 2).sum().backward()
+    assert b.all_reduce_mean() is None and torch.equal(b.flat, torch.full((3,), 2.0))
