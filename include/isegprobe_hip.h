@@ -175,6 +175,19 @@ int isp_classifier_fwd(const void* x_nhwc_bf16, const float* weight, float bias,
  * when with_flip=0) f32 -> probs [n,1,H,W] f32. */
 int isp_fuse_flip_sigmoid(const float* logits, float* probs, long n, int H, int W, int with_flip, void* stream);
 
+/* ---- backward of the trainable tail (loss.backward(), core/training/trainer.py:224, for clicks
+ * injected after the frozen backbone): weight gradients as a pixel-reduction ("TN") GEMM with an
+ * optional implicit 3x3 tap shift of Q (conv wgrad: call once per tap with out + tap*C), fp32
+ * atomics into a caller-zeroed buffer; ReLU mask + bias gradient; classifier backward; adjoint of
+ * the align_corners bilinear resize.  Activation gradients of 3x3 convs reuse
+ * isp_conv3x3_nhwc_bf16 with the 180-degree rotated, transposed weights. */
+int isp_tn_gemm_bf16_atomic(const void* P, long ldp, const void* Q, long ldq, float* out, long ldo, long M, int N, int J,
+                            int shift_H, int shift_W, int shift_dy, int shift_dx, int splits, void* stream);
+int isp_relu_mask_colsum(const void* dy, const void* y, void* g, float* colsum, long M, int N, void* stream);
+int isp_classifier_bwd(const float* grad_logits, const void* x, const float* w, void* dx, float* dw, float* db, long M,
+                       int C, void* stream);
+int isp_resize_bilinear_ac_nhwc_bwd(const void* dout, void* din, int B, int h, int w, int H, int W, int C, void* stream);
+
 /* ---- layout converters between the plugin API (NCHW f32) and the kernels (NHWC bf16).
  * The f32 source is addressed in[b*sb + c*sc + p*sp] so permuted views need no copy. */
 int isp_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int C, long HW, void* stream);

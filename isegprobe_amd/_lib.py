@@ -65,6 +65,10 @@ SIGNATURES = {
     "isp_loftup_fourier_cn": [_vp] * 8 + [_i, _i, _i, _i, _i, _f, _vp],
     "isp_conv3x3_s2_c32": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "isp_adaptive_max_pool_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "isp_tn_gemm_bf16_atomic": [_vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "isp_relu_mask_colsum": [_vp, _vp, _vp, _vp, _l, _i, _vp],
+    "isp_classifier_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp],
+    "isp_resize_bilinear_ac_nhwc_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_classifier_fwd": [_vp, _vp, _f, _vp, _l, _i, _vp],
     "isp_nhwc_bf16_to_nchw_f32": [_vp, _vp, _i, _i, _l, _vp],
     "isp_nchw_f32_to_nhwc_bf16": [_vp, _vp, _i, _i, _l, _l, _l, _l, _vp],

@@ -1,0 +1,329 @@
+// Backward kernels for the trainable tail of the path (seg head, resize, click patch-embed):
+// what loss.backward() needs when the clicks are injected after the frozen backbone
+// (reference core/training/trainer.py:224 on models/*/patch-embed_*.py with
+// feats_injection_mode="after_backbone").  The before-backbone mode additionally needs the
+// backward of the frozen ViT / upsampler (activation gradients only) -- not built yet.
+//
+//   isp_tn_gemm_bf16_atomic   Out[n][j] += sum_m P[m][n] * Q[m'][j]   (weight gradients: both
+//                             operands are pixel-major, the reduction runs over pixels; Q rows
+//                             optionally shifted by a 3x3 tap = implicit im2col for conv wgrad)
+//   isp_relu_mask_colsum      g = dy * (y > 0), bias gradient = column sums of g
+//   isp_classifier_bwd        dx = (x > 0) * g[m] * w[c], dw, db of the 1x1 classifier
+//   isp_resize_bilinear_ac_nhwc_bwd   adjoint of the align_corners bilinear resize
+#include "isp_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// ---------------------------------------------------------------------------------------
+// TN GEMM via transposed LDS reads.  Block tile 128(n) x 128(j), K-step = 64 pixels, 4 waves
+// (2 x 2, 64 x 64 each = 4 x 4 MFMA 16x16x32), 2-stage LDS ring filled by LDS-DMA.  Both tiles are
+// stored [pixel][channel] (256-byte rows); every MFMA fragment (8 consecutive pixels of one
+// channel) is two ds_read_b64_tr_b16.  16-B chunks are XOR-swizzled with
+// f(row) = ((row&3)<<1) ^ (((row>>3)&1)<<3) so the 8 rows a half-wave touches hit 8 distinct
+// 32-byte windows.  Split-K over pixels; fp32 atomicAdd of the finished tile.
+constexpr int TBK = 64, TBN = 128;
+constexpr int T_TILE = TBK * TBN * 2;  // 16 KiB per operand tile
+constexpr int T_LDS = 4 * T_TILE;
+
+__device__ __forceinline__ int tswz(int row, int chunk) { return chunk ^ (((row & 3) << 1) | (((row >> 3) & 1) << 3)); }
+
+struct TapShift {  // Q rows are pixels of an NHWC map shifted by a 3x3 tap (dy, dx); zero outside
+    int H, W, dy, dx, enabled;
+};
+
+__global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const bf16_t* __restrict__ P, long ldp,
+                                                          const bf16_t* __restrict__ Q, long ldq, float* __restrict__ out,
+                                                          long ldo, long M, int N, int J, long m_per_block, TapShift ts,
+                                                          int tiles_n, int tiles_j) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int tj = bid % tiles_j;
+    bid /= tiles_j;
+    const int tn = bid % tiles_n;
+    const long split = bid / tiles_n;
+    const long m_begin = split * m_per_block;
+    long m_end = m_begin + m_per_block;
+    if (m_end > M) m_end = M;
+    if (m_begin >= m_end) return;
+    const int n0 = tn * TBN, j0 = tj * TBN;
+
+    // --- DMA assignment: piece q = 4 pixel rows x 256 B; wave w takes pieces w, w+4, w+8, w+12
+    const int prow = lane >> 4, pch = lane & 15;
+    long mrow[4];
+    int yy[4], xx[4], pcol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wid + 4 * i) * 4 + prow;
+        mrow[i] = m_begin + row;
+        pcol[i] = tswz(row, pch) * 8;
+        if (ts.enabled) {
+            const unsigned hw = (unsigned)ts.H * (unsigned)ts.W;
+            const unsigned rem = (unsigned)((unsigned long)mrow[i] % hw);
+            yy[i] = (int)(rem / (unsigned)ts.W);
+            xx[i] = (int)(rem % (unsigned)ts.W);
+        }
+    }
+    auto stage = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool live = mrow[i] < m_end;
+            const int nn = n0 + pcol[i], jj = j0 + pcol[i];
+            const void* ps = (live && nn < N) ? (const void*)(P + (size_t)mrow[i] * ldp + nn) : (const void*)g_isp_zero16;
+            glds16(ps, buf + (wid + 4 * i) * 1024);
+            bool qok = live && jj < J;
+            long qrow = mrow[i];
+            if (ts.enabled) {
+                qok = qok && (unsigned)(yy[i] + ts.dy) < (unsigned)ts.H && (unsigned)(xx[i] + ts.dx) < (unsigned)ts.W;
+                qrow += (long)ts.dy * ts.W + ts.dx;
+            }
+            const void* qs = qok ? (const void*)(Q + (size_t)qrow * ldq + jj) : (const void*)g_isp_zero16;
+            glds16(qs, buf + T_TILE + (wid + 4 * i) * 1024);
+            mrow[i] += TBK;
+            if (ts.enabled) {
+                xx[i] += TBK;
+                while (xx[i] >= ts.W) xx[i] -= ts.W, ++yy[i];
+                while (yy[i] >= ts.H) yy[i] -= ts.H;
+            }
+        }
+    };
+
+    // --- fragment geometry: 16-lane group reads 4 pixel rows x 16 channels
+    const int wn = wid >> 1, wj = wid & 1;
+    const int g = lane >> 4, gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto frag = [&](const char* tile, int ks, int col0) {  // 8 pixels (k = 32ks + 8g + j) of channel col0 + gi
+        bf16x8 r;
+        s16x4 part[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = ks * 32 + 8 * g + 4 * jj + gq;
+            const int col = col0 + 4 * gp;
+            part[jj] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (ISP_LDS s16x4*)(tile + row * 256 + tswz(row, col >> 3) * 16 + (col & 7) * 2));
+        }
+        r = bf16x8{part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
+        return r;
+    };
+    auto compute = [&](const char* buf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = frag(buf, ks, wn * 64 + t * 16);
+                fb[t] = frag(buf + T_TILE, ks, wj * 64 + t * 16);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    const long nk = (m_end - m_begin + TBK - 1) / TBK;
+    char* buf0 = smem;
+    char* buf1 = smem + 2 * T_TILE;
+    stage(buf0);
+    __syncthreads();
+    long kt = 0;
+    for (; kt + 2 <= nk; kt += 2) {
+        stage(buf1);
+        compute(buf0);
+        __syncthreads();
+        if (kt + 2 < nk) stage(buf0);
+        compute(buf1);
+        __syncthreads();
+    }
+    if (kt < nk) compute(buf0);
+
+    // D[row = n][col = j]: lane col j = .. + (lane&15), rows n = .. + 4*(lane>>4) + i
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j = j0 + wj * 64 + b * 16 + gi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + wn * 64 + a * 16 + 4 * g + i;
+                if (n < N && j < J) atomicAdd(out + (size_t)n * ldo + j, acc[a][b][i]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------
+// g = dy * (y > 0) (bf16), colsum[n] += sum_m g[m][n].  Block = 64 rows x all columns.
+__global__ __launch_bounds__(256) void relu_mask_colsum_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                                bf16_t* __restrict__ g, float* __restrict__ colsum,
+                                                                long M, int N) {
+    const long r0 = (long)blockIdx.x * 64;
+    for (int c8 = threadIdx.x; c8 < N / 8; c8 += blockDim.x) {
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (long r = r0; r < r0 + 64 && r < M; ++r) {
+            const uint4 a = *reinterpret_cast<const uint4*>(dy + r * N + c8 * 8);
+            const uint4 b = *reinterpret_cast<const uint4*>(y + r * N + c8 * 8);
+            const unsigned* pa = &a.x;
+            const unsigned* pb = &b.x;
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ylo = __uint_as_float(pb[e] << 16), yhi = __uint_as_float(pb[e] & 0xffff0000u);
+                const unsigned lo = ylo > 0.f ? (pa[e] & 0xffffu) : 0u, hi = yhi > 0.f ? (pa[e] & 0xffff0000u) : 0u;
+                o[e] = lo | hi;
+                s[2 * e] += __uint_as_float(lo << 16);
+                s[2 * e + 1] += __uint_as_float(hi);
+            }
+            *reinterpret_cast<uint4*>(g + r * N + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        if (colsum) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(colsum + c8 * 8 + e, s[e]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 1x1 classifier backward fused with the ReLU mask of its input x (post-ReLU conv output):
+//   dx[m][c] = x[m][c] > 0 ? g[m] * w[c] : 0     dw[c] += sum_m g[m] * x[m][c]     db += sum_m g[m]
+__global__ __launch_bounds__(256) void classifier_bwd_kernel(const float* __restrict__ gl, const bf16_t* __restrict__ x,
+                                                              const float* __restrict__ w, bf16_t* __restrict__ dx,
+                                                              float* __restrict__ dw, float* __restrict__ db, long M,
+                                                              int C) {
+    const long r0 = (long)blockIdx.x * 64;
+    for (int c8 = threadIdx.x; c8 < C / 8; c8 += blockDim.x) {
+        float wv[8], s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = w[c8 * 8 + e];
+        for (long r = r0; r < r0 + 64 && r < M; ++r) {
+            const float gm = gl[r];
+            const uint4 b = *reinterpret_cast<const uint4*>(x + r * C + c8 * 8);
+            const unsigned* pb = &b.x;
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xlo = __uint_as_float(pb[e] << 16), xhi = __uint_as_float(pb[e] & 0xffff0000u);
+                s[2 * e] += gm * xlo;
+                s[2 * e + 1] += gm * xhi;
+                o[e] = pack2bf(xlo > 0.f ? gm * wv[2 * e] : 0.f, xhi > 0.f ? gm * wv[2 * e + 1] : 0.f);
+            }
+            *reinterpret_cast<uint4*>(dx + r * C + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(dw + c8 * 8 + e, s[e]);
+    }
+    if (threadIdx.x == 0) {
+        float sg = 0.f;
+        for (long r = r0; r < r0 + 64 && r < M; ++r) sg += gl[r];
+        atomicAdd(db, sg);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Adjoint of the align_corners bilinear resize [B,h,w,C] -> [B,H,W,C]: gather form, one thread
+// per (source pixel, 8 channels) sweeping the destination pixels whose 2x2 support contains it.
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const bf16_t* __restrict__ dout, bf16_t* __restrict__ din,
+                                                            int h, int w, int H, int W, int C, float sy, float sx,
+                                                            long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C >> 3, c8 = (int)(idx % cv);
+    long t = idx / cv;
+    const int x = (int)(t % w);
+    t /= w;
+    const int y = (int)(t % h);
+    const long b = t / h;
+    // destination rows Y with floor(sy*Y) in {y-1, y}; generous bounds, exact test inside
+    const int Y0 = sy > 0.f ? max(0, (int)floorf((float)(y - 1) / sy) - 1) : 0;
+    const int Y1 = sy > 0.f ? min(H - 1, (int)ceilf((float)(y + 1) / sy) + 1) : H - 1;
+    const int X0 = sx > 0.f ? max(0, (int)floorf((float)(x - 1) / sx) - 1) : 0;
+    const int X1 = sx > 0.f ? min(W - 1, (int)ceilf((float)(x + 1) / sx) + 1) : W - 1;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int Y = Y0; Y <= Y1; ++Y) {
+        const float fy = sy * (float)Y;
+        const int y0 = (int)fy, y1 = min(y0 + 1, h - 1);
+        const float ly = fy - (float)y0;
+        float wy = 0.f;
+        if (y0 == y) wy += 1.f - ly;
+        if (y1 == y) wy += ly;
+        if (wy == 0.f) continue;
+        for (int X = X0; X <= X1; ++X) {
+            const float fx = sx * (float)X;
+            const int x0 = (int)fx, x1 = min(x0 + 1, w - 1);
+            const float lx = fx - (float)x0;
+            float wx = 0.f;
+            if (x0 == x) wx += 1.f - lx;
+            if (x1 == x) wx += lx;
+            if (wx == 0.f) continue;
+            const uint4 u = *reinterpret_cast<const uint4*>(dout + (((size_t)b * H + Y) * W + X) * C + c8 * 8);
+            const unsigned* p = &u.x;
+            const float wgt = wy * wx;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += wgt * __uint_as_float(p[e] << 16);
+                acc[2 * e + 1] += wgt * __uint_as_float(p[e] & 0xffff0000u);
+            }
+        }
+    }
+    *reinterpret_cast<uint4*>(din + idx * 8) =
+        make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+}
+
+}  // namespace
+
+extern "C" int isp_tn_gemm_bf16_atomic(const void* P, long ldp, const void* Q, long ldq, float* out, long ldo, long M,
+                                       int N, int J, int shift_H, int shift_W, int shift_dy, int shift_dx,
+                                       int splits, void* stream) {
+    ISP_CHECK_ARG(P && Q && out && M > 0 && N > 0 && J > 0 && ldp >= N && ldq >= J && ldo >= J && splits > 0);
+    ISP_CHECK_ARG(ldp % 8 == 0 && ldq % 8 == 0 && N % 8 == 0 && J % 8 == 0);
+    TapShift ts{shift_H, shift_W, shift_dy, shift_dx, (shift_H > 0 && shift_W > 0) ? 1 : 0};
+    if (ts.enabled) ISP_CHECK_ARG(M % ((long)shift_H * shift_W) == 0 && abs(shift_dy) <= 1 && abs(shift_dx) <= 1);
+    const int tiles_n = (N + TBN - 1) / TBN, tiles_j = (J + TBN - 1) / TBN;
+    long per = ((M + splits - 1) / splits + TBK - 1) / TBK * TBK;
+    const long nsplit = (M + per - 1) / per;
+    const long nwg = nsplit * tiles_n * tiles_j;
+    ISP_CHECK_ARG(nwg <= 0x7fffffffL);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)tn_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS) != hipSuccess)
+            return ISP_ERR_LAUNCH;
+        attr_done = true;
+    }
+    tn_gemm_kernel<<<(unsigned)nwg, 256, T_LDS, (hipStream_t)stream>>>((const bf16_t*)P, ldp, (const bf16_t*)Q, ldq, out,
+                                                                     ldo, M, N, J, per, ts, tiles_n, tiles_j);
+    return isp_launch_status();
+}
+
+extern "C" int isp_relu_mask_colsum(const void* dy, const void* y, void* g, float* colsum, long M, int N, void* stream) {
+    ISP_CHECK_ARG(dy && y && g && M > 0 && N > 0 && N % 8 == 0);
+    relu_mask_colsum_kernel<<<(unsigned)((M + 63) / 64), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)g, colsum, M, N);
+    return isp_launch_status();
+}
+
+extern "C" int isp_classifier_bwd(const float* grad_logits, const void* x, const float* w, void* dx, float* dw,
+                                  float* db, long M, int C, void* stream) {
+    ISP_CHECK_ARG(grad_logits && x && w && dx && dw && db && M > 0 && C > 0 && C % 8 == 0);
+    classifier_bwd_kernel<<<(unsigned)((M + 63) / 64), 256, 0, (hipStream_t)stream>>>(
+        grad_logits, (const bf16_t*)x, w, (bf16_t*)dx, dw, db, M, C);
+    return isp_launch_status();
+}
+
+extern "C" int isp_resize_bilinear_ac_nhwc_bwd(const void* dout, void* din, int B, int h, int w, int H, int W, int C,
+                                               void* stream) {
+    ISP_CHECK_ARG(dout && din && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const long total = (long)B * h * w * (C / 8);
+    bilinear_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dout, (bf16_t*)din, h, w, H, W, C, sy, sx, total);
+    return isp_launch_status();
+}

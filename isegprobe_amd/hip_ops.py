@@ -438,3 +438,55 @@ def adaptive_max_pool_nhwc(x, OH, OW):
     check(_lib.lib().isp_adaptive_max_pool_nhwc_bf16(_p(x), _p(out), B, H, W, OH, OW, C, _stream()),
           "isp_adaptive_max_pool_nhwc_bf16")
     return out
+
+
+# ---------------------------------------------------------------------------------- backward
+def tn_gemm_atomic(P, Q, out, shift=None, splits=None):
+    """out[n, j] += sum_m P[m, n] * Q[m', j]   (P [M,N], Q [M,J] bf16 row-major; out f32, pre-zeroed).
+    shift=(H, W, dy, dx): Q rows are pixels of an NHWC map read at (y+dy, x+dx), zero outside."""
+    _need(P, BF16, "P", contiguous=False)
+    _need(Q, BF16, "Q", contiguous=False)
+    _need(out, torch.float32, "out", contiguous=False)
+    M, N = P.shape
+    J = Q.shape[1]
+    if splits is None:
+        tiles = ((N + 127) // 128) * ((J + 127) // 128)
+        splits = max(1, min((M + 1023) // 1024, 2048 // tiles))
+    H, W, dy, dx = shift if shift else (0, 0, 0, 0)
+    check(_lib.lib().isp_tn_gemm_bf16_atomic(_p(P), P.stride(0), _p(Q), Q.stride(0), _p(out), out.stride(0), M, N, J,
+                                             H, W, dy, dx, splits, _stream()), "isp_tn_gemm_bf16_atomic")
+    return out
+
+
+def relu_mask_colsum(dy, y, want_colsum=True):
+    _need(dy, BF16, "dy")
+    _need(y, BF16, "y")
+    N = y.shape[-1]
+    M = y.numel() // N
+    g = torch.empty_like(dy)
+    cs = torch.zeros(N, device=y.device, dtype=torch.float32) if want_colsum else None
+    check(_lib.lib().isp_relu_mask_colsum(_p(dy), _p(y), _p(g), _p(cs), M, N, _stream()), "isp_relu_mask_colsum")
+    return g, cs
+
+
+def classifier_bwd(grad_logits, x, w):
+    """grad_logits [M] f32, x [M,C] bf16 (post-ReLU), w [C] f32 -> (dx bf16 masked by x>0, dw [C], db [1])."""
+    grad_logits = _need(grad_logits.contiguous(), torch.float32, "grad_logits")
+    _need(x, BF16, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x)
+    dw = torch.zeros(C, device=x.device, dtype=torch.float32)
+    db = torch.zeros(1, device=x.device, dtype=torch.float32)
+    check(_lib.lib().isp_classifier_bwd(_p(grad_logits), _p(x), _p(w), _p(dx), _p(dw), _p(db), M, C, _stream()),
+          "isp_classifier_bwd")
+    return dx, dw, db
+
+
+def resize_bilinear_nhwc_bwd(dout, h, w):
+    _need(dout, BF16, "dout")
+    B, H, W, C = dout.shape
+    din = torch.empty(B, h, w, C, device=dout.device, dtype=BF16)
+    check(_lib.lib().isp_resize_bilinear_ac_nhwc_bwd(_p(dout), _p(din), B, h, w, H, W, C, _stream()),
+          "isp_resize_bilinear_ac_nhwc_bwd")
+    return din
