@@ -1,0 +1,161 @@
+"""torch.autograd glue for the trainable tail of the path (seg head, resize, click patch-embed,
+after-backbone click injection).  Forward and backward are HIP kernels; autograd only carries the
+graph so that the reference's training loop (``loss.backward()``, Adam; core/training/trainer.py:
+219-226) runs unchanged.  Gradients of parameters are fp32; activation gradients bf16 NHWC.
+
+Scope: gradients flow logits -> head -> resize -> (features + click tokens) -> embed_coords.  The
+reference's default ``before_backbone`` injection also needs activation gradients through the
+frozen ViT and upsampler; that backward is not built -- the model raises when
+asked to train in that mode."""
+import torch
+
+from ... import hip_ops as ops
+
+BF16 = torch.bfloat16
+
+
+def _pack_conv(weight):
+    n = weight.shape[0]
+    return weight.detach().permute(0, 2, 3, 1).reshape(n, -1).to(BF16).contiguous()
+
+
+class Conv3x3ReluFn(torch.autograd.Function):
+    """relu(conv3x3(x) + bias): x [B,H,W,C] bf16 NHWC, weight [N,C,3,3] fp32 -> [B,H,W,N] bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = ops.conv3x3(x, _pack_conv(weight), bias.detach().float().contiguous(), "relu")
+        ctx.save_for_backward(x, y, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, weight = ctx.saved_tensors
+        B, H, W, C = x.shape
+        N = weight.shape[0]
+        M = B * H * W
+        g, db = ops.relu_mask_colsum(gy.contiguous(), y)
+        dw = torch.zeros(N, 9 * C, device=x.device, dtype=torch.float32)
+        for t in range(9):  # one pixel-reduction GEMM per tap, implicit im2col of x
+            ops.tn_gemm_atomic(g.view(M, N), x.view(M, C), dw[:, t * C:(t + 1) * C], shift=(H, W, t // 3 - 1, t % 3 - 1))
+        dweight = dw.view(N, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:  # data gradient = the same conv kernel with rotated, transposed weights
+            w_rot = weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * N).to(BF16).contiguous()
+            dx = ops.conv3x3(g, w_rot, None, None)
+        return dx, dweight, db
+
+
+class Conv1x1ReluFn(torch.autograd.Function):
+    """relu(x W^T + b) per pixel (SimpleConvSegHead layers)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, H, W, C = x.shape
+        w = weight.detach().flatten(1).to(BF16).contiguous()
+        y = ops.linear(x.view(-1, C), w, bias.detach().float().contiguous(), "relu").view(B, H, W, -1)
+        ctx.save_for_backward(x, y, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, weight = ctx.saved_tensors
+        B, H, W, C = x.shape
+        N = weight.shape[0]
+        M = B * H * W
+        g, db = ops.relu_mask_colsum(gy.contiguous(), y)
+        dw = torch.zeros(N, C, device=x.device, dtype=torch.float32)
+        ops.tn_gemm_atomic(g.view(M, N), x.view(M, C), dw)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().flatten(1).t().to(BF16).contiguous()  # [C, N]
+            dx = ops.linear(g.view(M, N), wt, None, None).view(B, H, W, C)
+        return dx, dw.view_as(weight), db
+
+
+class ClassifierFn(torch.autograd.Function):
+    """1x1 conv C -> 1 on a post-ReLU NHWC bf16 map -> logits [B,1,H,W] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, H, W, C = x.shape
+        w = weight.detach().float().reshape(-1).contiguous()
+        out = ops.classifier(x, w, float(bias.detach().float().item())).view(B, 1, H, W)
+        ctx.save_for_backward(x, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, gl):
+        x, weight = ctx.saved_tensors
+        w = weight.detach().float().reshape(-1).contiguous()
+        dx, dw, db = ops.classifier_bwd(gl.float().reshape(-1), x, w)
+        # NB: dx carries the ReLU mask of x (x is the output of a conv+ReLU layer); the producing
+        # layer's backward masks again with the same mask, which is idempotent.
+        return (dx if ctx.needs_input_grad[0] else None), dw.view_as(weight), db.view(1)
+
+
+class ResizeBilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        ctx.hw = x.shape[1:3]
+        return ops.resize_nhwc(x, H, W, "bilinear")
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ops.resize_bilinear_nhwc_bwd(gy.contiguous(), ctx.hw[0], ctx.hw[1]), None, None
+
+
+class TokenAddFn(torch.autograd.Function):
+    """features [B,T,D] bf16 (frozen backbone output) + click tokens [B,T,D] fp32 (DINOv2.py:516)."""
+
+    @staticmethod
+    def forward(ctx, feats, clicks):
+        out = feats.clone()
+        B, T, D = clicks.shape
+        ops.token_add_(out.view(-1, D), clicks.detach().float().contiguous(), B, T, has_cls=False)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        return None, gy.float()
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """tokens = patchify(maps) . W^T + b (featurizers/utils/patch_embed.py:37-42); the maps (click
+    disks, previous mask) carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, maps, weight, bias, patch, kpad):
+        D = weight.shape[0]
+        K = weight[0].numel()
+        wp = torch.zeros(D, kpad, device=weight.device, dtype=BF16)
+        wp[:, :K] = weight.detach().flatten(1).to(BF16)
+        A = ops.patchify(maps.float().contiguous(), None, None, patch, kpad)
+        tok = ops.linear(A, wp, bias.detach().float().contiguous(), None, out_dtype=torch.float32)
+        ctx.save_for_backward(A, weight)
+        B, _, H, W = maps.shape
+        return tok.view(B, (H // patch) * (W // patch), D)
+
+    @staticmethod
+    def backward(ctx, gtok):
+        A, weight = ctx.saved_tensors
+        D = weight.shape[0]
+        K = weight[0].numel()
+        g = gtok.reshape(-1, D).to(BF16).contiguous()
+        dw = torch.zeros(D, A.shape[1], device=A.device, dtype=torch.float32)
+        ops.tn_gemm_atomic(g, A, dw)
+        ones = torch.ones(g.shape[0], 8, device=g.device, dtype=BF16)
+        db = torch.zeros(D, 8, device=g.device, dtype=torch.float32)
+        ops.tn_gemm_atomic(g, ones, db)
+        return None, dw[:, :K].reshape(weight.shape).contiguous(), db[:, 0].contiguous(), None, None
+
+
+def grad_mode(*modules_or_params):
+    """True when autograd should record: grad enabled and something trainable is involved."""
+    if not torch.is_grad_enabled():
+        return False
+    for m in modules_or_params:
+        ps = m.parameters() if hasattr(m, "parameters") else [m]
+        if any(p.requires_grad for p in ps):
+            return True
+    return False

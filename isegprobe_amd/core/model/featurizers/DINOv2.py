@@ -24,6 +24,7 @@ from torch.nn.init import trunc_normal_
 from .... import hip_ops as ops
 from ...._lib import IspError
 from ...utils.log import logger
+from .._autograd import TokenAddFn
 from .._tensor import BF16, PackedCache, nchw_view
 
 ARCHS = {  # DINOv2.py:413-449 (vit_giant2 uses SwiGLU: not built)
@@ -226,19 +227,27 @@ class DINOv2Featurizer(nn.Module):
         inject = additional_features is not None and mode != "no_injection"
         if inject and mode not in ("before_backbone", "after_backbone"):
             raise NameError(f"Unknown feats_injection_mode: {mode}")
-        x = x.float().contiguous()
-        Wimg, bimg = self._image_weights()
-        A = ops.patchify(x, None, None, p, Wimg.shape[1])
-        xs, T = self._embed(A, Wimg, bimg, b, H, W)
+        wants_grad = torch.is_grad_enabled() and inject and additional_features.requires_grad
+        if wants_grad and mode == "before_backbone":
+            raise NotImplementedError(
+                "training with feats_injection_mode='before_backbone' needs the backward of the frozen ViT "
+                "(activation gradients, SURVEY.md fact 8), which is not built; use 'after_backbone' or no_grad")
         D = self.model.embed_dim
-        if inject:
-            if tuple(additional_features.shape) != (b, T, D):
-                raise AssertionError(f"x.shape: {(b, T, D)}, additional_features.shape: {tuple(additional_features.shape)}")
-            if mode == "before_backbone":  # DINOv2.py:518-523
-                ops.token_add_(xs, additional_features, b, T, has_cls=True)
-        feats = self._blocks(xs, b, T)
-        if inject and mode == "after_backbone":  # DINOv2.py:509-516
-            ops.token_add_(feats, additional_features, b, T, has_cls=False)
+        with torch.no_grad():  # frozen trunk: no graph
+            x = x.float().contiguous()
+            Wimg, bimg = self._image_weights()
+            A = ops.patchify(x, None, None, p, Wimg.shape[1])
+            xs, T = self._embed(A, Wimg, bimg, b, H, W)
+            if inject:
+                if tuple(additional_features.shape) != (b, T, D):
+                    raise AssertionError(f"x.shape: {(b, T, D)}, additional_features.shape: {tuple(additional_features.shape)}")
+                if mode == "before_backbone":  # DINOv2.py:518-523
+                    ops.token_add_(xs, additional_features, b, T, has_cls=True)
+            feats = self._blocks(xs, b, T)
+            if inject and mode == "after_backbone" and not wants_grad:  # DINOv2.py:509-516
+                ops.token_add_(feats, additional_features, b, T, has_cls=False)
+        if wants_grad:  # after_backbone, training: the add is the first node of the autograd graph
+            feats = TokenAddFn.apply(feats.view(b, T, D), additional_features)
         return nchw_view(feats.view(b, h, w, D))  # DINOv2.py:545
 
     def forward_fused_clicks(self, image, prev_mask, click_maps, embed_coords):

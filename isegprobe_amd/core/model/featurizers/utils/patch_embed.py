@@ -6,6 +6,7 @@ import torch
 from torch import nn
 
 from ..... import hip_ops as ops
+from ..._autograd import PatchEmbedFn, grad_mode
 from ..._tensor import BF16, PackedCache
 
 
@@ -45,6 +46,8 @@ class PatchEmbed(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B, C, H, W = x.shape
         p = self.patch_size[0]
+        if grad_mode(self.proj):
+            return PatchEmbedFn.apply(x, self.proj.weight, self.proj.bias, p, _pad64(self.proj.weight[0].numel()))
         wp, bias = self.packed()
         x = x.float().contiguous()
         A = ops.patchify(x, None, None, p, wp.shape[1])

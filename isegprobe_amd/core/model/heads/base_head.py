@@ -6,6 +6,7 @@ import torch.nn as nn
 
 from .... import hip_ops as ops
 from ...._lib import IspError
+from .._autograd import ClassifierFn, grad_mode
 from .._tensor import BF16, PackedCache
 
 
@@ -27,6 +28,9 @@ class BaseClassifierHead(nn.Module):
 
     def _classify(self, x_nhwc):
         """1x1 conv C -> num_classes on an NHWC bf16 map -> [B, num_classes, H, W] f32."""
+        if grad_mode(self.classifier) or (torch.is_grad_enabled() and x_nhwc.requires_grad):
+            self._cls_weights()  # validates num_classes
+            return ClassifierFn.apply(x_nhwc, self.classifier.weight, self.classifier.bias)
         w, b = self._cls_weights()
         B, H, W, _ = x_nhwc.shape
         return ops.classifier(x_nhwc, w, b).view(B, 1, H, W)

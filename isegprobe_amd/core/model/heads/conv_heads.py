@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .... import hip_ops as ops
+from .._autograd import ClassifierFn, Conv1x1ReluFn, Conv3x3ReluFn, grad_mode
 from .._tensor import BF16, PackedCache, to_nhwc_bf16
 from .base_head import BaseClassifierHead
 
@@ -30,6 +31,9 @@ class ConvModule(nn.Module):
         return self._packed.get((self.conv.weight, self.conv.bias), build)
 
     def run(self, x_nhwc):
+        if grad_mode(self.conv) or (torch.is_grad_enabled() and x_nhwc.requires_grad):
+            fn = Conv3x3ReluFn if self.conv.kernel_size == (3, 3) else Conv1x1ReluFn
+            return fn.apply(x_nhwc, self.conv.weight, self.conv.bias)
         w, b = self.packed()
         if self.conv.kernel_size == (3, 3):
             return ops.conv3x3(x_nhwc, w, b, "relu")
@@ -44,7 +48,7 @@ class SimpleClassifierHead(BaseClassifierHead):
         super().__init__(in_channels, num_classes)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self._classify(to_nhwc_bf16(x))
+        return self._classify(to_nhwc_bf16(x))  # (BaseClassifierHead._classify records autograd when training)
 
 
 class _StackedHead(BaseClassifierHead):
@@ -63,7 +67,9 @@ class _StackedHead(BaseClassifierHead):
     def _tail(self, y, layers):
         """Remaining conv layers + classifier; a trailing 3x3 layer is fused with the 1x1 classifier
         (its output map is never stored)."""
-        if layers and layers[-1].conv.kernel_size == (3, 3) and self.num_classes == 1 and (y.numel() // y.shape[-1]) % 4 == 0:
+        training = grad_mode(self) or (torch.is_grad_enabled() and y.requires_grad)
+        if (not training and layers and layers[-1].conv.kernel_size == (3, 3) and self.num_classes == 1
+                and (y.numel() // y.shape[-1]) % 4 == 0):
             for layer in layers[:-1]:
                 y = layer.run(y)
             w, b = layers[-1].packed()

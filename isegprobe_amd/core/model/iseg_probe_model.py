@@ -67,7 +67,8 @@ class iSegProbeModel(iSegBaseModel):
                 and isinstance(self.maps_transform, nn.Identity))
 
     def _forward_prepared(self, image, prev_mask, points):
-        if self._fusable():
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self._fusable() and not training:
             # click maps go straight into the patch matrix: no torch.cat, no token round trip
             maps = self.dist_maps(image, points)
             feats = self.backbone.forward_fused_clicks(image, prev_mask, maps, self.embed_coords)
@@ -81,7 +82,9 @@ class iSegProbeModel(iSegBaseModel):
 
     def _after_backbone(self, image, backbone_features):
         if self.architecture == "backbone_upsampler_head":
-            if (self.fold_upsampler_affine and isinstance(self.upsampler, JBUFeatUpUpsampler)
+            if (not (torch.is_grad_enabled() and backbone_features.requires_grad)
+                    and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.head.parameters()))
+                    and self.fold_upsampler_affine and isinstance(self.upsampler, JBUFeatUpUpsampler)
                     and isinstance(self.head, ConvSegHead) and self.head.num_layers >= 1):
                 # JBUStack ends with z = x + 0.1*conv1x1(x); that affine map commutes with the bilinear
                 # resize and folds into the head's first conv: the 2.5 TFLOP 1x1 GEMM disappears
@@ -98,8 +101,12 @@ class iSegProbeModel(iSegBaseModel):
     def _resize_and_head(self, image, hr_features):
         if self.upsampler_type != "identity" and image.size()[2:] != hr_features.size()[2:]:
             # iseg_probe_model.py:120-129: bilinear(align_corners=True) to the image size
-            hr_features = nchw_view(ops.resize_nhwc(to_nhwc_bf16(hr_features), image.shape[2], image.shape[3],
-                                                    "bilinear"))
+            x = to_nhwc_bf16(hr_features)
+            if torch.is_grad_enabled() and x.requires_grad:
+                from ._autograd import ResizeBilinearFn
+                hr_features = nchw_view(ResizeBilinearFn.apply(x, image.shape[2], image.shape[3]))
+            else:
+                hr_features = nchw_view(ops.resize_nhwc(x, image.shape[2], image.shape[3], "bilinear"))
         return self.head(hr_features)
 
     def get_lowres_highres_feats(self, image: torch.Tensor, points: torch.Tensor) -> Tuple:

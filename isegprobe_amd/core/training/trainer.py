@@ -1,0 +1,90 @@
+"""Data-parallel training step for the probe (reference core/training/trainer.py:193-314,377-477,
+577-618), reduced to what sits on the dense-feature path:
+
+  batch -> [0..max_num_next_clicks no-grad forwards that simulate corrective clicks] -> forward
+        -> NFL loss -> backward (HIP kernels through core/model/_autograd.py) -> ONE flat-bucket
+        all-reduce of the trainable gradients (RCCL over xGMI; utils/distributed.GradBucket)
+        -> Adam step.
+
+The reference wraps the net in DistributedDataParallel; here the collective is explicit and sits
+between backward and the optimizer step, on the gradient step only.  Dataset readers, augmentation,
+samplers, logging and checkpoint cadence are outside this path.
+Click simulation: the reference picks a random interior point of the largest error region using
+OpenCV's 5x5 chamfer distance transform; OpenCV is not a dependency, so the exact Euclidean
+transform (scipy) is used -- the sampled point differs, the training signal is the same in kind."""
+import random
+from typing import Dict
+
+import numpy as np
+import torch
+from scipy.ndimage import distance_transform_edt
+
+from ..utils import distributed as D
+from .losses import NormalizedFocalLossSigmoid
+
+
+def get_next_points(pred, gt, points, click_indx, pred_thresh=0.49, rng=np.random):
+    """trainer.py:577-618: add one corrective click per sample at slot (num_points - click_indx)."""
+    assert click_indx > 0
+    pred = pred.detach().float().cpu().numpy()[:, 0]
+    gt = gt.detach().cpu().numpy()[:, 0] > 0.5
+    fn_mask = np.pad(np.logical_and(gt, pred < pred_thresh), ((0, 0), (1, 1), (1, 1)), "constant")
+    fp_mask = np.pad(np.logical_and(~gt, pred > pred_thresh), ((0, 0), (1, 1), (1, 1)), "constant")
+    num_points = points.size(1) // 2
+    points = points.clone()
+    for b in range(fn_mask.shape[0]):
+        fn_dt = distance_transform_edt(fn_mask[b])[1:-1, 1:-1]
+        fp_dt = distance_transform_edt(fp_mask[b])[1:-1, 1:-1]
+        fn_max, fp_max = fn_dt.max(), fp_dt.max()
+        is_positive = fn_max > fp_max
+        dt = fn_dt if is_positive else fp_dt
+        indices = np.argwhere(dt > max(fn_max, fp_max) / 2.0)
+        if len(indices) > 0:
+            r, c = indices[rng.randint(0, len(indices))]
+            slot = (num_points if is_positive else 2 * num_points) - click_indx
+            points[b, slot, 0], points[b, slot, 1], points[b, slot, 2] = float(r), float(c), float(click_indx)
+    return points
+
+
+class DataParallelTrainer:
+    def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, max_num_next_clicks=3,
+                 prev_mask_drop_prob=0.0, loss=None):
+        self.net = model
+        self.loss_fn = loss or NormalizedFocalLossSigmoid(alpha=0.5, gamma=2)
+        self.max_num_next_clicks = max_num_next_clicks
+        self.prev_mask_drop_prob = prev_mask_drop_prob
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.bucket = D.GradBucket(params)
+        self.optim = torch.optim.Adam(params, lr=lr, betas=betas, eps=eps)  # trainer.py:141, optimizer.py:14-35
+
+    def batch_forward(self, batch: Dict, num_iters=None):
+        """trainer.py:377-477 (training branch)."""
+        image, gt_mask, points = batch["images"], batch["instances"], batch["points"]
+        prev_output = torch.zeros_like(image[:, :1], dtype=torch.float32)
+        with torch.no_grad():
+            if num_iters is None:
+                num_iters = random.randint(0, self.max_num_next_clicks)
+            for click_indx in range(num_iters):
+                self.net.eval()
+                net_input = torch.cat((image, prev_output), dim=1) if self.net.with_prev_mask else image
+                prev_output = torch.sigmoid(self.net(net_input, points)["instances"])
+                points = get_next_points(prev_output, gt_mask, points, click_indx + 1)
+                self.net.train()
+            if self.net.with_prev_mask and self.prev_mask_drop_prob > 0 and num_iters > 0:
+                zero = torch.from_numpy(np.random.random(size=prev_output.size(0)) < self.prev_mask_drop_prob)
+                prev_output[zero.to(prev_output.device)] = 0
+        net_input = torch.cat((image, prev_output), dim=1) if self.net.with_prev_mask else image
+        output = self.net(net_input, points)
+        loss = self.loss_fn(output["instances"], gt_mask).mean()
+        return loss, output
+
+    def step(self, batch: Dict, num_iters=None):
+        """One optimisation step; returns the (rank-local) loss as a 0-dim tensor."""
+        self.net.train()
+        self.bucket.zero()
+        loss, _ = self.batch_forward(batch, num_iters)
+        loss.backward()
+        work = self.bucket.all_reduce_mean(async_op=True)  # gradient step only; overlaps host-side bookkeeping
+        self.bucket.finish(work)
+        self.optim.step()
+        return loss.detach()

@@ -41,6 +41,13 @@ def forward(image, points, w, cfg):
     injection, upsampler ('identity'|'nearest'|'bilinear'|'bicubic'|'lift'|'loftup'|'jbu_featup'),
     with_prev_mask, use_disks, norm_radius.  Returns logits [B,1,H,W]."""
     with torch.no_grad():
+        return forward_with_grad(image, points, w, cfg)
+
+
+def forward_with_grad(image, points, w, cfg):
+    """Same computation with autograd left on (weights in `w` may require grad): the oracle for the
+    backward kernels."""
+    if True:
         image = image.float()
         prev = None
         if cfg.get("with_prev_mask", True):  # iseg_base_model.py:91-98
