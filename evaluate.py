@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""NoC evaluation entry point on the HIP path (the reference's evaluate.py:30-221 is a Hydra script
+around the same loop: load model -> get_predictor(NoBRS, flip, zoom-in fixed<S>) -> evaluate_dataset ->
+NoC table).
+
+    python evaluate.py --dataset /path/to/GrabCut --checkpoint ckpt.pth --eval-mode fixed224
+    python evaluate.py --synthetic 50                 # GrabCut-layout fixture of seeded ellipses
+"""
+import argparse
+import os
+import sys
+import tempfile
+from datetime import timedelta
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset", default=None, help="GrabCut/Berkeley-layout directory")
+    ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N synthetic GrabCut-layout samples")
+    ap.add_argument("--checkpoint", default=None, help="reference-format checkpoint {'state_dict','config'}")
+    ap.add_argument("--arch", default="dinov2_vits14")
+    ap.add_argument("--upsampler", default="bilinear")
+    ap.add_argument("--eval-mode", default="fixed224", help="fixed<H>[,<W>] (reference eval_cfg.yaml:36)")
+    ap.add_argument("--n-clicks", type=int, default=20)
+    ap.add_argument("--thresh", type=float, default=0.5)
+    ap.add_argument("--target-iou", type=float, default=0.90)
+    args = ap.parse_args()
+
+    import isegprobe_amd
+    from isegprobe_amd.core.inference.datasets import GrabCutLayoutDataset, write_synthetic_grabcut
+    from isegprobe_amd.core.inference.evaluation import evaluate_dataset
+    from isegprobe_amd.core.inference.predictors import get_predictor
+    from isegprobe_amd.core.inference.utils import compute_noc_metric
+    from isegprobe_amd.core.model import iSegProbeModel
+    from isegprobe_amd.core.utils.serialization import load_model
+
+    parts = args.eval_mode[5:].split(",")
+    crop = (int(parts[0]), int(parts[1]) if len(parts) > 1 else int(parts[0]))  # inference/utils.py:307-316
+    device = torch.device("cuda")
+    if args.checkpoint:
+        isegprobe_amd.install_as_core()  # reference checkpoints name core.* classes
+        ckpt = torch.load(args.checkpoint, map_location="cpu", weights_only=False)
+        model = load_model(ckpt["config"])
+        print("load_state_dict:", model.load_state_dict(ckpt["state_dict"], strict=False))
+    else:
+        dim = {"dinov2_vits14": 384, "dinov2_vitb14": 768, "dinov2_vitl14": 1024}[args.arch]
+        up_params = {"backbone_type": "dinov2"} if args.upsampler == "jbu_featup" else None
+        torch.manual_seed(0)
+        model = iSegProbeModel(
+            backbone_cfg={"type": "dinov2", "params": {"arch": args.arch, "feats_injection_mode": "before_backbone"}},
+            head_cfg={"type": "convhead", "params": dict(in_channels=dim, num_layers=2, num_classes=1)},
+            embed_coords_cfg={"type": "patchEmbed", "params": dict(img_size=crop, patch_size=(14, 14), embed_dim=dim)},
+            upsampler_cfg={"type": args.upsampler, "params": up_params},
+            use_disks=True, norm_radius=5, with_prev_mask=True)
+    model = model.to(device).eval()
+
+    tmp = None
+    if args.synthetic:
+        tmp = tempfile.TemporaryDirectory()
+        args.dataset = str(write_synthetic_grabcut(tmp.name, args.synthetic))
+    if not args.dataset:
+        raise SystemExit("give --dataset or --synthetic N")
+    dataset = GrabCutLayoutDataset(args.dataset)
+    predictor = get_predictor(model, "NoBRS", device, prob_thresh=args.thresh,
+                              zoom_in_params={"skip_clicks": -1, "target_size": crop})
+    # print_ious=True in the reference forces all n_clicks to run (inference/utils.py:254-255)
+    all_ious, elapsed = evaluate_dataset(dataset, predictor, pred_thr=args.thresh, max_iou_thr=1.01,
+                                         min_clicks=1, max_clicks=args.n_clicks)
+    noc, noc_std, over = compute_noc_metric(all_ious, [0.8, 0.85, args.target_iou], max_clicks=args.n_clicks)
+    n_clicks_total = sum(len(x) for x in all_ious)
+    print(f"|{'Upsampler':^22}|{'Dataset':^11}|{'NoC@80%':^9}|{'NoC@85%':^9}|{'NoC@' + str(int(args.target_iou * 100)) + '%':^9}|"
+          f"{'IoU@1':^9}|{'SPC,s':^7}|{'Time':^9}|")
+    print(f"|{model.upsampler.__class__.__name__:^22}|{os.path.basename(args.dataset.rstrip('/'))[:11]:^11}|"
+          f"{noc[0]:^9.2f}|{noc[1]:^9.2f}|{noc[2]:^9.2f}|{np.mean([x[0] for x in all_ious]):^9.2f}|"
+          f"{elapsed / max(n_clicks_total, 1):^7.3f}|{str(timedelta(seconds=int(elapsed))):^9}|")
+    if tmp:
+        tmp.cleanup()
+
+
+if __name__ == "__main__":
+    main()

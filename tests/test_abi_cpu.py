@@ -67,3 +67,35 @@ def test_serialize_roundtrip():
     m2 = load_model(m._config)
     assert type(m2) is type(m) and set(m2.state_dict()) == set(m.state_dict())
     assert m2.upsampler_type == "identity" and m2.with_prev_mask
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """{"state_dict", "config"} as core/utils/misc.py:68 writes it, resolved through the `core.*` alias
+    exactly like a reference checkpoint (serialization.py:61-91)."""
+    import isegprobe_amd
+    from helpers import build_model
+    from isegprobe_amd.core.utils.serialization import load_model
+    m = build_model("bilinear")
+    m.save_cfg = {"backbone": False, "upsampler": False, "head": True, "embed_coords": True}
+    cfg = dict(m._config)
+    cfg["class"] = "core.model.iseg_probe_model.iSegProbeModel"  # what a reference checkpoint names
+    path = tmp_path / "last_checkpoint.pth"
+    torch.save({"state_dict": m.get_state_dict_to_save(), "config": cfg}, str(path))
+    isegprobe_amd.install_as_core()
+    ckpt = torch.load(str(path), map_location="cpu", weights_only=False)
+    m2 = load_model(ckpt["config"])
+    msg = m2.load_state_dict(ckpt["state_dict"], strict=False)
+    assert not msg.unexpected_keys and all(k.startswith(("backbone.", "upsampler.")) for k in msg.missing_keys)
+    assert torch.equal(m2.head.convs[0].conv.weight, m.head.convs[0].conv.weight)
+    assert type(m2).__name__ == "iSegProbeModel"
+
+
+def test_grabcut_layout_reader(tmp_path):
+    import numpy as np
+    from isegprobe_amd.core.inference.datasets import GrabCutLayoutDataset, write_synthetic_grabcut
+    ds = GrabCutLayoutDataset(write_synthetic_grabcut(tmp_path, n=3, size=(60, 80)))
+    assert len(ds) == 3
+    s = ds.get_sample(1)
+    assert s.image.shape == (60, 80, 3) and s.image.dtype == np.uint8
+    m = s.gt_mask(1)
+    assert set(np.unique(m)) == {-1, 0, 1} and s.objects_ids == [1]
