@@ -80,7 +80,7 @@ class DinoVisionTransformer(nn.Module):
     """Parameter container with the hub key layout; see module docstring."""
 
     def __init__(self, img_size=518, patch_size=14, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4.0,
-                 init_values=1.0):
+                 init_values=1.0, mask_token=True):
         super().__init__()
         if embed_dim % num_heads or embed_dim // num_heads != 64:
             raise NotImplementedError("the fused attention kernel is built for head_dim 64")
@@ -94,7 +94,8 @@ class DinoVisionTransformer(nn.Module):
         self.pos_embed = nn.Parameter(torch.zeros(1, grid * grid + 1, embed_dim))
         self.blocks = nn.ModuleList([_Block(embed_dim, mlp_ratio, init_values) for _ in range(depth)])
         self.norm = nn.LayerNorm(embed_dim, eps=LN_EPS)
-        self.mask_token = nn.Parameter(torch.zeros(1, embed_dim))
+        if mask_token:
+            self.mask_token = nn.Parameter(torch.zeros(1, embed_dim))
         trunc_normal_(self.pos_embed, std=0.02)  # DINOv2.py:194-197
         nn.init.normal_(self.cls_token, std=1e-6)
         for m in self.modules():
@@ -193,13 +194,16 @@ class DINOv2Featurizer(nn.Module):
         x.view(B, T + 1, D)[:, 0].copy_(cls_row)  # cls_token + pos[0] (DINOv2.py:525-528)
         return x, T
 
-    def _blocks(self, x, B, T):
+    def _blocks(self, x, B, T, want_last_keys=False):
         P = self.packed()
         heads = self.model.num_heads
         L = T + 1
-        for blk in P["blocks"]:
+        nblk = len(P["blocks"])
+        for i, blk in enumerate(P["blocks"]):
             hbuf = ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS)
             qkv = ops.linear(hbuf, blk["qkv_w"], blk["qkv_b"])
+            if want_last_keys and i == nblk - 1:
+                return qkv  # packed [B*L, 3, heads, 64]: the caller extracts K; the rest of the block is unused
             att = ops.attention_packed_qkv(qkv, B, L, heads, 64 ** -0.5)
             ops.linear_residual_(x, att, blk["proj_w"], blk["proj_b"], blk["ls1"])
             hbuf = ops.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS)

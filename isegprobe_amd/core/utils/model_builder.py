@@ -4,7 +4,7 @@ from typing import Dict
 
 import torch.nn as nn
 
-from ..model.featurizers import DINOv2Featurizer
+from ..model.featurizers import DINOFeaturizer, DINOv2Featurizer
 from ..model.heads import HEAD_REGISTRY, BaseClassifierHead
 from ..model.upsamplers import UPSAMPLER_REGISTRY, BaseUpsampler
 from .log import logger
@@ -20,7 +20,9 @@ class ModelBuilder:
         type = type.lower()
         if type == "dinov2":
             backbone = DINOv2Featurizer(**params)
-        elif type in ("mask_clip", "vit", "simple_vit"):
+        elif type == "vit":
+            backbone = DINOFeaturizer(**params)
+        elif type in ("mask_clip", "simple_vit"):
             # reference model_builder.py:28-51; these backbones are later rows of the scope table
             raise NotImplementedError(f"featurizer '{type}' has no HIP path yet (DINOv2 is built)")
         else:

@@ -110,3 +110,40 @@ def dinov2_features(image, w, *, patch, depth, heads, click_tokens=None,
     if return_tokens:
         return feats
     return feats.reshape(-1, h, wd, D).permute(0, 3, 1, 2)  # :545
+
+
+def dino_features(image, w, *, patch, depth, heads, feat_type="key", click_tokens=None,
+                  injection="before_backbone", prefix=""):
+    """DINOFeaturizer.forward (reference core/model/featurizers/DINO.py:529-611), n=1: a DINO-v1
+    style ViT (no LayerScale, qkv bias, LN eps 1e-6) that returns either the last block's KEYS
+    (``feat_type="key"``: channel index = d*heads + head, :588-603) or its normalised tokens."""
+    w = {k[len(prefix):]: v for k, v in w.items() if k.startswith(prefix)} if prefix else w
+    B, _, H, W = image.shape
+    assert H % patch == 0 and W % patch == 0  # DINO.py:536-537
+    h, wd = H // patch, W // patch
+    D = w["cls_token"].shape[-1]
+    x = patch_tokens(image, w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], patch)
+    if click_tokens is not None and injection == "before_backbone":  # :542-549
+        assert x.shape == click_tokens.shape
+        x = x + click_tokens
+    x = torch.cat((w["cls_token"].expand(B, -1, -1), x), dim=1)
+    x = x + interpolated_pos_embed(w["pos_embed"], x.shape[1], H, W, patch)  # DINO.py:289-314, same recipe
+    keys = None
+    for i in range(depth):
+        p = f"blocks.{i}."
+        if i == depth - 1:  # qkv of the last block (DINO.py:107-143 returns it)
+            xn = F.layer_norm(x, (D,), w[p + "norm1.weight"], w[p + "norm1.bias"], LN_EPS)
+            qkv = F.linear(xn, w[p + "attn.qkv.weight"], w.get(p + "attn.qkv.bias"))
+            keys = qkv.reshape(B, -1, 3, heads, D // heads)[:, :, 1]  # [B, N, heads, hd]
+        x = block(x, w, p, heads)
+    feat = F.layer_norm(x, (D,), w["norm.weight"], w["norm.bias"], LN_EPS)
+    if feat_type == "token":
+        out = feat[:, 1:]
+    elif feat_type == "key":
+        out = keys[:, 1:].permute(0, 1, 3, 2).flatten(2)  # [B, T, hd*heads]: index d*heads + head
+    else:
+        raise ValueError("Unknown feat type:{}".format(feat_type))
+    if click_tokens is not None and injection == "after_backbone":  # :572-580 / :590-597
+        assert out.shape == click_tokens.shape
+        out = out + click_tokens
+    return out.reshape(B, h, wd, -1).permute(0, 3, 1, 2)

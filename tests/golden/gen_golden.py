@@ -279,6 +279,36 @@ def gen_vit():
     save("vit_tiny", **out)
 
 
+def gen_dino():
+    """DINOFeaturizer ("vit" backbone type): tiny DINO-v1 ViT with seeded weights (the constructor's
+    timm / torch.hub weight fetch, DINO.py:497-510, is bypassed)."""
+    from functools import partial
+    from core.model.featurizers.DINO import DINOFeaturizer, VisionTransformer
+    torch.manual_seed(8)
+    out = {}
+    for feat_type in ("key", "token"):
+        for inj in ("before_backbone", "after_backbone"):
+            f = DINOFeaturizer.__new__(DINOFeaturizer)
+            nn.Module.__init__(f)
+            f.arch, f.patch_size, f.feat_type, f.feats_injection_mode, f.n_feats = "vit_small", 16, feat_type, inj, 128
+            f.model = VisionTransformer(img_size=[64], patch_size=16, embed_dim=128, depth=2, num_heads=2,
+                                        mlp_ratio=4, qkv_bias=True, num_classes=0,
+                                        norm_layer=partial(nn.LayerNorm, eps=1e-6))
+            seeded_(f, 12)
+            with torch.no_grad():
+                f.model.pos_embed.mul_(0.3)
+            f.eval()
+            x = torch.randn(2, 3, 64, 96)  # even patch-grid rows: DINO.py:205-208 drops a row+col otherwise
+            clicks = 0.5 * torch.randn(2, 4 * 6, 128)
+            with torch.no_grad():
+                y = f(x, clicks.clone())
+            tag = f"{feat_type}_{inj}"
+            out[tag + "_x"], out[tag + "_clicks"], out[tag + "_y"] = x.numpy(), clicks.numpy(), y.contiguous().numpy()
+    for k, v in sd_np(f.model).items():
+        out["w::" + k] = v
+    save("dino_tiny", **out)
+
+
 def gen_upsamplers_and_head():
     from core.model.heads import HEAD_REGISTRY
     from core.model.upsamplers import UPSAMPLER_REGISTRY
@@ -467,8 +497,8 @@ def gen_inference():
 def main():
     torch.set_num_threads(4)
     install_standins()
-    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "upsamplers", "model", "inference"]
-    fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit,
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "upsamplers", "model", "inference"]
+    fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino,
            "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference}
     for w in which:
         fns[w]()

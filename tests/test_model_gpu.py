@@ -153,3 +153,21 @@ def test_tiny_lift_model_vs_golden(golden):
     print(f"lift model: max {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g} ref rms {ref.pow(2).mean().sqrt():.3f}")
     assert _close(y, ref, TOL_TINY), err.max().item()
     assert _mask_agreement(y, ref, TOL_TINY) == 1.0
+
+
+@pytest.mark.parametrize("feat_type", ["key", "token"])
+@pytest.mark.parametrize("inj", ["before_backbone", "after_backbone"])
+def test_dino_vit_featurizer_vs_golden(golden, feat_type, inj):
+    from isegprobe_amd.core.utils.model_builder import ModelBuilder
+    g = golden("dino_tiny")
+    f = ModelBuilder().load_featurizer("vit", dict(arch="vit_small", patch_size=16, feat_type=feat_type, feats_injection_mode=inj,
+                                                   vit_kwargs=dict(img_size=64, embed_dim=128, depth=2, num_heads=2)))
+    f.model.load_state_dict(weights_from(g, "w"))
+    f = f.cuda().eval()
+    tag = f"{feat_type}_{inj}"
+    with torch.no_grad():
+        y = f(torch.from_numpy(g[tag + "_x"]).cuda(), torch.from_numpy(g[tag + "_clicks"]).cuda())
+    ref = torch.from_numpy(g[tag + "_y"])
+    assert y.shape == ref.shape
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err < 3e-2 * max(1.0, ref.abs().max().item()), err

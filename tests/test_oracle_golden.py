@@ -114,3 +114,13 @@ def test_model_forward(golden, up):
     w = {**weights_from(g, "common_w"), **weights_from(g, up.replace("_after", "") + "_w")}
     y = omodel.forward(torch.from_numpy(g["image"]), torch.from_numpy(g["points"]), w, cfg)
     np.testing.assert_allclose(y.numpy(), g[up + "_logits"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("feat_type", ["key", "token"])
+@pytest.mark.parametrize("inj", ["before_backbone", "after_backbone"])
+def test_dino_vit_features(golden, feat_type, inj):
+    g = golden("dino_tiny")
+    tag = f"{feat_type}_{inj}"
+    y = ovit.dino_features(torch.from_numpy(g[tag + "_x"]), weights_from(g, "w"), patch=16, depth=2, heads=2,
+                           feat_type=feat_type, click_tokens=torch.from_numpy(g[tag + "_clicks"]), injection=inj)
+    np.testing.assert_allclose(y.numpy(), g[tag + "_y"], atol=2e-5, rtol=1e-5)
