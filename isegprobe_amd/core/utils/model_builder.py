@@ -4,10 +4,10 @@ from typing import Dict
 
 import torch.nn as nn
 
-from ..model.featurizers import DINOFeaturizer, DINOv2Featurizer
-from ..model.heads import HEAD_REGISTRY, BaseClassifierHead
-from ..model.upsamplers import UPSAMPLER_REGISTRY, BaseUpsampler
 from .log import logger
+
+# the plugin registries are imported inside the loaders: `core.model` imports this module
+# (iSegProbeModel's default builder), so a module-level import would be circular
 
 
 class ModelBuilder:
@@ -17,12 +17,18 @@ class ModelBuilder:
         pass
 
     def load_featurizer(self, type: str, params: Dict, freeze: bool = True) -> nn.Module:
+        from ..model.featurizers import DINOFeaturizer, DINOv2Featurizer, SimpleViTFeaturizer
         type = type.lower()
         if type == "dinov2":
             backbone = DINOv2Featurizer(**params)
         elif type == "vit":
             backbone = DINOFeaturizer(**params)
-        elif type in ("mask_clip", "simple_vit"):
+        elif type == "simple_vit":  # model_builder.py:40-49
+            backbone = SimpleViTFeaturizer(image_size=params["img_size"], patch_size=params["patch_size"],
+                                           dim=params["embed_dim"], depth=params["depth"], heads=params["heads"],
+                                           mlp_dim=params["mlp_dim"], channels=params["channels"],
+                                           dim_head=params["dim_head"])
+        elif type == "mask_clip":
             # reference model_builder.py:28-51; these backbones are later rows of the scope table
             raise NotImplementedError(f"featurizer '{type}' has no HIP path yet (DINOv2 is built)")
         else:
@@ -32,7 +38,8 @@ class ModelBuilder:
                 param.requires_grad = False
         return backbone
 
-    def load_upsampler(self, type: str, params: Dict = None, freeze: bool = True) -> BaseUpsampler:
+    def load_upsampler(self, type: str, params: Dict = None, freeze: bool = True):
+        from ..model.upsamplers import UPSAMPLER_REGISTRY
         type = type.lower()
         if type not in UPSAMPLER_REGISTRY:
             raise ValueError(f"Unsupported upsampler type: {type}")
@@ -44,7 +51,8 @@ class ModelBuilder:
         logger.info(f"UPSAMPLER: Loaded {upsampler.__class__.__name__}")
         return upsampler
 
-    def load_head(self, type: str, params: Dict, freeze: Dict = False) -> BaseClassifierHead:
+    def load_head(self, type: str, params: Dict, freeze: Dict = False):
+        from ..model.heads import HEAD_REGISTRY
         if type not in HEAD_REGISTRY:
             raise ValueError(f"Unsupported head type: {type}")
         head = HEAD_REGISTRY[type](**params)

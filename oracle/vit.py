@@ -147,3 +147,34 @@ def dino_features(image, w, *, patch, depth, heads, feat_type="key", click_token
         assert out.shape == click_tokens.shape
         out = out + click_tokens
     return out.reshape(B, h, wd, -1).permute(0, 3, 1, 2)
+
+
+def simple_vit_tokens(x, w, *, patch, heads, dim_head=64, depth=None, prefix=""):
+    """SimpleViTFeaturizer.forward (reference core/model/featurizers/simple_ViT.py:96-150): patches in
+    (p1 p2 c) order -> LN -> Linear -> LN -> + 2-D sincos pos-emb -> pre-norm transformer -> LN."""
+    w = {k[len(prefix):]: v for k, v in w.items() if k.startswith(prefix)} if prefix else w
+    B, C, H, W = x.shape
+    h, wd = H // patch, W // patch
+    t = x.reshape(B, C, h, patch, wd, patch).permute(0, 2, 4, 3, 5, 1).reshape(B, h * wd, patch * patch * C)
+    t = F.layer_norm(t, (t.shape[-1],), w["to_patch_embedding.1.weight"], w["to_patch_embedding.1.bias"])
+    t = F.linear(t, w["to_patch_embedding.2.weight"], w["to_patch_embedding.2.bias"])
+    dim = t.shape[-1]
+    t = F.layer_norm(t, (dim,), w["to_patch_embedding.3.weight"], w["to_patch_embedding.3.bias"])
+    # posemb_sincos_2d (simple_ViT.py:18-27)
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(wd), indexing="ij")
+    omega = 1.0 / (10000 ** (torch.arange(dim // 4) / (dim // 4 - 1)))
+    yy, xx = yy.flatten()[:, None] * omega[None, :], xx.flatten()[:, None] * omega[None, :]
+    t = t + torch.cat((xx.sin(), xx.cos(), yy.sin(), yy.cos()), dim=1).float()
+    i = 0
+    while f"transformer.layers.{i}.0.to_qkv.weight" in w:
+        p = f"transformer.layers.{i}."
+        a = F.layer_norm(t, (dim,), w[p + "0.norm.weight"], w[p + "0.norm.bias"])
+        q, k, v = F.linear(a, w[p + "0.to_qkv.weight"]).chunk(3, dim=-1)
+        sp = lambda z: z.reshape(B, -1, heads, dim_head).transpose(1, 2)
+        att = ((sp(q) @ sp(k).transpose(-1, -2)) * dim_head ** -0.5).softmax(-1) @ sp(v)
+        t = F.linear(att.transpose(1, 2).reshape(B, -1, heads * dim_head), w[p + "0.to_out.weight"]) + t
+        f = F.layer_norm(t, (dim,), w[p + "1.net.0.weight"], w[p + "1.net.0.bias"])
+        f = F.linear(F.gelu(F.linear(f, w[p + "1.net.1.weight"], w[p + "1.net.1.bias"])), w[p + "1.net.3.weight"], w[p + "1.net.3.bias"])
+        t = f + t
+        i += 1
+    return F.layer_norm(t, (dim,), w["transformer.norm.weight"], w["transformer.norm.bias"])

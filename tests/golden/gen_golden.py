@@ -309,6 +309,20 @@ def gen_dino():
     save("dino_tiny", **out)
 
 
+def gen_simple_vit():
+    from core.model.featurizers.simple_ViT import SimpleViTFeaturizer
+    torch.manual_seed(9)
+    f = seeded_(SimpleViTFeaturizer(image_size=(56, 84), patch_size=(14, 14), dim=128, depth=2, heads=2, mlp_dim=256,
+                                    channels=3, dim_head=64), 14).eval()
+    x = torch.rand(2, 3, 56, 84)
+    with torch.no_grad():
+        y = f(x.clone())
+    out = {"x": x.numpy(), "y": y.numpy()}
+    for k, v in sd_np(f).items():
+        out["w::" + k] = v
+    save("simple_vit_tiny", **out)
+
+
 def gen_upsamplers_and_head():
     from core.model.heads import HEAD_REGISTRY
     from core.model.upsamplers import UPSAMPLER_REGISTRY
@@ -497,8 +511,8 @@ def gen_inference():
 def main():
     torch.set_num_threads(4)
     install_standins()
-    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "upsamplers", "model", "inference"]
-    fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino,
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "upsamplers", "model", "inference"]
+    fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino, "simple_vit": gen_simple_vit,
            "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference}
     for w in which:
         fns[w]()

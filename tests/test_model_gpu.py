@@ -171,3 +171,18 @@ def test_dino_vit_featurizer_vs_golden(golden, feat_type, inj):
     assert y.shape == ref.shape
     err = (y.float().cpu() - ref).abs().max().item()
     assert err < 3e-2 * max(1.0, ref.abs().max().item()), err
+
+
+def test_simple_vit_click_encoder_vs_golden(golden):
+    from isegprobe_amd.core.utils.model_builder import ModelBuilder
+    g = golden("simple_vit_tiny")
+    f = ModelBuilder().load_featurizer("simple_vit", dict(img_size=(56, 84), patch_size=(14, 14), embed_dim=128, depth=2,
+                                                          heads=2, mlp_dim=256, channels=3, dim_head=64), freeze=True)
+    f.load_state_dict(weights_from(g, "w"))
+    with torch.no_grad():
+        y = f.cuda().eval()(torch.from_numpy(g["x"]).cuda()).cpu()
+    ref = torch.from_numpy(g["y"])
+    assert y.shape == ref.shape
+    err = (y - ref).abs().max().item()
+    print("simple_vit max err", err, "ref max", ref.abs().max().item())
+    assert err < 3e-2 * max(1.0, ref.abs().max().item()), err

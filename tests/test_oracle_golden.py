@@ -124,3 +124,9 @@ def test_dino_vit_features(golden, feat_type, inj):
     y = ovit.dino_features(torch.from_numpy(g[tag + "_x"]), weights_from(g, "w"), patch=16, depth=2, heads=2,
                            feat_type=feat_type, click_tokens=torch.from_numpy(g[tag + "_clicks"]), injection=inj)
     np.testing.assert_allclose(y.numpy(), g[tag + "_y"], atol=2e-5, rtol=1e-5)
+
+
+def test_simple_vit_tokens(golden):
+    g = golden("simple_vit_tiny")
+    y = ovit.simple_vit_tokens(torch.from_numpy(g["x"]), weights_from(g, "w"), patch=14, heads=2, dim_head=64)
+    np.testing.assert_allclose(y.numpy(), g["y"], atol=2e-5, rtol=1e-5)
