@@ -70,6 +70,8 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
                                          sum_n relu(v + bias[n]) * gamma[n] over the slot's channels;
                                          slots = isp_conv3x3_partial_slots(N); close with isp_sum_partials_f32 */
 
+#define ISP_EP_BIAS_QGELU_BF16 9 /* out bf16 = quick_gelu(v + bias) = x*sigmoid(1.702x)   CLIP MLP, maskclip/model.py:231-233 */
+
 typedef struct isp_epilogue {
     int kind;             /* ISP_EP_* */
     void* out;            /* bf16 or f32 per kind */

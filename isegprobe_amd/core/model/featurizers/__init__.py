@@ -14,5 +14,6 @@ class BaseFeaturizer(ABC, nn.Module):
 from .DINOv2 import DINOv2Featurizer  # noqa: E402
 from .DINO import DINOFeaturizer  # noqa: E402
 from .simple_ViT import SimpleViTFeaturizer  # noqa: E402
+from .MaskCLIP import MaskCLIPFeaturizer  # noqa: E402
 
-__all__ = ["BaseFeaturizer", "DINOv2Featurizer", "DINOFeaturizer", "SimpleViTFeaturizer"]
+__all__ = ["BaseFeaturizer", "DINOv2Featurizer", "DINOFeaturizer", "SimpleViTFeaturizer", "MaskCLIPFeaturizer"]

@@ -17,7 +17,7 @@ class ModelBuilder:
         pass
 
     def load_featurizer(self, type: str, params: Dict, freeze: bool = True) -> nn.Module:
-        from ..model.featurizers import DINOFeaturizer, DINOv2Featurizer, SimpleViTFeaturizer
+        from ..model.featurizers import DINOFeaturizer, DINOv2Featurizer, MaskCLIPFeaturizer, SimpleViTFeaturizer
         type = type.lower()
         if type == "dinov2":
             backbone = DINOv2Featurizer(**params)
@@ -29,8 +29,7 @@ class ModelBuilder:
                                            mlp_dim=params["mlp_dim"], channels=params["channels"],
                                            dim_head=params["dim_head"])
         elif type == "mask_clip":
-            # reference model_builder.py:28-51; these backbones are later rows of the scope table
-            raise NotImplementedError(f"featurizer '{type}' has no HIP path yet (DINOv2 is built)")
+            backbone = MaskCLIPFeaturizer(**params)
         else:
             raise ValueError(f"Unsupported backbone type: {type}")
         if freeze:

@@ -142,7 +142,7 @@ struct Conv3x3A {
 
 // ------------------------------------------------------------------------------ epilogues
 // Epilogue contract: operator()(m, n, v[4]) for output row m < M, columns n..n+3 < N.
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QGELU = 3 };  // QGELU: x*sigmoid(1.702x), CLIP's QuickGELU
 
 template <int ACT>
 struct EpBiasActBf16 {  // out[m][n] = bf16(act(v + bias[n]))
@@ -157,6 +157,7 @@ struct EpBiasActBf16 {  // out[m][n] = bf16(act(v + bias[n]))
         for (int j = 0; j < 4; ++j) {
             if (ACT == ACT_RELU) r[j] = fmaxf(r[j], 0.f);
             if (ACT == ACT_GELU) r[j] = gelu_erf(r[j]);
+            if (ACT == ACT_QGELU) r[j] = r[j] / (1.0f + __expf(-1.702f * r[j]));
         }
         *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = make_uint2(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]));
     }
@@ -504,6 +505,10 @@ int dispatch_epilogue(AL al, const void* Wt, long M, int N, int K, const isp_epi
             return launch_gemm<CFG>(al, Wt, M, N, K,
                                EpBiasTapsReluBf16{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
             }
+        case ISP_EP_BIAS_QGELU_BF16:
+            if constexpr (!((KINDS >> ISP_EP_BIAS_QGELU_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpBiasActBf16<ACT_QGELU>{(bf16_t*)e->out, e->bias, ldo}, s);
+            }
         case ISP_EP_RELU_DOT_PARTIAL_F32:
             if constexpr (!((KINDS >> ISP_EP_RELU_DOT_PARTIAL_F32) & 1u)) return ISP_ERR_UNSUPPORTED; else {
             if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
@@ -523,7 +528,7 @@ extern "C" int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, in
     al.A = (const bf16_t*)A;
     al.lda = lda;
     al.M = M;
-    return dispatch_epilogue<Cfg128, DenseA<Cfg128::PA>, 0x7fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
+    return dispatch_epilogue<Cfg128, DenseA<Cfg128::PA>, 0x27fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
 }
 
 // number of partial-sum slots isp_conv3x3_nhwc_bf16 writes with ISP_EP_RELU_DOT_PARTIAL_F32

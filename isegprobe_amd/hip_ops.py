@@ -104,7 +104,8 @@ def linear(A, Wt, bias=None, act=None, out_dtype=BF16):
     N = Wt.shape[0]
     out = torch.empty(A.shape[0], N, device=A.device, dtype=out_dtype)
     if out_dtype == BF16:
-        kind = {None: _lib.EP_BIAS_BF16, "relu": _lib.EP_BIAS_RELU_BF16, "gelu": _lib.EP_BIAS_GELU_BF16}[act]
+        kind = {None: _lib.EP_BIAS_BF16, "relu": _lib.EP_BIAS_RELU_BF16, "gelu": _lib.EP_BIAS_GELU_BF16,
+                "quick_gelu": _lib.EP_BIAS_QGELU_BF16}[act]
     else:
         if act is not None:
             raise IspError("fp32 output supports no activation")

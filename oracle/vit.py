@@ -178,3 +178,48 @@ def simple_vit_tokens(x, w, *, patch, heads, dim_head=64, depth=None, prefix="")
         t = f + t
         i += 1
     return F.layer_norm(t, (dim,), w["transformer.norm.weight"], w["transformer.norm.bias"])
+
+
+def maskclip_features(image, w, *, patch, heads, click_tokens=None, injection="no_injection", prefix="visual."):
+    """MaskCLIPFeaturizer.forward (reference core/model/featurizers/MaskCLIP.py:41-92) on CLIP's
+    VisionTransformer with patch_output=True (maskclip/model.py:321-358, :251-263): all but the last
+    block run normally, the last block contributes only out_proj(v_proj(ln_1 x)); cls dropped; ln_post;
+    @ proj.  fp32 here (the reference runs fp16 weights on the GPU)."""
+    w = {k[len(prefix):]: v.float() for k, v in w.items() if k.startswith(prefix)}
+    B, _, H, W = image.shape
+    h, wd = H // patch, W // patch
+    x = F.conv2d(image, w["conv1.weight"], None, stride=patch).flatten(2).permute(0, 2, 1)
+    if click_tokens is not None and injection == "before_backbone":  # MaskCLIP.py:51-65
+        assert x.shape == click_tokens.shape
+        x = x + click_tokens
+    D = x.shape[-1]
+    x = torch.cat([w["class_embedding"].expand(B, 1, D), x], dim=1)
+    pe = w["positional_embedding"]  # maskclip/interpolate.py:5-59: same bicubic recipe as DINO
+    # Reference quirk: the before_backbone route (forward_without_patch_embed, model.py:389,402-404) passes
+    # (h, w) = (H, W) where the normal route passes (w, h) = (H, W) (model.py:322,341): for non-square
+    # images its grid is interpolated as [W/p, H/p] and then read row-major.  Reproduced as is.
+    swap = click_tokens is not None and injection == "before_backbone"
+    x = x + interpolated_pos_embed(pe.unsqueeze(0), x.shape[1], W if swap else H, H if swap else W, patch)[0]
+    x = F.layer_norm(x, (D,), w["ln_pre.weight"], w["ln_pre.bias"])
+    n = 0
+    while f"transformer.resblocks.{n}.ln_1.weight" in w:
+        n += 1
+    hd = D // heads
+    for i in range(n):
+        p = f"transformer.resblocks.{i}."
+        a = F.layer_norm(x, (D,), w[p + "ln_1.weight"], w[p + "ln_1.bias"])
+        if i == n - 1:  # forward_v (model.py:251-263)
+            v = F.linear(a, w[p + "attn.in_proj_weight"][-D:], w[p + "attn.in_proj_bias"][-D:])
+            x = F.linear(v, w[p + "attn.out_proj.weight"], w[p + "attn.out_proj.bias"])
+            break
+        qkv = F.linear(a, w[p + "attn.in_proj_weight"], w[p + "attn.in_proj_bias"]).reshape(B, -1, 3, heads, hd)
+        q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
+        o = ((q * hd ** -0.5) @ k.transpose(-1, -2)).softmax(-1) @ v
+        x = x + F.linear(o.transpose(1, 2).reshape(B, -1, D), w[p + "attn.out_proj.weight"], w[p + "attn.out_proj.bias"])
+        m = F.linear(F.layer_norm(x, (D,), w[p + "ln_2.weight"], w[p + "ln_2.bias"]), w[p + "mlp.c_fc.weight"], w[p + "mlp.c_fc.bias"])
+        x = x + F.linear(m * torch.sigmoid(1.702 * m), w[p + "mlp.c_proj.weight"], w[p + "mlp.c_proj.bias"])
+    x = F.layer_norm(x[:, 1:], (D,), w["ln_post.weight"], w["ln_post.bias"]) @ w["proj"]
+    if click_tokens is not None and injection == "after_backbone":  # MaskCLIP.py:75-83
+        assert x.shape == click_tokens.shape
+        x = x + click_tokens
+    return x.reshape(B, h, wd, -1).permute(0, 3, 1, 2)

@@ -323,6 +323,42 @@ def gen_simple_vit():
     save("simple_vit_tiny", **out)
 
 
+def gen_maskclip():
+    """MaskCLIPFeaturizer with a tiny CLIP visual tower (clip.load's URL download, clip.py:118-177, is
+    bypassed); run in fp32 on the CPU."""
+    from core.model.featurizers.MaskCLIP import MaskCLIPFeaturizer
+    from core.model.featurizers.maskclip.model import VisionTransformer
+    torch.manual_seed(10)
+    out = {}
+
+    class _Clip(nn.Module):  # the three members MaskCLIPFeaturizer touches (maskclip/model.py:543-566)
+        def __init__(self):
+            super().__init__()
+            self.visual = VisionTransformer(input_resolution=64, patch_size=16, width=128, layers=3, heads=2, output_dim=64)
+            self.dtype = torch.float32
+
+        def get_patch_encodings(self, image):
+            return self.visual(image.type(self.dtype), patch_output=True)
+
+        def encode_projected_patches(self, patches, orig_image_hw):
+            return self.visual.forward_without_patch_embed(patches.type(self.dtype), orig_image_hw, patch_output=True)
+
+    for inj, cdim in (("before_backbone", 128), ("after_backbone", 64), ("no_injection", 64)):
+        f = MaskCLIPFeaturizer.__new__(MaskCLIPFeaturizer)
+        nn.Module.__init__(f)
+        f.feats_injection_mode = inj
+        f.model = seeded_(_Clip(), 15).eval()
+        f.patch_size = 16
+        x = torch.randn(2, 3, 48, 80)
+        clicks = 0.5 * torch.randn(2, 15, cdim)
+        with torch.no_grad():
+            y = f(x, clicks.clone())
+        out[inj + "_x"], out[inj + "_clicks"], out[inj + "_y"] = x.numpy(), clicks.numpy(), y.contiguous().numpy()
+    for k, v in sd_np(f.model).items():
+        out["w::" + k] = v
+    save("maskclip_tiny", **out)
+
+
 def gen_upsamplers_and_head():
     from core.model.heads import HEAD_REGISTRY
     from core.model.upsamplers import UPSAMPLER_REGISTRY
@@ -511,8 +547,8 @@ def gen_inference():
 def main():
     torch.set_num_threads(4)
     install_standins()
-    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "upsamplers", "model", "inference"]
-    fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino, "simple_vit": gen_simple_vit,
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference"]
+    fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino, "simple_vit": gen_simple_vit, "maskclip": gen_maskclip,
            "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference}
     for w in which:
         fns[w]()

@@ -130,3 +130,11 @@ def test_simple_vit_tokens(golden):
     g = golden("simple_vit_tiny")
     y = ovit.simple_vit_tokens(torch.from_numpy(g["x"]), weights_from(g, "w"), patch=14, heads=2, dim_head=64)
     np.testing.assert_allclose(y.numpy(), g["y"], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("inj", ["before_backbone", "after_backbone", "no_injection"])
+def test_maskclip_features(golden, inj):
+    g = golden("maskclip_tiny")
+    y = ovit.maskclip_features(torch.from_numpy(g[inj + "_x"]), weights_from(g, "w"), patch=16, heads=2,
+                               click_tokens=torch.from_numpy(g[inj + "_clicks"]), injection=inj)
+    np.testing.assert_allclose(y.numpy(), g[inj + "_y"], atol=2e-5, rtol=1e-5)
