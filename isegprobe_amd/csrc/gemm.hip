@@ -67,19 +67,18 @@ struct DenseA {
     template <int BM>
     long num_tiles() const { return (M + BM - 1) / BM; }
     __device__ __forceinline__ const void* ptr(int i) const { return cur[i]; }
-    __device__ __forceinline__ void advance() {
+    __device__ __forceinline__ long advance() {  // returns the step of the weight-column cursor (elements)
 #pragma unroll
         for (int i = 0; i < NS; ++i) cur[i] += BK;
+        return BK;
     }
 };
 
 // Implicit GEMM for a 3x3, stride 1, pad 1 convolution on an NHWC bf16 map with C % 64 == 0:
-// K index = tap*C + c, tap = (dy+1)*3 + (dx+1).  An M-tile is a 2-D patch of (BM/16) x 16 output
+// weight column k = tap*C + c, tap = (dy+1)*3 + (dx+1).  An M-tile is a 2-D patch of (BM/16) x 16 output
 // pixels, not BM consecutive pixels of a row: its 9 taps touch an (BM/16+2) x 18 input patch
 // (1.27x the outputs for BM=256) instead of 3 x (BM+2) (3.0x), which is what the L2 has to hold
-// and what spills to the fabric.  Addresses are
-// incremental: within a tap a slot advances by 64 channels (or stays on the zero constant when
-// the tap is outside the image); the tap change recomputes the slot bases.
+// and what spills to the fabric.  Out-of-image taps read a 16-byte zero constant.
 template <int NS>
 struct Conv3x3A {
     const bf16_t* in;
@@ -89,12 +88,15 @@ struct Conv3x3A {
     int tap, cb;  // wave-uniform iteration state
     const bf16_t* pix[NS];
     const bf16_t* cur[NS];
-    int yy[NS], xx[NS], inc[NS];
+    int yy[NS], xx[NS];
+    // K order is CHANNEL-BLOCK major, tap minor: nine consecutive K-steps sweep the 3x3 taps of one
+    // 64-channel slice, so they re-touch the same 128-byte lines of the block's 18x18 input patch while
+    // those are still in L2 (tap-major order walks all 384 channels per tap: 8 MB of live patches per XCD
+    // against a 4 MiB L2).  Weight columns follow: k = tap*C + cb*64.
     __device__ __forceinline__ void set_tap(int i) {
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const bool ok = (unsigned)(yy[i] + dy) < (unsigned)H && (unsigned)(xx[i] + dx) < (unsigned)W;
-        cur[i] = ok ? pix[i] + ((long)dy * W + dx) * C : reinterpret_cast<const bf16_t*>(g_isp_zero16);
-        inc[i] = ok ? BK : 0;
+        cur[i] = ok ? pix[i] + ((long)dy * W + dx) * C + cb * BK : reinterpret_cast<const bf16_t*>(g_isp_zero16);
     }
     int tiles_x, tiles_y;  // patches per image
     template <int BM>
@@ -127,16 +129,16 @@ struct Conv3x3A {
     template <int BM>
     long num_tiles() const { return (long)(M / ((long)H * W)) * tiles_x * tiles_y; }
     __device__ __forceinline__ const void* ptr(int i) const { return cur[i]; }
-    __device__ __forceinline__ void advance() {
-        if (++cb == cblocks) {  // uniform branch
-            cb = 0;
-            ++tap;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) set_tap(i);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NS; ++i) cur[i] += inc[i];
+    __device__ __forceinline__ long advance() {
+        long wstep = C;  // next tap, same channel block
+        if (++tap == 9) {  // uniform branch
+            tap = 0;
+            ++cb;
+            wstep = BK - 8L * C;
         }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) set_tap(i);
+        return wstep;
     }
 };
 
@@ -291,6 +293,47 @@ struct EpTokens {  // patch-embed: token row b*(T+1)+1+t gets v + bias[n] + pos[
 // ------------------------------------------------------------------------------ the engine
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
+// Shared epilogue driver.  A lane holds, for accumulator tile (mi, ni), output row (row_base + 16*mi +
+// fr) and the 4 consecutive columns n_base + 16*ni + 4*fq + j.  `row_of(local_row)` maps a tile row
+// to the global output row (or -1).  EP::kRowReduce epilogues reduce over the wave's columns instead
+// of storing them (conv + classifier fusion): slot = which (n-tile, n-wave) partial this wave owns.
+template <int TM, int TN, class EP, class RowFn>
+__device__ __forceinline__ void run_epilogue(const EP& ep, f32x4 (&acc)[TM][TN], RowFn row_of, int row_base, int fr,
+                                             int fq, int n_base, int N, int slot) {
+    if constexpr (requires { EP::kRowReduce; }) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const long m = row_of(row_base + mi * 16 + fr);
+            float sum = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n_base + ni * 16 + fq * 4;
+                const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                if (n < N) sum += ep.term(n, v);
+            }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            if (fq == 0 && m >= 0) ep.partial[(size_t)slot * ep.M + m] = sum;
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const long m = row_of(row_base + mi * 16 + fr);
+            if (m < 0) continue;
+            [[maybe_unused]] unsigned ctx = 0;
+            if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n_base + ni * 16 + fq * 4;
+                if (n >= N) continue;
+                const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                if constexpr (requires { ep.row_begin(m); }) ep(m, n, v, ctx);
+                else ep(m, n, v);
+            }
+        }
+    }
+}
+
 template <class CFG, class AL, class EP>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL al, const bf16_t* __restrict__ Wt, long M,
                                                                           int N, int K, int tiles_n, int nwg, EP ep) {
@@ -323,11 +366,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
 #pragma unroll
         for (int i = 0; i < PA; ++i) glds16(al.ptr(i), buf + (wid + i * NW) * 1024);
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            glds16(w_src[i], buf + CFG::A_BYTES + (wid + i * NW) * 1024);
-            w_src[i] += BK;
-        }
-        al.advance();
+        for (int i = 0; i < PW; ++i) glds16(w_src[i], buf + CFG::A_BYTES + (wid + i * NW) * 1024);
+        const long wstep = al.advance();
+#pragma unroll
+        for (int i = 0; i < PW; ++i) w_src[i] += wstep;
     };
 
     // --- fragment read addresses (bytes inside a stage)
@@ -387,8 +429,14 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef ISP_ABLATE_NO_DMA  // timing experiment only: MFMA + fragment reads on stale LDS
+        if (t + NST - 1 < nk) (void)al.advance();
+#else
         if (t + NST - 1 < nk) stage(refill);
+#endif
+#ifndef ISP_ABLATE_NO_MFMA  // timing experiment only: DMA + barriers, no fragment reads / MFMA
         compute(cur);
+#endif
     };
     int t = 0;
     if constexpr (NST == 2) {
@@ -407,40 +455,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
         if (t + 1 < nk) step(t + 1, smem + CFG::STAGE, smem);
     }
 
-    // --- epilogue: lane holds, for mi/ni, row m = .. + fr and 4 consecutive n = .. + 4*fq + j
-    if constexpr (requires { EP::kRowReduce; }) {
-        const int slot = tn * CFG::WN + wn;
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const long m = al.template out_row<BM>(tm, wm * (TM * 16) + mi * 16 + fr);
-            float sum = 0.f;
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int n = n0 + wn * (TN * 16) + ni * 16 + fq * 4;
-                const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-                if (n < N) sum += ep.term(n, v);
-            }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            if (fq == 0 && m >= 0) ep.partial[(size_t)slot * ep.M + m] = sum;
-        }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const long m = al.template out_row<BM>(tm, wm * (TM * 16) + mi * 16 + fr);
-            if (m < 0) continue;
-            [[maybe_unused]] unsigned ctx = 0;
-            if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int n = n0 + wn * (TN * 16) + ni * 16 + fq * 4;
-                if (n >= N) continue;
-                const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-                if constexpr (requires { ep.row_begin(m); }) ep(m, n, v, ctx);
-                else ep(m, n, v);
-            }
-        }
-    }
+    run_epilogue<TM, TN>(ep, acc, [&](int r) { return al.template out_row<BM>(tm, r); }, wm * (TM * 16), fr, fq,
+                         n0 + wn * (TN * 16), N, tn * CFG::WN + wn);
 }
 
 template <class CFG, class AL, class EP>
@@ -459,6 +475,215 @@ int launch_gemm(AL al, const void* Wt, long M, int N, int K, EP ep, hipStream_t 
     }
     kern<<<(unsigned)nwg, CFG::THREADS, CFG::LDS, s>>>(al, (const bf16_t*)Wt, M, N, K, tiles_n, (int)nwg, ep);
     return isp_launch_status();
+}
+
+// ------------------------------------------------------------------------------ patch conv
+// 3x3 / stride 1 / pad 1 convolution with the INPUT PATCH resident in LDS.  The tile engine above
+// stages a fresh 256 x 64 activation tile for every one of the 9 taps although the 9 tiles are shifted
+// views of one 18 x 18 x 64 input patch; here that patch (41 KiB, zero outside the image) is staged
+// ONCE per 64-channel block and the A fragments of each tap are read from it at shifted addresses.
+// LDS-DMA traffic per channel block drops from 9 x (32 + 24) KiB to 41 + 9 x 24 KiB (0.51x): measured
+// (B=8, 448^2, C=N=384) the staging path alone took 2.95 ms and the MFMA path alone 2.88 ms of a
+// 3.73 ms launch, i.e. the kernel was LDS-DMA bound as much as MFMA bound.
+//   block = 16 x 16 output pixels x 192 output channels, 8 waves (4 pixel-row groups x 2 channel
+//   halves), K order = channel block major, tap minor; weight tiles in a 2-stage ring (one
+//   vmcnt(0)+barrier per K-step; a 3-stage ring fetched two steps ahead measured 6 % slower), the next
+//   channel block's patch trickles in one piece per wave per K-step into a second patch buffer.
+//   LDS = 2 x 42 KiB + 2 x 24 KiB = 132 KiB.
+constexpr int PT = 16, PW_ = 18, PPIX = PW_ * PW_;       // 16x16 outputs, 18x18 inputs
+constexpr int P_PIECES = (PPIX + 7) / 8 + 1;              // 42 one-KiB pieces (8 pixels x 128 B)
+constexpr int P_BYTES = P_PIECES * 1024, PBN = 192, PWB = PBN * BK * 2,
+#ifdef ISP_P_WST3
+              P_WST = 3,
+#else
+              P_WST = 2,
+#endif
+              P_LDS = 2 * P_BYTES + P_WST * PWB;
+
+template <class EP>
+__global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const bf16_t* __restrict__ in,
+                                                               const bf16_t* __restrict__ Wt, int H, int W, int C,
+                                                               int N, int tiles_x, int tiles_y, int tiles_n, int nwg,
+                                                               EP ep) {
+    constexpr int TM = 4, TN = 6, NWV = 8, PPW = (P_PIECES + NWV - 1) / NWV;  // 6 patch pieces per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tn = wg % tiles_n;
+    const int tmi = wg / tiles_n;
+    const int per_img = tiles_x * tiles_y;
+    const int b = tmi / per_img, tt = tmi - b * per_img;
+    const int y0 = (tt / tiles_x) * PT, x0 = (tt % tiles_x) * PT, n0 = tn * PBN;
+    const long K = 9L * C;
+    const int cblocks = C / BK;
+
+    // --- patch DMA slots: wave w owns pieces w, w+8, ...; lane -> (pixel = 8*piece + lane/8, phys chunk).
+    // 32-bit element offsets from the image base + a validity mask keep this at 7 registers.
+    const bf16_t* const img = in + (size_t)b * H * W * C;
+    const bf16_t* const zero = reinterpret_cast<const bf16_t*>(g_isp_zero16);
+    unsigned poff[PPW], pmask = 0;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pix = (wid + NWV * i) * 8 + (lane >> 3);
+        const int py = pix / PW_, px = pix - py * PW_;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = pix < PPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        poff[i] = ok ? (unsigned)((iy * W + ix) * C + swz(pix, lane & 7) * 8) : 0u;
+        pmask |= ok ? 1u << i : 0u;
+    }
+    auto issue_patch = [&](int i, int cb, char* buf) {
+        if (wid + NWV * i < P_PIECES)
+            glds16((pmask >> i & 1) ? img + poff[i] + cb * BK : zero, buf + (wid + NWV * i) * 1024);
+    };
+    // --- weight DMA slots: 24 pieces per stage, 3 per wave
+    const bf16_t* const wbase = Wt + (size_t)n0 * K;
+    unsigned woff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int row = (wid + NWV * i) * 8 + (lane >> 3);
+        woff[i] = (unsigned)((n0 + row < N ? row : N - 1 - n0) * K + swz(row, lane & 7) * 8);
+    }
+    auto issue_w = [&](long col, char* buf) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) glds16(wbase + col + woff[i], buf + (wid + NWV * i) * 1024);
+    };
+
+    // --- fragment geometry
+    const int wm = wid >> 1, wn = wid & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int p00 = (4 * wm + 1) * PW_ + fr + 1;  // patch pixel of fragment row fr of the wave's first pixel row
+    // weight rows wn*96 + 16*t + fr: the swizzle term (row>>1)&7 depends on fr only
+    const int w_off0 = (wn * (TN * 16) + fr) * 128 + swz(fr, fq) * 16;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    char* const s_w = smem + 2 * P_BYTES;
+    // --- prologue: whole patch of channel block 0, weight tile of step 0
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_patch(i, 0, smem);
+    issue_w(0, s_w);
+    if (P_WST == 3) issue_w(C, s_w + PWB);
+
+    // A fragments of K-half 0 of the NEXT K-step are read before that step's barrier (the patch is
+    // already resident; only the weight tile needs the barrier), so that after the barrier the first
+    // MFMA waits for one weight read instead of ten reads: all 8 waves leave the barrier in phase and
+    // nobody covers that bubble.
+    auto read_a = [&](bf16x8 (&fa)[TM], const char* patch, int shift, int ks) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int p = p00 + t * PW_ + shift;
+            fa[t] = *reinterpret_cast<const bf16x8*>(patch + p * 128 + swz(p, ks * 4 + fq) * 16);
+        }
+    };
+    auto read_w = [&](bf16x8 (&fw)[TN], const char* wb, int ks) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) fw[t] = *reinterpret_cast<const bf16x8*>(wb + ((w_off0 ^ (ks * 64)) + t * 2048));
+    };
+    auto mma = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fw)[TN]) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+    };
+    auto tap_shift = [&](int tap) {
+        int shift = (tap / 3 - 1) * PW_ + (tap % 3 - 1);
+        asm volatile("" : "+s"(shift));  // opaque: keeps the 72 per-tap fragment addresses out of registers
+        return shift;
+    };
+
+    const int nsteps = 9 * cblocks;
+    bf16x8 fa0[TM];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_a(fa0, smem, tap_shift(0), 0);
+    int s = 0;
+    for (int cb = 0; cb < cblocks; ++cb) {
+        const char* patch = smem + (cb & 1) * P_BYTES;
+        char* patch_next = smem + ((cb + 1) & 1) * P_BYTES;
+        const bool more = cb + 1 < cblocks;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            if (P_WST == 3 && s + 1 < nsteps)  // the 3 weight loads of K-step s+1 are the youngest in flight
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef ISP_ABLATE_NO_BARRIER
+            __builtin_amdgcn_s_barrier();
+#endif
+#ifndef ISP_ABLATE_NO_DMA  // timing experiments only
+            if (tap < PPW && more) issue_patch(tap, cb + 1, patch_next);  // next patch: one piece / wave / step
+            if (s + P_WST - 1 < nsteps) {  // weight tile P_WST-1 K-steps ahead (issued last: see the vmcnt above)
+                constexpr int ahead = P_WST - 1;
+                const long col = tap + ahead < 9 ? (long)(tap + ahead) * C + (long)cb * BK
+                                                 : (long)(tap + ahead - 9) * C + (long)(cb + 1) * BK;
+                issue_w(col, s_w + (P_WST == 3 ? (tap + ahead) % 3 : (s + ahead) & 1) * PWB);  // 9 % 3 == 0
+            }
+#endif
+#ifdef ISP_ABLATE_NO_MFMA
+            continue;
+#endif
+            const char* wb = s_w + (P_WST == 3 ? tap % 3 : s & 1) * PWB;
+            bf16x8 fa1[TM], fw[TN];
+            read_w(fw, wb, 0);
+            read_a(fa1, patch, tap_shift(tap), 1);
+            mma(fa0, fw);
+            read_w(fw, wb, 1);
+            mma(fa1, fw);
+            read_a(fa0, tap < 8 ? patch : patch_next, tap_shift(tap < 8 ? tap + 1 : 0), 0);
+        }
+    }
+    auto row_of = [&](int r) -> long {
+        const int y = y0 + (r >> 4), x = x0 + (r & 15);
+        return (y < H && x < W) ? ((long)b * H + y) * W + x : -1;
+    };
+#ifdef ISP_ABLATE_NO_EPILOGUE
+    if (acc[0][0][0] == 12345.678f)
+#endif
+    run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
+}
+
+template <class EP>
+int launch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int C, int N, EP ep, hipStream_t s) {
+    const int tiles_x = (W + PT - 1) / PT, tiles_y = (H + PT - 1) / PT, tiles_n = (N + PBN - 1) / PBN;
+    const long nwg = (long)B * tiles_x * tiles_y * tiles_n;
+    if (nwg > 0x7fffffffL || (long)H * W * C > 0x7fffffffL || 192L * 9 * C > 0x7fffffffL) return ISP_ERR_INVALID;
+    static bool attr_done = false;
+    auto kern = conv3x3_patch_kernel<EP>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess)
+            return ISP_ERR_LAUNCH;
+        attr_done = true;
+    }
+    kern<<<(unsigned)nwg, 512, P_LDS, s>>>((const bf16_t*)in, (const bf16_t*)Wt, H, W, C, N, tiles_x, tiles_y, tiles_n,
+                                          (int)nwg, ep);
+    return isp_launch_status();
+}
+
+// dispatch of the epilogue kinds the patch conv supports
+inline int dispatch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int C, int N, const isp_epilogue* e,
+                               hipStream_t s) {
+    const long M = (long)B * H * W;
+    const long ldo = e->ldo > 0 ? e->ldo : N;
+    switch (e->kind) {
+        case ISP_EP_BIAS_BF16:
+            return launch_conv_patch(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_NONE>{(bf16_t*)e->out, e->bias, ldo}, s);
+        case ISP_EP_BIAS_RELU_BF16:
+            return launch_conv_patch(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_RELU>{(bf16_t*)e->out, e->bias, ldo}, s);
+        case ISP_EP_BIAS_TAPS_RELU_BF16:
+            if (!e->bias || !e->pos || e->img_h <= 0 || e->img_w <= 0 || ldo != N) return ISP_ERR_INVALID;
+            return launch_conv_patch(in, Wt, B, H, W, C, N,
+                                     EpBiasTapsReluBf16{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
+        case ISP_EP_RELU_DOT_PARTIAL_F32:
+            if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
+            return launch_conv_patch(in, Wt, B, H, W, C, N, EpReluDotPartial{(float*)e->out, e->bias, e->gamma, M}, s);
+        default:
+            return ISP_ERR_UNSUPPORTED;
+    }
 }
 
 template <class CFG, class AL, unsigned KINDS = 0xffffffffu>  // KINDS: bit mask of epilogue kinds to instantiate
@@ -531,6 +756,16 @@ extern "C" int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, in
     return dispatch_epilogue<Cfg128, DenseA<Cfg128::PA>, 0x27fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
 }
 
+// A/B switch for experiments: ISEGPROBE_CONV_ENGINE=tile selects the generic tile engine for every conv
+static bool ep_forces_tile_engine() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ISEGPROBE_CONV_ENGINE");
+        v = (e && e[0] == 't') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 // number of partial-sum slots isp_conv3x3_nhwc_bf16 writes with ISP_EP_RELU_DOT_PARTIAL_F32
 extern "C" int isp_conv3x3_partial_slots(int N) {
     if (N % 192 == 0) return ((N + CfgConv192::BN - 1) / CfgConv192::BN) * CfgConv192::WN;
@@ -558,6 +793,10 @@ extern "C" int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int 
         al.tiles_y = (H + CFG::BM / 16 - 1) / (CFG::BM / 16);
         return dispatch_epilogue<CFG, Conv3x3A<CFG::PA>, CONV_KINDS>(al, Wt, M, N, 9 * C, ep, (hipStream_t)stream);
     };
+    if (N % 192 == 0 && !ep_forces_tile_engine()) {
+        const int rc = ep ? dispatch_conv_patch(in, Wt, B, H, W, C, N, ep, (hipStream_t)stream) : ISP_ERR_INVALID;
+        if (rc != ISP_ERR_UNSUPPORTED) return rc;
+    }
     if (N % 192 == 0) return run(CfgConv192{});
     if (N > 64) return run(CfgConv128{});
     return run(Cfg128{});
