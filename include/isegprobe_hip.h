@@ -71,6 +71,10 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
                                          slots = isp_conv3x3_partial_slots(N); close with isp_sum_partials_f32 */
 
 #define ISP_EP_BIAS_QGELU_BF16 9 /* out bf16 = quick_gelu(v + bias) = x*sigmoid(1.702x)   CLIP MLP, maskclip/model.py:231-233 */
+#define ISP_EP_BIAS_GELU_SAVE_BF16 10 /* training forward of Mlp.fc1: out bf16 = gelu_erf(v + bias) and out2 bf16 = v + bias
+                                       * (the pre-activation the backward needs; mlp.py:34-40 under autograd) */
+#define ISP_EP_MUL_DGELU_BF16 11 /* backward of GELU fused into the fc2 data-gradient GEMM: out bf16 = v * gelu'(res),
+                                  * res bf16 = the saved pre-activation (row stride ldo) */
 
 typedef struct isp_epilogue {
     int kind;             /* ISP_EP_* */
@@ -83,6 +87,7 @@ typedef struct isp_epilogue {
     const void* res;      /* bf16 [M, ldo] residual (AXPY_RES) */
     float alpha;          /* (AXPY_RES) */
     int img_h, img_w;     /* image extent (BIAS_TAPS) */
+    void* out2;           /* second output (BIAS_GELU_SAVE), row stride ldo */
 } isp_epilogue;
 
 /* ---- C = A . Wt^T with a fused epilogue.  A [M, lda>=K] bf16, Wt [N,K] bf16, K % 64 == 0,
@@ -115,6 +120,35 @@ int isp_layernorm_fwd(const void* x, void* y, const float* gamma, const float* b
 int isp_attention_fwd(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, int head_dim,
                       long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
                       long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
+
+/* Training variant: also writes lse[b*H+h][q] (row stride lse_ld >= Lq, fp32) = log2 sum_k exp2(s_qk * scale * log2 e),
+ * the statistic isp_attention_bwd needs to recompute the probabilities. */
+int isp_attention_fwd_lse(const void* Q, const void* K, const void* V, void* O, float* lse, long lse_ld, int B, int H, int Lq,
+                          int Lk, int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
+                          long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
+                          float scale, void* stream);
+
+/* ---- Backward of isp_attention_fwd (head_dim 64): dQ, dK, dV (bf16, strides of Q / of K,V) from O, dO (strides
+ * o_stride_*) and lse.  delta is a [B*H, stat_ld] fp32 workspace (rowsum(dO*O)); stat_ld % 64 == 0 is the row
+ * stride of BOTH lse and delta.  What autograd does for Attention.forward (dinov2/layers/attention.py:54-71) when the
+ * reference trains with feats_injection_mode="before_backbone" (models/sbd/dinov2/patch-embed_*.py:40); the
+ * probability matrix is recomputed per 64x64 tile, never stored. */
+int isp_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                      float* delta, long stat_ld, void* dQ, void* dK, void* dV, int B, int H, int Lq, int Lk, int head_dim,
+                      long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
+                      long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
+
+/* ---- LayerNorm backward w.r.t. the input (frozen affine): gx (fp32 [rows,D]) (+)= dLN(x; gamma)(gy), statistics
+ * recomputed from x (fp32 [rows,D]); gy bf16 [rows_out,D]; optional bf16 copy of the updated gx.  group_out/skip as
+ * in isp_layernorm_fwd (rows = input rows; dropped rows get zero gradient).  Autograd of nn.LayerNorm in
+ * dinov2/layers/block.py:92-117 and DINOv2.py:533. */
+int isp_layernorm_bwd(const float* x, const void* gy, const float* gamma, float* gx, void* gx_bf16, long rows, int D,
+                      float eps, int group_out, int skip, int accumulate, void* stream);
+
+/* ---- Adjoint of isp_resize_bilinear_ac_nchw_f32 for planar fp32 maps: din [planes,h,w] = R^T dout [planes,H,W].
+ * The logits resize of iseg_base_model.py:75-80 under autograd (identity / LiFT-sized upsampler outputs). */
+int isp_resize_bilinear_ac_nchw_f32_bwd(const float* dout, float* din, long planes, int h, int w, int H, int W,
+                                        void* stream);
 
 /* ---- F.interpolate(mode="bilinear", align_corners=True): basic_upsamplers.py:28-33,
  * iseg_probe_model.py:120-129 (NHWC bf16 feature maps) and iseg_base_model.py:75-80,

@@ -9,10 +9,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "libisegprobe_hip.so")  # env override: kernel A/B experiments
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ISP_F32, ISP_BF16 = 0, 1
-EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16 = range(10)
+EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16 = range(12)
 
 _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed"}
 
@@ -34,6 +34,7 @@ class Epilogue(ctypes.Structure):
         ("alpha", ctypes.c_float),
         ("img_h", ctypes.c_int),
         ("img_w", ctypes.c_int),
+        ("out2", ctypes.c_void_p),
     ]
 
 
@@ -52,6 +53,10 @@ SIGNATURES = {
     "isp_sum_partials_f32": [_vp, _vp, _l, _i, _f, _vp],
     "isp_layernorm_fwd": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _l, _l, _vp],
     "isp_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
+    "isp_attention_fwd_lse": [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
+    "isp_attention_bwd": [_vp] * 7 + [_l] + [_vp] * 3 + [_i] * 5 + [_l] * 9 + [_f, _vp],
+    "isp_resize_bilinear_ac_nchw_f32_bwd": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
+    "isp_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _vp],
     "isp_resize_bilinear_ac_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_resize_bilinear_ac_nchw_f32": [_vp, _vp, _l, _i, _i, _i, _i, _l, _vp],
     "isp_resize_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -3,10 +3,12 @@ after-backbone click injection).  Forward and backward are HIP kernels; autograd
 graph so that the reference's training loop (``loss.backward()``, Adam; core/training/trainer.py:
 219-226) runs unchanged.  Gradients of parameters are fp32; activation gradients bf16 NHWC.
 
-Scope: gradients flow logits -> head -> resize -> (features + click tokens) -> embed_coords.  The
-reference's default ``before_backbone`` injection also needs activation gradients through the
-frozen ViT and upsampler; that backward is not built -- the model raises when
-asked to train in that mode."""
+Scope: gradients flow logits -> head -> resize -> features -> (frozen ViT blocks, when the click
+tokens are injected ``before_backbone`` -- the reference's default training mode,
+models/sbd/dinov2/patch-embed_*.py:40) -> click tokens -> embed_coords.  Frozen weights get no
+gradient; only activation gradients are propagated through the trunk (``ViTTrunkFn``).  The learned
+upsamplers (LoftUp / LiFT / FeatUp JBU) have no backward yet: with them the model raises when asked
+to train with ``before_backbone``."""
 import torch
 
 from ... import hip_ops as ops
@@ -105,6 +107,19 @@ class ResizeBilinearFn(torch.autograd.Function):
         return ops.resize_bilinear_nhwc_bwd(gy.contiguous(), ctx.hw[0], ctx.hw[1]), None, None
 
 
+class ResizeLogitsFn(torch.autograd.Function):
+    """Final logits resize [B,1,h,w] -> [B,1,H,W] fp32 (iseg_base_model.py:75-80)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W):
+        ctx.hw = x.shape[2:]
+        return ops.resize_bilinear_nchw_f32(x.float().contiguous(), H, W)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ops.resize_bilinear_nchw_f32_bwd(gy.float().contiguous(), ctx.hw[0], ctx.hw[1]), None, None
+
+
 class TokenAddFn(torch.autograd.Function):
     """features [B,T,D] bf16 (frozen backbone output) + click tokens [B,T,D] fp32 (DINOv2.py:516)."""
 
@@ -148,6 +163,85 @@ class PatchEmbedFn(torch.autograd.Function):
         db = torch.zeros(D, 8, device=g.device, dtype=torch.float32)
         ops.tn_gemm_atomic(g, ones, db)
         return None, dw[:, :K].reshape(weight.shape).contiguous(), db[:, 0].contiguous(), None, None
+
+
+class ViTTrunkFn(torch.autograd.Function):
+    """Frozen DINOv2-style trunk on the residual stream: ``x0`` [B*(T+1), D] fp32 (patch + cls +
+    pos-embed tokens, click tokens already added on rows 1..T of each image) -> final-norm features
+    [B*T, D] bf16 (cls dropped).  Forward = the inference kernels plus the statistics the backward
+    needs (attention log-sum-exp, fc1 pre-activations, the residual stream before each norm);
+    backward = activation gradients only (block.py:92-117, attention.py:54-71, mlp.py:34-40 under
+    autograd with all weights frozen):
+        LN bwd -> fc2^T (x LayerScale, x gelu') -> fc1^T -> LN bwd -> proj^T (x LayerScale) ->
+        attention bwd -> qkv^T -> LN bwd, accumulating into an fp32 gradient stream."""
+
+    @staticmethod
+    def forward(ctx, x0, packed, heads, B, T, eps):
+        L = T + 1
+        x = x0.detach().clone()
+        saved = []
+        for blk in packed["blocks"]:
+            x_in = x.clone()
+            h1 = ops.layernorm(x, blk["n1w"], blk["n1b"], eps)
+            qkv = ops.linear(h1, blk["qkv_w"], blk["qkv_b"])
+            att, lse = ops.attention_packed_qkv_lse(qkv, B, L, heads, 64 ** -0.5)
+            ops.linear_residual_(x, att, blk["proj_w"], blk["proj_b"], blk["ls1"])
+            x_mid = x.clone()
+            h2 = ops.layernorm(x, blk["n2w"], blk["n2b"], eps)
+            hid, pre = ops.linear_gelu_save(h2, blk["fc1_w"], blk["fc1_b"])
+            ops.linear_residual_(x, hid, blk["fc2_w"], blk["fc2_b"], blk["ls2"])
+            saved.append((x_in, qkv, att, lse, x_mid, pre))
+        feats = ops.layernorm(x, packed["nw"], packed["nb"], eps, group_out=T, skip=1, rows_out=B * T)
+        ctx.saved, ctx.x_final, ctx.packed, ctx.geom = saved, x, packed, (heads, B, T, eps)
+        return feats
+
+    @staticmethod
+    def _bwd_weights(blk):
+        """Transposed (data-gradient) weight copies, LayerScale folded in, cached beside the packed weights."""
+        if "bwd" not in blk:
+            def t(w, gamma=None):  # forward y = x W^T (W [N,K]); backward gx = gy W -> gemm weight [K,N]
+                w = w.float()
+                if gamma is not None:
+                    w = w * gamma[:, None]
+                return w.t().contiguous().to(BF16)
+            blk["bwd"] = dict(fc2=t(blk["fc2_w"], blk["ls2"]), fc1=t(blk["fc1_w"]), proj=t(blk["proj_w"], blk["ls1"]),
+                              qkv=t(blk["qkv_w"]))
+        return blk["bwd"]
+
+    @staticmethod
+    def backward(ctx, gfeats):
+        heads, B, T, eps = ctx.geom
+        L = T + 1
+        P = ctx.packed
+        gx, g16 = ops.layernorm_bwd(ctx.x_final, gfeats.contiguous().view(B * T, -1), P["nw"], eps, group_out=T, skip=1)
+        for blk, (x_in, qkv, att, lse, x_mid, pre) in zip(reversed(P["blocks"]), reversed(ctx.saved)):
+            W = ViTTrunkFn._bwd_weights(blk)
+            g_pre = ops.linear_mul_dgelu(g16, W["fc2"], pre)             # d/d(fc1 out), LayerScale + gelu' fused
+            g_h2 = ops.linear(g_pre, W["fc1"])
+            gx, g16 = ops.layernorm_bwd(x_mid, g_h2, blk["n2w"], eps, gx=gx)
+            g_att = ops.linear(g16, W["proj"])
+            g_qkv = ops.attention_packed_qkv_bwd(qkv, att, g_att, lse, B, L, heads, 64 ** -0.5)
+            g_h1 = ops.linear(g_qkv, W["qkv"])
+            gx, g16 = ops.layernorm_bwd(x_in, g_h1, blk["n1w"], eps, gx=gx)
+        ctx.saved = None
+        return gx, None, None, None, None, None
+
+
+class TokenInjectFn(torch.autograd.Function):
+    """x0[b, 1+t] = tokens[b, 1+t] + clicks[b, t] (DINOv2.py:518-523): the gradient of the click tokens is the
+    gradient of the stream rows 1..T."""
+
+    @staticmethod
+    def forward(ctx, xs, clicks, B, T):
+        out = xs.clone()
+        ops.token_add_(out, clicks.detach().float().contiguous(), B, T, has_cls=True)
+        ctx.geom = (B, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, gx):
+        B, T = ctx.geom
+        return None, gx.view(B, T + 1, -1)[:, 1:].contiguous(), None, None
 
 
 def grad_mode(*modules_or_params):

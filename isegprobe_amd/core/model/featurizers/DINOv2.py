@@ -24,7 +24,7 @@ from torch.nn.init import trunc_normal_
 from .... import hip_ops as ops
 from ...._lib import IspError
 from ...utils.log import logger
-from .._autograd import TokenAddFn
+from .._autograd import TokenAddFn, TokenInjectFn, ViTTrunkFn
 from .._tensor import BF16, PackedCache, nchw_view
 
 ARCHS = {  # DINOv2.py:413-449 (vit_giant2 uses SwiGLU: not built)
@@ -232,11 +232,20 @@ class DINOv2Featurizer(nn.Module):
         if inject and mode not in ("before_backbone", "after_backbone"):
             raise NameError(f"Unknown feats_injection_mode: {mode}")
         wants_grad = torch.is_grad_enabled() and inject and additional_features.requires_grad
-        if wants_grad and mode == "before_backbone":
-            raise NotImplementedError(
-                "training with feats_injection_mode='before_backbone' needs the backward of the frozen ViT "
-                "(activation gradients, SURVEY.md fact 8), which is not built; use 'after_backbone' or no_grad")
         D = self.model.embed_dim
+        if wants_grad and mode == "before_backbone":  # the reference's default training mode
+            if D // self.model.num_heads != 64:
+                raise NotImplementedError("the attention backward is built for head_dim 64")
+            with torch.no_grad():
+                x = x.float().contiguous()
+                Wimg, bimg = self._image_weights()
+                A = ops.patchify(x, None, None, p, Wimg.shape[1])
+                xs, T = self._embed(A, Wimg, bimg, b, H, W)
+            if tuple(additional_features.shape) != (b, T, D):
+                raise AssertionError(f"x.shape: {(b, T, D)}, additional_features.shape: {tuple(additional_features.shape)}")
+            x0 = TokenInjectFn.apply(xs, additional_features, b, T)
+            feats = ViTTrunkFn.apply(x0, self.packed(), self.model.num_heads, b, T, LN_EPS)
+            return nchw_view(feats.view(b, h, w, D))
         with torch.no_grad():  # frozen trunk: no graph
             x = x.float().contiguous()
             Wimg, bimg = self._image_weights()

@@ -45,7 +45,8 @@ class iSegBaseModel(nn.Module):
         if tuple(logits.shape[2:]) == tuple(size):
             return logits
         if torch.is_grad_enabled() and logits.requires_grad:
-            raise NotImplementedError("backward of the final logit resize is not built (upsampler output != image size)")
+            from ._autograd import ResizeLogitsFn
+            return ResizeLogitsFn.apply(logits, size[0], size[1])
         return ops.resize_bilinear_nchw_f32(logits.float().contiguous(), size[0], size[1])
 
     def prepare_input(self, image: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

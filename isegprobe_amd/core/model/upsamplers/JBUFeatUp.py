@@ -122,4 +122,5 @@ class JBUFeatUpUpsampler(BaseUpsampler):
         self.eval()
 
     def forward(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
+        self._refuse_source_grad(source)
         return self.upsampler(source, guidance)

@@ -114,6 +114,7 @@ class LiFTUpsampler(BaseUpsampler):
         return self._packed.get(params, build)
 
     def forward(self, source, guidance):
+        self._refuse_source_grad(source)
         """LiFT(imgs=guidance, x=source) (LiFT.py:106-122, :145-146) -> [B, C, 2h, 2w]."""
         P = self.packed()
         x = to_nhwc_bf16(source)

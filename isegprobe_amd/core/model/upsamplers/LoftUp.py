@@ -227,6 +227,7 @@ class LoftUpUpsampler(BaseUpsampler):
         return self._pe_cache[key]
 
     def forward(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
+        self._refuse_source_grad(source)
         P = self.packed()
         src = to_nhwc_bf16(source)
         B, h, w, C = src.shape

@@ -11,6 +11,16 @@ class BaseUpsampler(nn.Module, ABC):
     def forward(self, source, guidance):
         pass
 
+    def _refuse_source_grad(self, source):
+        """The learned upsamplers run raw HIP kernels with no backward: asking autograd to
+        differentiate through them (training with clicks injected before them) must fail loudly
+        instead of silently producing zero gradients."""
+        import torch
+        if torch.is_grad_enabled() and source.requires_grad:
+            raise NotImplementedError(
+                f"{type(self).__name__} has no backward on the HIP path: train with the identity/bilinear "
+                "upsampler, or run this upsampler under torch.no_grad()")
+
 
 from .basic_upsamplers import (  # noqa: E402
     BicubicUpsampler,

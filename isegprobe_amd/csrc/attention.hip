@@ -52,7 +52,8 @@ template <int HD>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                         const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H,
                                                         int Lq, int Lk, long qsb, long qsl, long qsh, long ksb, long ksl,
-                                                        long ksh, long osb, long osl, long osh, float c /* scale*log2e */) {
+                                                        long ksh, long osb, long osl, long osh, float c /* scale*log2e */,
+                                                        float* __restrict__ lse, long lse_ld) {
     using G = Geo<HD>;
     constexpr int KK = HD / 16;  // k-steps of the QK^T product
     constexpr int DB = HD / 32;  // 32-wide blocks of the head dim (rows of O^T)
@@ -203,6 +204,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     // ---- epilogue: O[b, q, h, d] = o / l
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
+    // base-2 log-sum-exp of the scaled scores, kept for the backward (P = exp2(s*c - lse))
+    if (lse && hh == 0 && qrow < Lq) lse[(size_t)blockIdx.y * lse_ld + qrow] = m_run + log2f(l_tot);
     if (qrow < Lq) {
         bf16_t* op = O + (size_t)b * osb + (size_t)qrow * osl + (size_t)h * osh;
 #pragma unroll
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 template <int HD>
 int launch_attention(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, long qsb,
                      long qsl, long qsh, long ksb, long ksl, long ksh, long osb, long osl, long osh, float scale,
-                     hipStream_t s) {
+                     float* lse, long lse_ld, hipStream_t s) {
     static bool attr_done = false;
     auto kern = attention_kernel<HD>;
     if (!attr_done) {
@@ -230,28 +233,47 @@ int launch_attention(const void* Q, const void* K, const void* V, void* O, int B
     }
     dim3 grid((Lq + QB - 1) / QB, B * H);
     kern<<<grid, 256, Geo<HD>::LDS, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, H, Lq, Lk, qsb,
-                                         qsl, qsh, ksb, ksl, ksh, osb, osl, osh, scale * 1.4426950408889634f);
+                                         qsl, qsh, ksb, ksl, ksh, osb, osl, osh, scale * 1.4426950408889634f, lse,
+                                         lse_ld);
     return isp_launch_status();
 }
 
 }  // namespace
 
-extern "C" int isp_attention_fwd(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
-                                 int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
-                                 long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l,
-                                 long o_stride_h, float scale, void* stream) {
+static int attention_fwd_impl(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
+                              int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
+                              long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
+                              float scale, float* lse, long lse_ld, void* stream) {
     ISP_CHECK_ARG(Q && K && V && O && B > 0 && H > 0 && Lq > 0 && Lk > 0 && scale > 0.f);
     ISP_CHECK_ARG((long)B * H <= 65535);
     // 16-byte vector loads / 8-byte stores need aligned strides
     ISP_CHECK_ARG(q_stride_b % 8 == 0 && q_stride_l % 8 == 0 && q_stride_h % 8 == 0);
     ISP_CHECK_ARG(kv_stride_b % 8 == 0 && kv_stride_l % 8 == 0 && kv_stride_h % 8 == 0);
     ISP_CHECK_ARG(o_stride_b % 4 == 0 && o_stride_l % 4 == 0 && o_stride_h % 4 == 0);
+    ISP_CHECK_ARG(!lse || lse_ld >= Lq);
     hipStream_t s = (hipStream_t)stream;
     if (head_dim == 64)
         return launch_attention<64>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
-                                    kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, s);
+                                    kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
     if (head_dim == 128)
         return launch_attention<128>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
-                                     kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, s);
+                                     kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
     return ISP_ERR_UNSUPPORTED;
+}
+
+extern "C" int isp_attention_fwd(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
+                                 int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
+                                 long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l,
+                                 long o_stride_h, float scale, void* stream) {
+    return attention_fwd_impl(Q, K, V, O, B, H, Lq, Lk, head_dim, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                              kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, nullptr, 0, stream);
+}
+
+extern "C" int isp_attention_fwd_lse(const void* Q, const void* K, const void* V, void* O, float* lse, long lse_ld, int B,
+                                     int H, int Lq, int Lk, int head_dim, long q_stride_b, long q_stride_l,
+                                     long q_stride_h, long kv_stride_b, long kv_stride_l, long kv_stride_h,
+                                     long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream) {
+    ISP_CHECK_ARG(lse);
+    return attention_fwd_impl(Q, K, V, O, B, H, Lq, Lk, head_dim, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                              kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, stream);
 }

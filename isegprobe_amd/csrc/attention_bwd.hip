@@ -1,0 +1,249 @@
+// Backward of softmax(Q K^T * scale) V for head_dim 64 on gfx950 (bf16 MFMA, fp32 accumulate):
+// dQ, dK, dV from Q, K, V, O, dO and the forward's log-sum-exp; the [Lq, Lk] probability matrix
+// is recomputed tile by tile and never stored.
+//
+// Needed for the reference's default training mode (feats_injection_mode="before_backbone",
+// models/sbd/dinov2/patch-embed_*.py:40): the click patch-embedding receives its gradient through
+// every frozen block of the ViT, i.e. through Attention.forward (dinov2/layers/attention.py:54-71),
+// which the reference differentiates with autograd (and materialises [B, heads, N, N] twice).
+//
+// Two launches share one kernel template.  A block of 4 waves OWNS 64 rows of one side and STREAMS
+// 64-row tiles of the other side through LDS:
+//   * dK/dV launch: owner = 64 keys   (K, V rows in registers), stream = query tiles (Q, dO);
+//   * dQ    launch: owner = 64 queries (Q, dO rows in registers), stream = key tiles   (K, V).
+// Per tile and wave (16 owner rows o, 64 streamed rows s):
+//   X1[s][o] = stream1[s] . own1[o]   (S or S^T)      X2[s][o] = stream2[s] . own2[o]   (dP or dP^T)
+//   P = exp2(X1*c - lse[query]);  dS = P * (X2 - delta[query]) * scale        (fp32, in registers)
+//   out^T[d][o] += sum_s streamX[s][d] * {P | dS}[s][o]
+// The score products are v_mfma_f32_16x16x32_bf16 (A = streamed rows by ds_read_b128, B = owner rows);
+// their accumulator layout (4 consecutive s per lane, o = lane&15) IS the B operand layout of
+// v_mfma_f32_16x16x16_bf16, whose A operand (streamed tile transposed) comes from
+// ds_read_b64_tr_b16: P / dS never touch LDS.  Streamed tiles are staged twice by LDS-DMA, once
+// swizzled for the row reads and once for the transposed reads (source-side XOR swizzles).
+#include "isp_common.h"
+
+namespace {
+
+constexpr int TB = 64;  // owner rows per block, streamed rows per tile
+constexpr int HD = 64;
+constexpr int TILE = TB * HD * 2;  // 8 KiB
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((ISP_LDS s16x4*)p);
+}
+__device__ __forceinline__ int rswz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }         // ds_read_b128 image
+__device__ __forceinline__ int tswz(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }  // tr-read image
+
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+__global__ void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, float* __restrict__ delta,
+                                  int H, int Lq, long osb, long osl, long osh, long ld) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Lq) return;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+    const size_t off = (size_t)b * osb + (size_t)q * osl + (size_t)h * osh;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < HD / 8; ++i) {
+        const bf16x8 o = *reinterpret_cast<const bf16x8*>(O + off + 8 * i);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dO + off + 8 * i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += bf2f((bf16_t)o[j]) * bf2f((bf16_t)g[j]);
+    }
+    delta[(size_t)blockIdx.y * ld + q] = acc;
+}
+
+struct Side {  // one side of the attention (queries or keys): two row-major [L, 64] bf16 matrices
+    const bf16_t* m1;
+    const bf16_t* m2;
+    long sb1, sl1, sh1, sb2, sl2, sh2;  // element strides (batch, row, head) of m1 / m2
+    int L;
+};
+
+// OWN_KEYS: owner side = keys (outputs dK = out1 with m-stream Q, dV = out2 with stream dO);
+// otherwise owner side = queries (output dQ = out1 with stream K).
+template <bool OWN_KEYS>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const float* __restrict__ lse,
+                                                       const float* __restrict__ delta, long ld_stat,
+                                                       bf16_t* __restrict__ out1, bf16_t* __restrict__ out2, long ob,
+                                                       long ol, long oh, int H, float scale, float c) {
+    // LDS per stage: [stream1 rows][stream2 rows][stream1 tr]([stream2 tr] when OWN_KEYS)
+    constexpr int NT_IMG = OWN_KEYS ? 4 : 3;
+    constexpr int STAGE = NT_IMG * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.y / H, h = blockIdx.y % H;
+
+    // ---- owner rows: B operands of the score products, element j <-> d = 32kk + 8fq + j
+    const int orow = blockIdx.x * TB + wid * 16 + fr;
+    const int orow_c = orow < own.L ? orow : own.L - 1;
+    const bf16_t* o1 = own.m1 + (size_t)b * own.sb1 + (size_t)orow_c * own.sl1 + (size_t)h * own.sh1 + 8 * fq;
+    const bf16_t* o2 = own.m2 + (size_t)b * own.sb2 + (size_t)orow_c * own.sl2 + (size_t)h * own.sh2 + 8 * fq;
+    bf16x8 own1[2], own2[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        own1[kk] = *reinterpret_cast<const bf16x8*>(o1 + 32 * kk);
+        own2[kk] = *reinterpret_cast<const bf16x8*>(o2 + 32 * kk);
+    }
+    const size_t stat_row = (size_t)blockIdx.y * ld_stat;
+    float lse_o = 0.f, delta_o = 0.f;
+    if (!OWN_KEYS) {
+        lse_o = lse[stat_row + orow_c];
+        delta_o = delta[stat_row + orow_c];
+    }
+
+    // ---- DMA: a tile image = 8 pieces of 1 KiB (8 rows x 128 B); wave w takes pieces w and w+4
+    const bf16_t* s1 = str.m1 + (size_t)b * str.sb1 + (size_t)h * str.sh1;
+    const bf16_t* s2 = str.m2 + (size_t)b * str.sb2 + (size_t)h * str.sh2;
+    auto stage = [&](int tile, char* buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wid + 4 * i;
+            const int row = piece * 8 + (lane >> 3), pch = lane & 7;
+            int g = tile * TB + row;
+            g = g < str.L ? g : str.L - 1;
+            const bf16_t* r1 = s1 + (size_t)g * str.sl1;
+            const bf16_t* r2 = s2 + (size_t)g * str.sl2;
+            glds16(r1 + rswz(row, pch) * 8, buf + piece * 1024);
+            glds16(r2 + rswz(row, pch) * 8, buf + TILE + piece * 1024);
+            glds16(r1 + tswz(row, pch) * 8, buf + 2 * TILE + piece * 1024);
+            if (OWN_KEYS) glds16(r2 + tswz(row, pch) * 8, buf + 3 * TILE + piece * 1024);
+        }
+    };
+
+    // ---- fragment offsets.  Row image: row 16mi + fr, logical chunk 4kk + fq (swizzle term depends on fr only).
+    int r_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) r_off[kk] = fr * 128 + (rswz(fr, 4 * kk + fq) << 4);
+    // Transposed image: lane i = 4q+p of 16-lane group fq addresses row 16mi + 4fq + q, columns 16dt + 4p .. +3;
+    // the hardware hands lane fr column 16dt + fr of rows 4fq .. 4fq+3 (A operand of the 16x16x16 product).
+    int t_off[4];
+    {
+        const int row = 4 * fq + (fr >> 2), colb = 8 * (fr & 3);  // byte offset of the 4 columns within 32 B
+        const int sw = ((row >> 1) & 3) << 1;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) t_off[dt] = row * 128 + (((2 * dt + (colb >> 4)) ^ sw) << 4) + (colb & 15);
+    }
+
+    f32x4 acc1[4], acc2[4];  // out^T tiles: [dt] -> rows d = 16dt + 4fq + r, column o = fr
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc1[i] = acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = (str.L + TB - 1) / TB;
+    stage(0, smem);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const char* buf = smem + (t & 1) * STAGE;
+        if (t + 1 < nt) stage(t + 1, smem + ((t + 1) & 1) * STAGE);
+
+        f32x4 x1[4], x2[4];  // [mi]: streamed rows s = 16mi + 4fq + r, owner o = fr
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            x1[mi] = x2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(buf + mi * 2048 + r_off[kk]);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(buf + TILE + mi * 2048 + r_off[kk]);
+                x1[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, own1[kk], x1[mi], 0, 0, 0);
+                x2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, own2[kk], x2[mi], 0, 0, 0);
+            }
+        }
+        // P and dS in place (x1 -> P, x2 -> dS)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int sbase = t * TB + 16 * mi + 4 * fq;
+            float l4[4], d4[4];
+            if (OWN_KEYS) {  // statistics belong to the streamed (query) rows; buffers are padded to 64
+                const float4 lv = *reinterpret_cast<const float4*>(lse + stat_row + sbase);
+                const float4 dv = *reinterpret_cast<const float4*>(delta + stat_row + sbase);
+                l4[0] = lv.x, l4[1] = lv.y, l4[2] = lv.z, l4[3] = lv.w;
+                d4[0] = dv.x, d4[1] = dv.y, d4[2] = dv.z, d4[3] = dv.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) l4[r] = lse_o, d4[r] = delta_o;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = sbase + r < str.L && orow < own.L;
+                const float p = ok ? __builtin_amdgcn_exp2f(x1[mi][r] * c - l4[r]) : 0.f;
+                x1[mi][r] = p;
+                x2[mi][r] = ok ? p * (x2[mi][r] - d4[r]) * scale : 0.f;
+            }
+        }
+        // out1^T += stream1^T . dS ; out2^T += stream2^T . P   (contraction over the 16 streamed rows of tile mi)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const s16x4 ds = {(short)f2bf(x2[mi][0]), (short)f2bf(x2[mi][1]), (short)f2bf(x2[mi][2]), (short)f2bf(x2[mi][3])};
+            const s16x4 pp = {(short)f2bf(x1[mi][0]), (short)f2bf(x1[mi][1]), (short)f2bf(x1[mi][2]), (short)f2bf(x1[mi][3])};
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const s16x4 a1 = tr_read(buf + 2 * TILE + mi * 2048 + t_off[dt]);
+                acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, ds, acc1[dt], 0, 0, 0);
+                if (OWN_KEYS) {
+                    const s16x4 a2 = tr_read(buf + 3 * TILE + mi * 2048 + t_off[dt]);
+                    acc2[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, pp, acc2[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (orow < own.L) {
+        const size_t off = (size_t)b * ob + (size_t)orow * ol + (size_t)h * oh + 4 * fq;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            *reinterpret_cast<uint2*>(out1 + off + 16 * dt) =
+                make_uint2(pack2bf(acc1[dt][0], acc1[dt][1]), pack2bf(acc1[dt][2], acc1[dt][3]));
+            if (OWN_KEYS)
+                *reinterpret_cast<uint2*>(out2 + off + 16 * dt) =
+                    make_uint2(pack2bf(acc2[dt][0], acc2[dt][1]), pack2bf(acc2[dt][2], acc2[dt][3]));
+        }
+    }
+}
+
+template <bool OWN_KEYS>
+int launch_bwd(const Side& own, const Side& str, const float* lse, const float* delta, long ld, void* out1, void* out2,
+               long ob, long ol, long oh, int B, int H, float scale, hipStream_t s) {
+    constexpr int lds = 2 * (OWN_KEYS ? 4 : 3) * TILE;
+    static bool attr_done = false;
+    auto kern = attn_bwd_kernel<OWN_KEYS>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return ISP_ERR_LAUNCH;
+        attr_done = true;
+    }
+    dim3 grid((own.L + TB - 1) / TB, B * H);
+    kern<<<grid, 256, lds, s>>>(own, str, lse, delta, ld, (bf16_t*)out1, (bf16_t*)out2, ob, ol, oh, H, scale,
+                               scale * 1.4426950408889634f);
+    return isp_launch_status();
+}
+
+}  // namespace
+
+extern "C" int isp_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                                 const float* lse, float* delta, long stat_ld, void* dQ, void* dK, void* dV, int B, int H,
+                                 int Lq, int Lk, int head_dim, long q_stride_b, long q_stride_l, long q_stride_h,
+                                 long kv_stride_b, long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l,
+                                 long o_stride_h, float scale, void* stream) {
+    ISP_CHECK_ARG(Q && K && V && O && dO && lse && delta && dQ && dK && dV);
+    ISP_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0 && scale > 0.f && (long)B * H <= 65535);
+    if (head_dim != HD) return ISP_ERR_UNSUPPORTED;
+    ISP_CHECK_ARG(stat_ld % TB == 0 && stat_ld >= Lq);  // statistics rows padded: float4 reads of a partial last tile
+    ISP_CHECK_ARG(q_stride_b % 8 == 0 && q_stride_l % 8 == 0 && q_stride_h % 8 == 0);
+    ISP_CHECK_ARG(kv_stride_b % 8 == 0 && kv_stride_l % 8 == 0 && kv_stride_h % 8 == 0);
+    ISP_CHECK_ARG(o_stride_b % 8 == 0 && o_stride_l % 8 == 0 && o_stride_h % 8 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    attn_delta_kernel<<<dim3((Lq + 255) / 256, B * H), 256, 0, s>>>((const bf16_t*)O, (const bf16_t*)dO, delta, H, Lq,
+                                                                    o_stride_b, o_stride_l, o_stride_h, stat_ld);
+    if (int rc = isp_launch_status()) return rc;
+    const Side qs{(const bf16_t*)Q, (const bf16_t*)dO, q_stride_b, q_stride_l, q_stride_h, o_stride_b, o_stride_l, o_stride_h, Lq};
+    const Side ks{(const bf16_t*)K, (const bf16_t*)V, kv_stride_b, kv_stride_l, kv_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, Lk};
+    // dK (stream1 = Q with dS) and dV (stream2 = dO with P): gradients share the K/V strides
+    if (int rc = launch_bwd<true>(ks, qs, lse, delta, stat_ld, dK, dV, kv_stride_b, kv_stride_l, kv_stride_h, B, H, scale, s))
+        return rc;
+    // dQ (stream1 = K with dS)
+    return launch_bwd<false>(qs, ks, lse, delta, stat_ld, dQ, nullptr, q_stride_b, q_stride_l, q_stride_h, B, H, scale, s);
+}

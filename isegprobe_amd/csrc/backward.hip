@@ -277,7 +277,129 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const bf16_t* __restr
         make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
 }
 
+// Same adjoint for planar fp32 maps [N,h,w] <- [N,H,W] (the logits resize of iseg_base_model.py:75-80,
+// which sits between the head and the loss when the upsampler output is smaller than the image).
+__global__ __launch_bounds__(256) void bilinear_bwd_planar_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                                   int h, int w, int H, int W, float sy, float sx,
+                                                                   long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % w);
+    const int y = (int)((idx / w) % h);
+    const long n = idx / ((long)w * h);
+    const int Y0 = sy > 0.f ? max(0, (int)floorf((float)(y - 1) / sy) - 1) : 0;
+    const int Y1 = sy > 0.f ? min(H - 1, (int)ceilf((float)(y + 1) / sy) + 1) : H - 1;
+    const int X0 = sx > 0.f ? max(0, (int)floorf((float)(x - 1) / sx) - 1) : 0;
+    const int X1 = sx > 0.f ? min(W - 1, (int)ceilf((float)(x + 1) / sx) + 1) : W - 1;
+    float acc = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+        const float fy = sy * (float)Y;
+        const int y0 = (int)fy, y1 = min(y0 + 1, h - 1);
+        const float ly = fy - (float)y0;
+        float wy = 0.f;
+        if (y0 == y) wy += 1.f - ly;
+        if (y1 == y) wy += ly;
+        if (wy == 0.f) continue;
+        for (int X = X0; X <= X1; ++X) {
+            const float fx = sx * (float)X;
+            const int x0 = (int)fx, x1 = min(x0 + 1, w - 1);
+            const float lx = fx - (float)x0;
+            float wx = 0.f;
+            if (x0 == x) wx += 1.f - lx;
+            if (x1 == x) wx += lx;
+            if (wx != 0.f) acc += wy * wx * dout[((size_t)n * H + Y) * W + X];
+        }
+    }
+    din[idx] = acc;
+}
+
 }  // namespace
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm backward w.r.t. the input (weights frozen), one wave per INPUT row:
+//   g^ = gy * gamma,  x^ = (x - mean) * rstd,  dx = rstd * (g^ - mean(g^) - x^ * mean(g^ x^)).
+// Statistics are recomputed from the fp32 row.  gx (fp32, the gradient of the residual stream) is
+// accumulated (gx += dx) or overwritten; a bf16 copy of the updated row feeds the next GEMM.
+// With group_out > 0 the forward dropped `skip` leading rows of each (group_out+skip)-row group
+// (the cls token, DINOv2.py:533-534): those rows receive zero.
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ gy,
+                                                             const float* __restrict__ gamma, float* __restrict__ gx,
+                                                             bf16_t* __restrict__ gx16, long rows, int D, float eps,
+                                                             int group_out, int skip, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    long rg = r;  // row of gy
+    bool has_g = true;
+    if (group_out > 0) {
+        const long grp = r / (group_out + skip), idx = r % (group_out + skip);
+        has_g = idx >= skip;
+        rg = grp * group_out + (idx - skip);
+    }
+    const int nchunk = D >> 2;
+    const float* xr = x + r * D;
+    float4 v[MAXV], g[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        v[i] = g[i] = make_float4(0, 0, 0, 0);
+        if (c < nchunk) {
+            v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            if (has_g) {
+                const uint2 u = *reinterpret_cast<const uint2*>(gy + rg * D + c * 4);
+                const float4 gm = *reinterpret_cast<const float4*>(gamma + c * 4);
+                g[i] = make_float4(__uint_as_float(u.x << 16) * gm.x, __uint_as_float(u.x & 0xffff0000u) * gm.y,
+                                   __uint_as_float(u.y << 16) * gm.z, __uint_as_float(u.y & 0xffff0000u) * gm.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            v[i].x -= mean, v[i].y -= mean, v[i].z -= mean, v[i].w -= mean;
+            sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)D + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        v[i].x *= rstd, v[i].y *= rstd, v[i].z *= rstd, v[i].w *= rstd;  // x^
+        sg += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        sgx += (g[i].x * v[i].x + g[i].y * v[i].y) + (g[i].z * v[i].z + g[i].w * v[i].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sg += __shfl_xor(sg, o);
+        sgx += __shfl_xor(sgx, o);
+    }
+    const float mg = sg / (float)D, mgx = sgx / (float)D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            float4 d = make_float4(rstd * (g[i].x - mg - v[i].x * mgx), rstd * (g[i].y - mg - v[i].y * mgx),
+                                   rstd * (g[i].z - mg - v[i].z * mgx), rstd * (g[i].w - mg - v[i].w * mgx));
+            float* gp = gx + r * D + c * 4;
+            if (accumulate) {
+                const float4 old = *reinterpret_cast<const float4*>(gp);
+                d.x += old.x, d.y += old.y, d.z += old.z, d.w += old.w;
+            }
+            *reinterpret_cast<float4*>(gp) = d;
+            if (gx16) *reinterpret_cast<uint2*>(gx16 + r * D + c * 4) = make_uint2(pack2bf(d.x, d.y), pack2bf(d.z, d.w));
+        }
+    }
+}
 
 extern "C" int isp_tn_gemm_bf16_atomic(const void* P, long ldp, const void* Q, long ldq, float* out, long ldo, long M,
                                        int N, int J, int shift_H, int shift_W, int shift_dy, int shift_dx,
@@ -325,5 +447,34 @@ extern "C" int isp_resize_bilinear_ac_nhwc_bwd(const void* dout, void* din, int 
     const long total = (long)B * h * w * (C / 8);
     bilinear_bwd_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         (const bf16_t*)dout, (bf16_t*)din, h, w, H, W, C, sy, sx, total);
+    return isp_launch_status();
+}
+
+extern "C" int isp_layernorm_bwd(const float* x, const void* gy, const float* gamma, float* gx, void* gx_bf16, long rows,
+                                 int D, float eps, int group_out, int skip, int accumulate, void* stream) {
+    ISP_CHECK_ARG(x && gy && gamma && gx && rows > 0 && D > 0 && D % 4 == 0 && group_out >= 0 && skip >= 0);
+    ISP_CHECK_ARG(group_out == 0 || rows % (group_out + skip) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = D / 4;
+    dim3 grid((unsigned)((rows + 3) / 4));
+#define LNB_CASE(MV)                                                                                                    \
+    layernorm_bwd_kernel<MV><<<grid, 256, 0, s>>>(x, (const bf16_t*)gy, gamma, gx, (bf16_t*)gx_bf16, rows, D, eps, group_out, \
+                                                  skip, accumulate)
+    if (nchunk <= 64) LNB_CASE(1);
+    else if (nchunk <= 128) LNB_CASE(2);
+    else if (nchunk <= 256) LNB_CASE(4);
+    else return ISP_ERR_UNSUPPORTED;
+#undef LNB_CASE
+    return isp_launch_status();
+}
+
+extern "C" int isp_resize_bilinear_ac_nchw_f32_bwd(const float* dout, float* din, long planes, int h, int w, int H, int W,
+                                                   void* stream) {
+    ISP_CHECK_ARG(dout && din && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0);
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const long total = planes * h * w;
+    bilinear_bwd_planar_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(dout, din, h, w, H, W, sy,
+                                                                                               sx, total);
     return isp_launch_status();
 }

@@ -165,6 +165,39 @@ struct EpBiasActBf16 {  // out[m][n] = bf16(act(v + bias[n]))
     }
 };
 
+struct EpBiasGeluSaveBf16 {  // out = gelu(v + bias), pre = v + bias (kept for the backward)
+    bf16_t* out;
+    bf16_t* pre;
+    const float* bias;
+    long ldo;
+    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
+        float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
+        const float r[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
+        *reinterpret_cast<uint2*>(pre + (size_t)m * ldo + n) = make_uint2(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]));
+        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) =
+            make_uint2(pack2bf(gelu_erf(r[0]), gelu_erf(r[1])), pack2bf(gelu_erf(r[2]), gelu_erf(r[3])));
+    }
+};
+
+struct EpMulDGeluBf16 {  // out = v * gelu'(pre):  gelu'(x) = Phi(x) + x phi(x)
+    bf16_t* out;
+    const bf16_t* pre;
+    long ldo;
+    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
+        const uint2 raw = *reinterpret_cast<const uint2*>(pre + (size_t)m * ldo + n);
+        const float x[4] = {bf2f((bf16_t)(raw.x & 0xffff)), bf2f((bf16_t)(raw.x >> 16)), bf2f((bf16_t)(raw.y & 0xffff)),
+                            bf2f((bf16_t)(raw.y >> 16))};
+        float r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float cdf = 0.5f * (1.0f + fast_erf(x[j] * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * __expf(-0.5f * x[j] * x[j]);
+            r[j] = v[j] * (cdf + x[j] * pdf);
+        }
+        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = make_uint2(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]));
+    }
+};
+
 template <int ACT>
 struct EpBiasActF32 {  // out[m][n] = act(v + bias[n]) in fp32
     float* out;
@@ -739,6 +772,16 @@ int dispatch_epilogue(AL al, const void* Wt, long M, int N, int K, const isp_epi
             if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
             return launch_gemm<CFG>(al, Wt, M, N, K, EpReluDotPartial{(float*)e->out, e->bias, e->gamma, M}, s);
             }
+        case ISP_EP_BIAS_GELU_SAVE_BF16:
+            if constexpr (!((KINDS >> ISP_EP_BIAS_GELU_SAVE_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            if (!e->out2) return ISP_ERR_INVALID;
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpBiasGeluSaveBf16{(bf16_t*)e->out, (bf16_t*)e->out2, e->bias, ldo}, s);
+            }
+        case ISP_EP_MUL_DGELU_BF16:
+            if constexpr (!((KINDS >> ISP_EP_MUL_DGELU_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            if (!e->res) return ISP_ERR_INVALID;
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpMulDGeluBf16{(bf16_t*)e->out, (const bf16_t*)e->res, ldo}, s);
+            }
         default:
             return ISP_ERR_UNSUPPORTED;
     }
@@ -753,7 +796,7 @@ extern "C" int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, in
     al.A = (const bf16_t*)A;
     al.lda = lda;
     al.M = M;
-    return dispatch_epilogue<Cfg128, DenseA<Cfg128::PA>, 0x27fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
+    return dispatch_epilogue<Cfg128, DenseA<Cfg128::PA>, 0xe7fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
 }
 
 // A/B switch for experiments: ISEGPROBE_CONV_ENGINE=tile selects the generic tile engine for every conv

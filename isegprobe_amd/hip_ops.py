@@ -85,6 +85,7 @@ def _epilogue(kind, out, ldo=0, bias=None, gamma=None, pos=None, tokens=0, res=N
     ep.tokens_per_image = tokens
     ep.res = res.data_ptr() if res is not None else None
     ep.alpha = alpha
+    ep.out2 = None
     return ep
 
 
@@ -111,6 +112,28 @@ def linear(A, Wt, bias=None, act=None, out_dtype=BF16):
             raise IspError("fp32 output supports no activation")
         kind = _lib.EP_BIAS_F32
     gemm(A, Wt, _epilogue(kind, out, N, bias))
+    return out
+
+
+def linear_gelu_save(A, Wt, bias):
+    """Training forward of Mlp.fc1 (mlp.py:34-40): returns (gelu(pre), pre), pre = A Wt^T + bias, both bf16."""
+    N = Wt.shape[0]
+    out = torch.empty(A.shape[0], N, device=A.device, dtype=BF16)
+    pre = torch.empty_like(out)
+    ep = _epilogue(_lib.EP_BIAS_GELU_SAVE_BF16, out, N, bias)
+    ep.out2 = pre.data_ptr()
+    gemm(A, Wt, ep)
+    return out, pre
+
+
+def linear_mul_dgelu(A, Wt, pre):
+    """(A Wt^T) * gelu'(pre): the fc2 data gradient with the GELU backward fused; pre bf16 [M,N]."""
+    _need(pre, BF16, "pre")
+    N = Wt.shape[0]
+    if tuple(pre.shape) != (A.shape[0], N):
+        raise IspError("pre-activation shape mismatch")
+    out = torch.empty(A.shape[0], N, device=A.device, dtype=BF16)
+    gemm(A, Wt, _epilogue(_lib.EP_MUL_DGELU_BF16, out, N, res=pre))
     return out
 
 
@@ -206,6 +229,72 @@ def attention_packed_qkv(qkv, B, L, heads, scale):
                                        L * 3 * D, 3 * D, 64, L * 3 * D, 3 * D, 64, L * D, D, 64,
                                        float(scale), _stream()), "isp_attention_fwd")
     return out
+
+
+def _stat_ld(L):
+    return (L + 63) // 64 * 64
+
+
+def attention_packed_qkv_lse(qkv, B, L, heads, scale):
+    """attention_packed_qkv + the base-2 log-sum-exp [B*heads, round_up(L,64)] f32 the backward needs."""
+    _need(qkv, BF16, "qkv")
+    D = heads * 64
+    out = torch.empty(B * L, D, device=qkv.device, dtype=BF16)
+    lse = torch.zeros(B * heads, _stat_ld(L), device=qkv.device, dtype=torch.float32)
+    base = qkv.data_ptr()
+    q, k, v = (ctypes.c_void_p(base + i * D * 2) for i in range(3))
+    check(_lib.lib().isp_attention_fwd_lse(q, k, v, _p(out), _p(lse), lse.shape[1], B, heads, L, L, 64,
+                                           L * 3 * D, 3 * D, 64, L * 3 * D, 3 * D, 64, L * D, D, 64,
+                                           float(scale), _stream()), "isp_attention_fwd_lse")
+    return out, lse
+
+
+def attention_packed_qkv_bwd(qkv, out, dout, lse, B, L, heads, scale):
+    """Gradient of attention_packed_qkv w.r.t. the packed qkv: returns [B*L, 3*heads*64] bf16."""
+    for t, n in ((qkv, "qkv"), (out, "out"), (dout, "dout")):
+        _need(t, BF16, n)
+    _need(lse, torch.float32, "lse")
+    D = heads * 64
+    if tuple(lse.shape) != (B * heads, _stat_ld(L)) or qkv.shape != (B * L, 3 * D) or out.shape != dout.shape:
+        raise IspError("attention backward: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.zeros_like(lse)
+    base, gbase = qkv.data_ptr(), dqkv.data_ptr()
+    q, k, v = (ctypes.c_void_p(base + i * D * 2) for i in range(3))
+    dq, dk, dv = (ctypes.c_void_p(gbase + i * D * 2) for i in range(3))
+    check(_lib.lib().isp_attention_bwd(q, k, v, _p(out), _p(dout), _p(lse), _p(delta), lse.shape[1], dq, dk, dv,
+                                       B, heads, L, L, 64, L * 3 * D, 3 * D, 64, L * 3 * D, 3 * D, 64, L * D, D, 64,
+                                       float(scale), _stream()), "isp_attention_bwd")
+    return dqkv
+
+
+def resize_bilinear_nchw_f32_bwd(gout, h, w):
+    """Adjoint of resize_bilinear_nchw_f32: gout [B,C,H,W] f32 -> [B,C,h,w] f32."""
+    _need(gout, torch.float32, "gout")
+    B, C, H, W = gout.shape
+    gin = torch.empty(B, C, h, w, device=gout.device, dtype=torch.float32)
+    check(_lib.lib().isp_resize_bilinear_ac_nchw_f32_bwd(_p(gout), _p(gin), B * C, h, w, H, W, _stream()),
+          "isp_resize_bilinear_ac_nchw_f32_bwd")
+    return gin
+
+
+def layernorm_bwd(x, gy, gamma, eps, gx=None, group_out=0, skip=0, want_bf16=True):
+    """gx (+)= d LayerNorm(x)/dx applied to gy.  x f32 [rows,D]; gy bf16 [rows_out,D]; gx f32 [rows,D] is
+    accumulated into when given, else created.  Returns (gx, bf16 copy of gx or None)."""
+    _need(x, torch.float32, "x")
+    _need(gy, BF16, "gy")
+    rows, D = x.shape
+    accumulate = gx is not None
+    if gx is None:
+        gx = torch.empty_like(x)
+    _need(gx, torch.float32, "gx")
+    rows_out = rows if group_out == 0 else rows // (group_out + skip) * group_out
+    if gy.shape != (rows_out, D) or gx.shape != x.shape:
+        raise IspError("layernorm_bwd: shape mismatch")
+    g16 = torch.empty(rows, D, device=x.device, dtype=BF16) if want_bf16 else None
+    check(_lib.lib().isp_layernorm_bwd(_p(x), _p(gy), _p(gamma), _p(gx), _p(g16) if g16 is not None else None, rows, D,
+                                       float(eps), group_out, skip, int(accumulate), _stream()), "isp_layernorm_bwd")
+    return gx, g16
 
 
 def attention(q, k, v, scale):

@@ -88,3 +88,96 @@ def test_bilinear_bwd(ops, shape):
     y.backward(gy)
     din = ops.resize_bilinear_nhwc_bwd(gy.permute(0, 2, 3, 1).contiguous().to(BF), h, w)
     assert rel(din.permute(0, 3, 1, 2), x.grad) < 1e-2
+
+
+# ------------------------------------------------------------------ frozen-ViT backward pieces
+@pytest.mark.parametrize("B,L,heads", [(2, 257, 2), (1, 64, 1), (2, 1025, 6), (3, 130, 3)])
+def test_attention_backward(ops, B, L, heads):
+    """dQ/dK/dV of the fused attention against autograd of the materialised softmax (fp32 on the
+    same bf16-rounded inputs).  L = 257 / 1025 / 130 exercise the partial last tile."""
+    torch.manual_seed(L + heads)
+    D = heads * 64
+    scale = 64 ** -0.5
+    qkv = torch.randn(B * L, 3 * D, device="cuda").to(BF)
+    dout = torch.randn(B * L, D, device="cuda").to(BF)
+    out, lse = ops.attention_packed_qkv_lse(qkv, B, L, heads, scale)
+    assert torch.equal(out, ops.attention_packed_qkv(qkv, B, L, heads, scale))  # same forward
+    dqkv = ops.attention_packed_qkv_bwd(qkv, out, dout, lse, B, L, heads, scale)
+
+    ref_in = qkv.float().requires_grad_(True)
+    q, k, v = ref_in.view(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = (q * scale) @ k.transpose(-2, -1)
+    ref_lse = torch.logsumexp(s, -1) * math.log2(math.e)  # base 2
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(B * L, D)
+    o.backward(dout.float())
+    assert (lse[:, :L] - ref_lse.reshape(B * heads, L)).abs().max().item() < 2e-2
+    g, r = dqkv.float().view(B * L, 3, D), ref_in.grad.view(B * L, 3, D)
+    for i, name in enumerate("qkv"):
+        err = (g[:, i] - r[:, i]).abs().max().item() / r[:, i].abs().max().item()
+        assert err < 2e-2, (name, err)
+
+
+def test_attention_backward_asymmetric(ops):
+    """One-hot style probe: a dominant key per query makes P ~ a permutation, so transposed or
+    mis-indexed fragments show up as O(1) errors rather than noise."""
+    B, L, heads = 1, 192, 1
+    torch.manual_seed(5)
+    q = torch.randn(L, 64, device="cuda") * 0.05
+    k = torch.randn(L, 64, device="cuda") * 0.05
+    perm = (torch.arange(L, device="cuda") * 37 + 11) % L
+    k[perm] += q * 60.0
+    v = torch.randn(L, 64, device="cuda")
+    qkv = torch.stack((q, k, v), 1).reshape(L, 192).to(BF)
+    dout = torch.randn(L, 64, device="cuda").to(BF)
+    out, lse = ops.attention_packed_qkv_lse(qkv, B, L, heads, 1.0)
+    dqkv = ops.attention_packed_qkv_bwd(qkv, out, dout, lse, B, L, heads, 1.0).float().view(L, 3, 64)
+    ref_in = qkv.float().requires_grad_(True)
+    qq, kk, vv = ref_in.view(L, 3, 64).unbind(1)
+    ((qq @ kk.t()).softmax(-1) @ vv).backward(dout.float())
+    r = ref_in.grad.view(L, 3, 64)
+    for i in range(3):
+        assert (dqkv[:, i] - r[:, i]).abs().max().item() / r[:, i].abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("rows,D,group_out,skip", [(257 * 2, 384, 0, 0), (64, 128, 0, 0), (3 * 26, 768, 25, 1), (10, 1024, 0, 0)])
+def test_layernorm_backward(ops, rows, D, group_out, skip):
+    torch.manual_seed(rows)
+    x = torch.randn(rows, D, device="cuda") * 2 + 0.5
+    gamma = torch.randn(D, device="cuda")
+    beta = torch.randn(D, device="cuda")
+    rows_out = rows if group_out == 0 else rows // (group_out + skip) * group_out
+    gy = torch.randn(rows_out, D, device="cuda").to(BF)
+    xr = x.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (D,), gamma, beta, 1e-6)
+    if group_out:
+        y = y.view(-1, group_out + skip, D)[:, skip:].reshape(rows_out, D)
+    y.backward(gy.float())
+    gx, g16 = ops.layernorm_bwd(x, gy, gamma, 1e-6, group_out=group_out, skip=skip)
+    assert rel(gx, xr.grad) < 1e-4
+    assert rel(g16, xr.grad) < 1e-2
+    base = torch.randn_like(x)
+    acc, _ = ops.layernorm_bwd(x, gy, gamma, 1e-6, gx=base.clone(), group_out=group_out, skip=skip)
+    assert rel(acc, base + xr.grad) < 1e-4
+
+
+def test_gelu_save_and_dgelu_epilogues(ops):
+    torch.manual_seed(3)
+    M, K, N = 300, 128, 512
+    A = torch.randn(M, K, device="cuda").to(BF)
+    W = (torch.randn(N, K, device="cuda") / 8).to(BF)
+    b = torch.randn(N, device="cuda")
+    hid, pre = ops.linear_gelu_save(A, W, b)
+    assert torch.equal(hid, ops.linear(A, W, b, "gelu"))       # identical to the inference epilogue
+    assert torch.equal(pre, ops.linear(A, W, b, None))
+    G = torch.randn(M, K, device="cuda").to(BF)
+    out = ops.linear_mul_dgelu(G, W, pre)
+    p = pre.float().requires_grad_(True)
+    F.gelu(p).backward(G.float() @ W.float().t())
+    assert rel(out, p.grad) < 1e-2
+
+
+def test_logits_resize_backward(ops):
+    g = torch.randn(3, 1, 56, 70, device="cuda")
+    x = torch.randn(3, 1, 4, 5, device="cuda", requires_grad=True)
+    F.interpolate(x, (56, 70), mode="bilinear", align_corners=True).backward(g)
+    assert rel(ops.resize_bilinear_nchw_f32_bwd(g, 4, 5), x.grad) < 1e-5

@@ -1,5 +1,6 @@
-"""GPU: gradients of the trainable tail (head + embed_coords, clicks injected after the backbone)
-through the HIP backward kernels against torch autograd on the CPU oracle; one trainer step."""
+"""GPU: gradients of the trainable parameters (head + embed_coords) through the HIP backward kernels
+against torch autograd on the CPU oracle -- clicks injected after the backbone (trainable tail only)
+and before it (the reference's default: activation gradients through the frozen ViT); one trainer step."""
 import numpy as np
 import pytest
 import torch
@@ -9,8 +10,8 @@ from helpers import build_model, rand_points, seeded_
 pytestmark = pytest.mark.gpu
 
 
-def _setup():
-    model = build_model("bilinear", injection="after_backbone")
+def _setup(upsampler="bilinear", injection="after_backbone"):
+    model = build_model(upsampler, injection=injection)
     seeded_(model, 9)
     torch.manual_seed(2)
     image = torch.rand(2, 4, 56, 56)
@@ -54,8 +55,52 @@ def test_gradients_vs_oracle_autograd():
     assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
 
 
-def test_before_backbone_training_is_refused():
-    model = build_model("bilinear", injection="before_backbone").cuda().train()
+@pytest.mark.parametrize("upsampler", ["bilinear", "identity"])
+def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
+    """The reference's default training mode (models/sbd/dinov2/patch-embed_*.py:40): the click
+    patch-embedding gets its gradient through both frozen ViT blocks (attention, LayerNorm, GELU
+    backward kernels) -- compared with autograd of the fp32 CPU oracle."""
+    from oracle import model as omodel
+    model, image, points = _setup(upsampler, "before_backbone")
+    w = {k: v.clone() for k, v in model.state_dict().items()}
+    train_keys = [k for k in w if k.startswith(("head.", "embed_coords."))]
+    for k in train_keys:
+        w[k].requires_grad_(True)
+    cfg = dict(patch=14, depth=2, heads=2, upsampler=upsampler, injection="before_backbone",
+               with_prev_mask=True, use_disks=True, norm_radius=5)
+    coef = torch.randn(2, 1, 56, 56)
+    ref_out = omodel.forward_with_grad(image, points, w, cfg)
+    (ref_out * coef).sum().backward()
+    model = model.cuda().train()
+    out = model(image.cuda(), points.cuda())["instances"]
+    assert out.requires_grad
+    # the training forward (statistics saved) computes the same logits as the inference path
+    with torch.no_grad():
+        assert (model(image.cuda(), points.cuda())["instances"] - out).abs().max().item() < 2e-2
+    assert (out.detach().cpu() - ref_out.detach()).abs().max().item() < 2e-2 * (1 + ref_out.abs().max().item())
+    (out * coef.cuda()).sum().backward()
+    named = dict(model.named_parameters())
+    worst = {}
+    for k in train_keys:
+        g, ref = named[k].grad.cpu(), w[k].grad
+        rms = (g - ref).pow(2).mean().sqrt().item() / (ref.pow(2).mean().sqrt().item() + 1e-12)
+        cos = torch.nn.functional.cosine_similarity(g.flatten(), ref.flatten(), dim=0).item()
+        print(f"{upsampler} {k:32s} rms-rel {rms:.3e}  cos {cos:.6f}")
+        worst[k] = (rms, cos)
+    # same bf16 / ReLU-mask argument as above; the embed_coords gradient additionally crosses two
+    # attention + MLP blocks in bf16
+    assert all(c > 0.99 for _, c in worst.values()), worst
+    assert all(r < 0.15 for r, _ in worst.values()), worst
+    assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
+
+
+@pytest.mark.parametrize("upsampler,params", [
+    ("lift", {"lift_path": None, "n_dim": 128, "patch": 14}),
+    ("loftup", {"upsampler_path": None, "n_dim": 128}),
+    ("jbu_featup", {"backbone_type": "dinov2", "feat_dim": 128})])
+def test_before_backbone_training_through_learned_upsamplers_is_refused(upsampler, params):
+    """No backward exists for the learned upsamplers: asking for it must raise, not return zeros."""
+    model = build_model(upsampler, injection="before_backbone", upsampler_params=params).cuda().train()
     image, points = torch.rand(1, 4, 56, 56).cuda(), torch.tensor([[[5., 5., 0.], [-1., -1., -1.]]]).cuda()
     with pytest.raises(NotImplementedError):
         model(image, points)
