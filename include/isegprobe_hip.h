@@ -128,7 +128,7 @@ int isp_attention_fwd_lse(const void* Q, const void* K, const void* V, void* O, 
                           long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
                           float scale, void* stream);
 
-/* ---- Backward of isp_attention_fwd (head_dim 64): dQ, dK, dV (bf16, strides of Q / of K,V) from O, dO (strides
+/* ---- Backward of isp_attention_fwd (head_dim 64 or 128): dQ (nullable: skipped), dK, dV (bf16, strides of Q / of K,V) from O, dO (strides
  * o_stride_*) and lse.  delta is a [B*H, stat_ld] fp32 workspace (rowsum(dO*O)); stat_ld % 64 == 0 is the row
  * stride of BOTH lse and delta.  What autograd does for Attention.forward (dinov2/layers/attention.py:54-71) when the
  * reference trains with feats_injection_mode="before_backbone" (models/sbd/dinov2/patch-embed_*.py:40); the
@@ -138,12 +138,15 @@ int isp_attention_bwd(const void* Q, const void* K, const void* V, const void* O
                       long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
                       long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
 
-/* ---- LayerNorm backward w.r.t. the input (frozen affine): gx (fp32 [rows,D]) (+)= dLN(x; gamma)(gy), statistics
- * recomputed from x (fp32 [rows,D]); gy bf16 [rows_out,D]; optional bf16 copy of the updated gx.  group_out/skip as
- * in isp_layernorm_fwd (rows = input rows; dropped rows get zero gradient).  Autograd of nn.LayerNorm in
- * dinov2/layers/block.py:92-117 and DINOv2.py:533. */
-int isp_layernorm_bwd(const float* x, const void* gy, const float* gamma, float* gx, void* gx_bf16, long rows, int D,
-                      float eps, int group_out, int skip, int accumulate, void* stream);
+/* ---- LayerNorm backward w.r.t. the input (frozen affine): gx (fp32, row stride ld_gx) (+)= dLN(x; gamma)(gy),
+ * statistics recomputed from x (fp32 or bf16, row stride ld_x, first D columns); gy bf16 (row stride ld_gy); optional
+ * bf16 copy of the updated gx (row stride ld_g16).  Row strides 0 = D; padding columns [D, ld) of gx (when not
+ * accumulating) and of the bf16 copy are zero-filled.  group_out/skip as in isp_layernorm_fwd (rows = input rows;
+ * dropped rows get zero gradient).  Autograd of nn.LayerNorm in dinov2/layers/block.py:92-117, DINOv2.py:533 and of
+ * the LayerNorm/ChannelNorm layers of loftup/layers.py:26-58. */
+int isp_layernorm_bwd(const void* x, int x_dtype, long ld_x, const void* gy, long ld_gy, const float* gamma, float* gx,
+                      long ld_gx, void* gx_bf16, long ld_g16, long rows, int D, float eps, int group_out, int skip,
+                      int accumulate, void* stream);
 
 /* ---- Adjoint of isp_resize_bilinear_ac_nchw_f32 for planar fp32 maps: din [planes,h,w] = R^T dout [planes,H,W].
  * The logits resize of iseg_base_model.py:75-80 under autograd (identity / LiFT-sized upsampler outputs). */
@@ -220,8 +223,9 @@ int isp_fuse_flip_sigmoid(const float* logits, float* probs, long n, int H, int 
 int isp_tn_gemm_bf16_atomic(const void* P, long ldp, const void* Q, long ldq, float* out, long ldo, long M, int N, int J,
                             int shift_H, int shift_W, int shift_dy, int shift_dx, int splits, void* stream);
 int isp_relu_mask_colsum(const void* dy, const void* y, void* g, float* colsum, long M, int N, void* stream);
-int isp_classifier_bwd(const float* grad_logits, const void* x, const float* w, void* dx, float* dw, float* db, long M,
-                       int C, void* stream);
+/* dx_colsum (nullable, [C], caller-zeroed): += column sums of dx = bias gradient of the conv that produced x */
+int isp_classifier_bwd(const float* grad_logits, const void* x, const float* w, void* dx, float* dw, float* db,
+                       float* dx_colsum, long M, int C, void* stream);
 int isp_resize_bilinear_ac_nhwc_bwd(const void* dout, void* din, int B, int h, int w, int H, int W, int C, void* stream);
 
 /* ---- layout converters between the plugin API (NCHW f32) and the kernels (NHWC bf16).

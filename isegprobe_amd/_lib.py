@@ -56,7 +56,7 @@ SIGNATURES = {
     "isp_attention_fwd_lse": [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
     "isp_attention_bwd": [_vp] * 7 + [_l] + [_vp] * 3 + [_i] * 5 + [_l] * 9 + [_f, _vp],
     "isp_resize_bilinear_ac_nchw_f32_bwd": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
-    "isp_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _vp],
+    "isp_layernorm_bwd": [_vp, _i, _l, _vp, _l, _vp, _vp, _l, _vp, _l, _l, _i, _f, _i, _i, _i, _vp],
     "isp_resize_bilinear_ac_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_resize_bilinear_ac_nchw_f32": [_vp, _vp, _l, _i, _i, _i, _i, _l, _vp],
     "isp_resize_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -72,7 +72,7 @@ SIGNATURES = {
     "isp_adaptive_max_pool_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_tn_gemm_bf16_atomic": [_vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _i, _vp],
     "isp_relu_mask_colsum": [_vp, _vp, _vp, _vp, _l, _i, _vp],
-    "isp_classifier_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp],
+    "isp_classifier_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp],
     "isp_resize_bilinear_ac_nhwc_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_classifier_fwd": [_vp, _vp, _f, _vp, _l, _i, _vp],
     "isp_nhwc_bf16_to_nchw_f32": [_vp, _vp, _i, _i, _l, _vp],

@@ -33,19 +33,48 @@ class Conv3x3ReluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, y, weight = ctx.saved_tensors
-        B, H, W, C = x.shape
-        N = weight.shape[0]
-        M = B * H * W
         g, db = ops.relu_mask_colsum(gy.contiguous(), y)
-        dw = torch.zeros(N, 9 * C, device=x.device, dtype=torch.float32)
-        for t in range(9):  # one pixel-reduction GEMM per tap, implicit im2col of x
-            ops.tn_gemm_atomic(g.view(M, N), x.view(M, C), dw[:, t * C:(t + 1) * C], shift=(H, W, t // 3 - 1, t % 3 - 1))
-        dweight = dw.view(N, 3, 3, C).permute(0, 3, 1, 2).contiguous()
-        dx = None
-        if ctx.needs_input_grad[0]:  # data gradient = the same conv kernel with rotated, transposed weights
-            w_rot = weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * N).to(BF16).contiguous()
-            dx = ops.conv3x3(g, w_rot, None, None)
+        dx, dweight = _conv3x3_grads(x, g, weight, ctx.needs_input_grad[0])
         return dx, dweight, db
+
+
+def _conv3x3_grads(x, g, weight, need_dx):
+    """Weight (and optionally data) gradient of a 3x3 conv given the pre-activation gradient g."""
+    B, H, W, C = x.shape
+    N = weight.shape[0]
+    M = B * H * W
+    dw = torch.zeros(N, 9 * C, device=x.device, dtype=torch.float32)
+    for t in range(9):  # one pixel-reduction GEMM per tap, implicit im2col of x
+        ops.tn_gemm_atomic(g.view(M, N), x.view(M, C), dw[:, t * C:(t + 1) * C], shift=(H, W, t // 3 - 1, t % 3 - 1))
+    dweight = dw.view(N, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+    dx = None
+    if need_dx:  # data gradient = the same conv kernel with rotated, transposed weights
+        w_rot = weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * N).to(BF16).contiguous()
+        dx = ops.conv3x3(g, w_rot, None, None)
+    return dx, dweight
+
+
+class Conv3x3ReluClassifierFn(torch.autograd.Function):
+    """Last 3x3 conv + ReLU + 1x1 classifier of ConvSegHead (conv_heads.py:69-73) as one node: the
+    classifier backward produces the conv's pre-activation gradient already ReLU-masked together with
+    its column sums (the conv's bias gradient), so no separate mask pass runs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cls_weight, cls_bias):
+        y = ops.conv3x3(x, _pack_conv(weight), bias.detach().float().contiguous(), "relu")
+        B, H, W, _ = y.shape
+        wc = cls_weight.detach().float().reshape(-1).contiguous()
+        out = ops.classifier(y, wc, float(cls_bias.detach().float().item())).view(B, 1, H, W)
+        ctx.save_for_backward(x, y, weight, cls_weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, gl):
+        x, y, weight, cls_weight = ctx.saved_tensors
+        wc = cls_weight.detach().float().reshape(-1).contiguous()
+        g, dwc, dbc, db = ops.classifier_bwd(gl.float().reshape(-1), y, wc, want_dx_colsum=True)
+        dx, dweight = _conv3x3_grads(x, g, weight, ctx.needs_input_grad[0])
+        return dx, dweight, db, dwc.view_as(cls_weight), dbc.view(1)
 
 
 class Conv1x1ReluFn(torch.autograd.Function):

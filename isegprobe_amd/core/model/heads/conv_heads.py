@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .... import hip_ops as ops
-from .._autograd import ClassifierFn, Conv1x1ReluFn, Conv3x3ReluFn, grad_mode
+from .._autograd import ClassifierFn, Conv1x1ReluFn, Conv3x3ReluClassifierFn, Conv3x3ReluFn, grad_mode
 from .._tensor import BF16, PackedCache, to_nhwc_bf16
 from .base_head import BaseClassifierHead
 
@@ -76,6 +76,11 @@ class _StackedHead(BaseClassifierHead):
             wc, bc = self._cls_weights()
             B, H, W, _ = y.shape
             return ops.conv3x3_relu_classifier(y, w, b, wc, bc).view(B, 1, H, W)
+        if training and layers and layers[-1].conv.kernel_size == (3, 3) and self.num_classes == 1:
+            for layer in layers[:-1]:
+                y = layer.run(y)
+            last = layers[-1].conv  # last conv + classifier as one autograd node (no separate ReLU-mask pass)
+            return Conv3x3ReluClassifierFn.apply(y, last.weight, last.bias, self.classifier.weight, self.classifier.bias)
         for layer in layers:
             y = layer.run(y)
         return self._classify(y)

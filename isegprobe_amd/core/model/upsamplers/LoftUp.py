@@ -227,9 +227,16 @@ class LoftUpUpsampler(BaseUpsampler):
         return self._pe_cache[key]
 
     def forward(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
-        self._refuse_source_grad(source)
-        P = self.packed()
         src = to_nhwc_bf16(source)
+        if torch.is_grad_enabled() and src.requires_grad:
+            # training with clicks injected before the upsampler (the reference's default): activation
+            # gradients w.r.t. the LR features flow back through the K/V side of both cross-attention layers
+            return nchw_view(_LoftUpFn.apply(src, guidance, self))
+        return nchw_view(self._run(src, guidance, None))
+
+    def _run(self, src, guidance, save):
+        """The whole upsampler on NHWC bf16 LR features; `save` (a dict) collects what the backward needs."""
+        P = self.packed()
         B, h, w, C = src.shape
         guidance = guidance.float().contiguous()
         H, W = guidance.shape[2:]
@@ -247,19 +254,89 @@ class LoftUpUpsampler(BaseUpsampler):
         x = ops.conv3x3(x, P["conv1_w"], P["conv1_b"], "relu")
         x = ops.conv3x3(x, P["conv2_w"], P["conv2_b"], "relu").view(M, cp)
         scale = P["hd"] ** -0.5
+        if save is not None:
+            save.update(kv=kv, layers=[], geom=(B, h, w, C, H, W))
         for L in P["layers"]:
             qn = ops.layernorm(x, L["nq_w"], L["nq_b"], L["nq_eps"], D=c, ld_out=cp)
             kn = ops.layernorm(kv, L["nkv_w"], L["nkv_b"], L["nkv_eps"], D=c, ld_out=cp)
             q = ops.linear(qn, L["wq"], L["bq"]).view(B, H * W, heads, hdp)
             k = ops.linear(kn, L["wk"], L["bk"]).view(B, T, heads, hdp)
             v = ops.linear(kn, L["wv"], L["bv"]).view(B, T, heads, hdp)
-            a = ops.attention(q, k, v, scale).view(M, heads * hdp)
-            x = ops.linear_axpy_res(a, L["wo"], L["bo"], x, 1.0)            # cross-attention + residual
-            f = ops.layernorm(x, L["ff_nw"], L["ff_nb"], L["ff_eps"], D=c, ld_out=cp)
-            f = ops.linear(f, L["ff1_w"], L["ff1_b"], "gelu")
-            x = ops.linear_axpy_res(f, L["ff2_w"], L["ff2_b"], x, 1.0)      # feed-forward + residual
-        x = ops.layernorm(x, P["tn_w"], P["tn_b"], P["tn_eps"], D=c, ld_out=cp)
-        y = ops.linear(x, P["fin_w"], P["fin_b"])                            # 1x1 conv c -> C
-        Cp = y.shape[1]
+            if save is None:
+                a = ops.attention(q, k, v, scale).view(M, heads * hdp)
+            else:
+                a, lse = ops.attention_lse(q, k, v, scale)
+                a = a.view(M, heads * hdp)
+            x_mid = ops.linear_axpy_res(a, L["wo"], L["bo"], x, 1.0)        # cross-attention + residual
+            f = ops.layernorm(x_mid, L["ff_nw"], L["ff_nb"], L["ff_eps"], D=c, ld_out=cp)
+            if save is None:
+                f = ops.linear(f, L["ff1_w"], L["ff1_b"], "gelu")
+            else:
+                f, pre = ops.linear_gelu_save(f, L["ff1_w"], L["ff1_b"])
+                save["layers"].append(dict(x_in=x, q=q, k=k, v=v, a=a, lse=lse, x_mid=x_mid, pre=pre))
+            x = ops.linear_axpy_res(f, L["ff2_w"], L["ff2_b"], x_mid, 1.0)  # feed-forward + residual
+        xn = ops.layernorm(x, P["tn_w"], P["tn_b"], P["tn_eps"], D=c, ld_out=cp)
+        y = ops.linear(xn, P["fin_w"], P["fin_b"])                           # 1x1 conv c -> C
         out = ops.layernorm(y, P["fln_w"], P["fln_b"], P["fln_eps"], D=C, ld_out=C)  # channel LayerNorm
-        return nchw_view(out.view(B, H, W, C))
+        if save is not None:
+            save.update(x_fin=x, y=y)
+        return out.view(B, H, W, C)
+
+    def _bwd_weights(self):
+        """Transposed (data-gradient) copies of the frozen projection weights, cached with the packed set."""
+        P = self.packed()
+        if "bwd" not in P:
+            t = lambda w: w.float().t().contiguous().to(BF16)
+            P["bwd"] = dict(fin=t(P["fin_w"]),
+                            layers=[dict(ff2=t(L["ff2_w"]), ff1=t(L["ff1_w"]), wo=t(L["wo"]), wq=t(L["wq"]), wk=t(L["wk"]),
+                                         wv=t(L["wv"])) for L in P["layers"]])
+        return P["bwd"]
+
+    def _backward(self, src, saved, g_out):
+        """d out / d src applied to g_out [B,H,W,C] bf16 (all weights frozen).  Mirrors loftup.py:100-138 under
+        autograd: channel-LN -> 1x1 conv -> LN -> 2 x [FF, cross-attention (dK, dV; dQ only where the queries depend
+        on the LR features, i.e. not in the first layer)] -> K/V LayerNorm -> ChannelNorm of the source."""
+        P, Wt = self.packed(), self._bwd_weights()
+        B, h, w, C, H, W = saved["geom"]
+        c, cp, heads, hdp = P["c"], P["cp"], P["heads"], P["hdp"]
+        M, T = B * H * W, h * w
+        scale = P["hd"] ** -0.5
+        _, gy16 = ops.layernorm_bwd(saved["y"], g_out.reshape(M, C).contiguous(), P["fln_w"], P["fln_eps"], D=C)
+        g_xt = ops.linear(gy16, Wt["fin"])
+        gx, gx16 = ops.layernorm_bwd(saved["x_fin"], g_xt, P["tn_w"], P["tn_eps"], D=c)
+        gkv = gkv16 = None
+        n = len(P["layers"])
+        for i in range(n - 1, -1, -1):
+            L, Wl, S = P["layers"][i], Wt["layers"][i], saved["layers"][i]
+            g_pre = ops.linear_mul_dgelu(gx16, Wl["ff2"], S["pre"])
+            g_f = ops.linear(g_pre, Wl["ff1"])
+            gx, gx16 = ops.layernorm_bwd(S["x_mid"], g_f, L["ff_nw"], L["ff_eps"], gx=gx, D=c)
+            g_a = ops.linear(gx16, Wl["wo"]).view(B, H * W, heads, hdp)
+            dq, dk, dv = ops.attention_bwd(S["q"], S["k"], S["v"], S["a"].view(B, H * W, heads, hdp), g_a, S["lse"],
+                                           scale, want_dq=i > 0)
+            g_kn = ops.linear(dk.view(B * T, heads * hdp), Wl["wk"])
+            g_kn = ops.linear_axpy_res(dv.view(B * T, heads * hdp), Wl["wv"], None, g_kn, 1.0)
+            gkv, gkv16 = ops.layernorm_bwd(saved["kv"], g_kn, L["nkv_w"], L["nkv_eps"], gx=gkv, D=c, want_bf16=i == 0)
+            if i > 0:  # the first layer's queries come from the image only
+                g_qn = ops.linear(dq.view(M, heads * hdp), Wl["wq"])
+                gx, gx16 = ops.layernorm_bwd(S["x_in"], g_qn, L["nq_w"], L["nq_eps"], gx=gx, D=c)
+        _, g_src = ops.layernorm_bwd(src.reshape(B * T, C), gkv16[:, :C], P["cn_w"], P["cn_eps"], D=C)
+        return g_src.view(B, h, w, C)
+
+
+class _LoftUpFn(torch.autograd.Function):
+    """LoftUpUpsampler as one autograd node: gradient w.r.t. the LR features only (frozen weights, guidance
+    carries no gradient)."""
+
+    @staticmethod
+    def forward(ctx, src, guidance, module):
+        saved = {}
+        out = module._run(src.detach(), guidance.detach(), saved)
+        ctx.module, ctx.saved, ctx.src = module, saved, src.detach()
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        g = ctx.module._backward(ctx.src, ctx.saved, g_out.contiguous())
+        ctx.saved = None
+        return g, None, None

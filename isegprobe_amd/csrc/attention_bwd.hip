@@ -1,4 +1,4 @@
-// Backward of softmax(Q K^T * scale) V for head_dim 64 on gfx950 (bf16 MFMA, fp32 accumulate):
+// Backward of softmax(Q K^T * scale) V for head_dim 64 and 128 on gfx950 (bf16 MFMA, fp32 accumulate):
 // dQ, dK, dV from Q, K, V, O, dO and the forward's log-sum-exp; the [Lq, Lk] probability matrix
 // is recomputed tile by tile and never stored.
 //
@@ -25,18 +25,33 @@
 namespace {
 
 constexpr int TB = 64;  // owner rows per block, streamed rows per tile
-constexpr int HD = 64;
-constexpr int TILE = TB * HD * 2;  // 8 KiB
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 __device__ __forceinline__ s16x4 tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((ISP_LDS s16x4*)p);
 }
-__device__ __forceinline__ int rswz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }         // ds_read_b128 image
-__device__ __forceinline__ int tswz(int row, int chunk) { return chunk ^ (((row >> 1) & 3) << 1); }  // tr-read image
+template <int HD>
+struct BGeo {
+    static constexpr int ROW = HD * 2;            // bytes per row (128 or 256)
+    static constexpr int CHUNKS = ROW / 16;       // 16-byte chunks per row
+    static constexpr int TILE = TB * ROW;         // one streamed tile image
+    static constexpr int ROWS_PER_PIECE = 1024 / ROW;
+    static constexpr int PIECES = TILE / 1024;    // 1 KiB DMA pieces per image (8 or 16)
+    static constexpr int KK = HD / 32;            // k-steps of the score products
+    static constexpr int DT = HD / 16;            // 16-wide column tiles of the outputs
+    // ds_read_b128 image: 128-B rows share a bank row in pairs, 256-B rows all start on bank 0
+    __device__ static __forceinline__ int rswz(int row, int chunk) {
+        return HD == 64 ? chunk ^ ((row >> 1) & 7) : chunk ^ (row & 15);
+    }
+    // tr-read image: a half-wave touches 8 rows x 32 B; spread the 32-B pair index over the rows
+    __device__ static __forceinline__ int tswz(int row, int chunk) {
+        return HD == 64 ? chunk ^ (((row >> 1) & 3) << 1) : chunk ^ ((row & 7) << 1);
+    }
+};
 
 // delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+template <int HD>
 __global__ void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, float* __restrict__ delta,
                                   int H, int Lq, long osb, long osl, long osh, long ld) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,12 +78,14 @@ struct Side {  // one side of the attention (queries or keys): two row-major [L,
 
 // OWN_KEYS: owner side = keys (outputs dK = out1 with m-stream Q, dV = out2 with stream dO);
 // otherwise owner side = queries (output dQ = out1 with stream K).
-template <bool OWN_KEYS>
+template <int HD, bool OWN_KEYS>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const float* __restrict__ lse,
                                                        const float* __restrict__ delta, long ld_stat,
                                                        bf16_t* __restrict__ out1, bf16_t* __restrict__ out2, long ob,
                                                        long ol, long oh, int H, float scale, float c) {
     // LDS per stage: [stream1 rows][stream2 rows][stream1 tr]([stream2 tr] when OWN_KEYS)
+    using G = BGeo<HD>;
+    constexpr int TILE = G::TILE, KK = G::KK, DT = G::DT;
     constexpr int NT_IMG = OWN_KEYS ? 4 : 3;
     constexpr int STAGE = NT_IMG * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,9 +99,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
     const int orow_c = orow < own.L ? orow : own.L - 1;
     const bf16_t* o1 = own.m1 + (size_t)b * own.sb1 + (size_t)orow_c * own.sl1 + (size_t)h * own.sh1 + 8 * fq;
     const bf16_t* o2 = own.m2 + (size_t)b * own.sb2 + (size_t)orow_c * own.sl2 + (size_t)h * own.sh2 + 8 * fq;
-    bf16x8 own1[2], own2[2];
+    bf16x8 own1[KK], own2[KK];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < KK; ++kk) {
         own1[kk] = *reinterpret_cast<const bf16x8*>(o1 + 32 * kk);
         own2[kk] = *reinterpret_cast<const bf16x8*>(o2 + 32 * kk);
     }
@@ -95,42 +112,42 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
         delta_o = delta[stat_row + orow_c];
     }
 
-    // ---- DMA: a tile image = 8 pieces of 1 KiB (8 rows x 128 B); wave w takes pieces w and w+4
+    // ---- DMA: a tile image = PIECES pieces of 1 KiB (1024/ROW rows each); wave w takes pieces w, w+4, ...
     const bf16_t* s1 = str.m1 + (size_t)b * str.sb1 + (size_t)h * str.sh1;
     const bf16_t* s2 = str.m2 + (size_t)b * str.sb2 + (size_t)h * str.sh2;
     auto stage = [&](int tile, char* buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < G::PIECES / 4; ++i) {
             const int piece = wid + 4 * i;
-            const int row = piece * 8 + (lane >> 3), pch = lane & 7;
+            const int row = piece * G::ROWS_PER_PIECE + lane / G::CHUNKS, pch = lane % G::CHUNKS;
             int g = tile * TB + row;
             g = g < str.L ? g : str.L - 1;
             const bf16_t* r1 = s1 + (size_t)g * str.sl1;
             const bf16_t* r2 = s2 + (size_t)g * str.sl2;
-            glds16(r1 + rswz(row, pch) * 8, buf + piece * 1024);
-            glds16(r2 + rswz(row, pch) * 8, buf + TILE + piece * 1024);
-            glds16(r1 + tswz(row, pch) * 8, buf + 2 * TILE + piece * 1024);
-            if (OWN_KEYS) glds16(r2 + tswz(row, pch) * 8, buf + 3 * TILE + piece * 1024);
+            glds16(r1 + G::rswz(row, pch) * 8, buf + piece * 1024);
+            glds16(r2 + G::rswz(row, pch) * 8, buf + TILE + piece * 1024);
+            glds16(r1 + G::tswz(row, pch) * 8, buf + 2 * TILE + piece * 1024);
+            if (OWN_KEYS) glds16(r2 + G::tswz(row, pch) * 8, buf + 3 * TILE + piece * 1024);
         }
     };
 
     // ---- fragment offsets.  Row image: row 16mi + fr, logical chunk 4kk + fq (swizzle term depends on fr only).
-    int r_off[2];
+    int r_off[KK];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) r_off[kk] = fr * 128 + (rswz(fr, 4 * kk + fq) << 4);
+    for (int kk = 0; kk < KK; ++kk) r_off[kk] = fr * G::ROW + (G::rswz(fr, 4 * kk + fq) << 4);
     // Transposed image: lane i = 4q+p of 16-lane group fq addresses row 16mi + 4fq + q, columns 16dt + 4p .. +3;
     // the hardware hands lane fr column 16dt + fr of rows 4fq .. 4fq+3 (A operand of the 16x16x16 product).
-    int t_off[4];
+    int t_off[DT];
     {
         const int row = 4 * fq + (fr >> 2), colb = 8 * (fr & 3);  // byte offset of the 4 columns within 32 B
-        const int sw = ((row >> 1) & 3) << 1;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) t_off[dt] = row * 128 + (((2 * dt + (colb >> 4)) ^ sw) << 4) + (colb & 15);
+        for (int dt = 0; dt < DT; ++dt)
+            t_off[dt] = row * G::ROW + (G::tswz(row, 2 * dt + (colb >> 4)) << 4) + (colb & 15);
     }
 
-    f32x4 acc1[4], acc2[4];  // out^T tiles: [dt] -> rows d = 16dt + 4fq + r, column o = fr
+    f32x4 acc1[DT], acc2[DT];  // out^T tiles: [dt] -> rows d = 16dt + 4fq + r, column o = fr
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc1[i] = acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < DT; ++i) acc1[i] = acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = (str.L + TB - 1) / TB;
     stage(0, smem);
@@ -144,9 +161,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
         for (int mi = 0; mi < 4; ++mi) {
             x1[mi] = x2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(buf + mi * 2048 + r_off[kk]);
-                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(buf + TILE + mi * 2048 + r_off[kk]);
+            for (int kk = 0; kk < KK; ++kk) {
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(buf + mi * 16 * G::ROW + r_off[kk]);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(buf + TILE + mi * 16 * G::ROW + r_off[kk]);
                 x1[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, own1[kk], x1[mi], 0, 0, 0);
                 x2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, own2[kk], x2[mi], 0, 0, 0);
             }
@@ -179,11 +196,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
             const s16x4 ds = {(short)f2bf(x2[mi][0]), (short)f2bf(x2[mi][1]), (short)f2bf(x2[mi][2]), (short)f2bf(x2[mi][3])};
             const s16x4 pp = {(short)f2bf(x1[mi][0]), (short)f2bf(x1[mi][1]), (short)f2bf(x1[mi][2]), (short)f2bf(x1[mi][3])};
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const s16x4 a1 = tr_read(buf + 2 * TILE + mi * 2048 + t_off[dt]);
+            for (int dt = 0; dt < DT; ++dt) {
+                const s16x4 a1 = tr_read(buf + 2 * TILE + mi * 16 * G::ROW + t_off[dt]);
                 acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, ds, acc1[dt], 0, 0, 0);
                 if (OWN_KEYS) {
-                    const s16x4 a2 = tr_read(buf + 3 * TILE + mi * 2048 + t_off[dt]);
+                    const s16x4 a2 = tr_read(buf + 3 * TILE + mi * 16 * G::ROW + t_off[dt]);
                     acc2[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, pp, acc2[dt], 0, 0, 0);
                 }
             }
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
     if (orow < own.L) {
         const size_t off = (size_t)b * ob + (size_t)orow * ol + (size_t)h * oh + 4 * fq;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             *reinterpret_cast<uint2*>(out1 + off + 16 * dt) =
                 make_uint2(pack2bf(acc1[dt][0], acc1[dt][1]), pack2bf(acc1[dt][2], acc1[dt][3]));
             if (OWN_KEYS)
@@ -204,12 +221,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
     }
 }
 
-template <bool OWN_KEYS>
+template <int HD, bool OWN_KEYS>
 int launch_bwd(const Side& own, const Side& str, const float* lse, const float* delta, long ld, void* out1, void* out2,
                long ob, long ol, long oh, int B, int H, float scale, hipStream_t s) {
-    constexpr int lds = 2 * (OWN_KEYS ? 4 : 3) * TILE;
+    constexpr int lds = 2 * (OWN_KEYS ? 4 : 3) * BGeo<HD>::TILE;
     static bool attr_done = false;
-    auto kern = attn_bwd_kernel<OWN_KEYS>;
+    auto kern = attn_bwd_kernel<HD, OWN_KEYS>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return ISP_ERR_LAUNCH;
@@ -223,27 +240,43 @@ int launch_bwd(const Side& own, const Side& str, const float* lse, const float* 
 
 }  // namespace
 
+template <int HD>
+int attention_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                       float* delta, long stat_ld, void* dQ, void* dK, void* dV, int B, int H, int Lq, int Lk, long q_stride_b,
+                       long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l, long kv_stride_h,
+                       long o_stride_b, long o_stride_l, long o_stride_h, float scale, hipStream_t s) {
+    attn_delta_kernel<HD><<<dim3((Lq + 255) / 256, B * H), 256, 0, s>>>((const bf16_t*)O, (const bf16_t*)dO, delta, H, Lq,
+                                                                        o_stride_b, o_stride_l, o_stride_h, stat_ld);
+    if (int rc = isp_launch_status()) return rc;
+    const Side qs{(const bf16_t*)Q, (const bf16_t*)dO, q_stride_b, q_stride_l, q_stride_h, o_stride_b, o_stride_l, o_stride_h, Lq};
+    const Side ks{(const bf16_t*)K, (const bf16_t*)V, kv_stride_b, kv_stride_l, kv_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, Lk};
+    // dK (stream1 = Q with dS) and dV (stream2 = dO with P): gradients share the K/V strides
+    if (int rc = launch_bwd<HD, true>(ks, qs, lse, delta, stat_ld, dK, dV, kv_stride_b, kv_stride_l, kv_stride_h, B, H, scale, s))
+        return rc;
+    if (!dQ) return ISP_OK;  // caller does not need the query gradient (LoftUp's first layer: queries come from the image)
+    // dQ (stream1 = K with dS)
+    return launch_bwd<HD, false>(qs, ks, lse, delta, stat_ld, dQ, nullptr, q_stride_b, q_stride_l, q_stride_h, B, H, scale, s);
+}
+
 extern "C" int isp_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                                  const float* lse, float* delta, long stat_ld, void* dQ, void* dK, void* dV, int B, int H,
                                  int Lq, int Lk, int head_dim, long q_stride_b, long q_stride_l, long q_stride_h,
                                  long kv_stride_b, long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l,
                                  long o_stride_h, float scale, void* stream) {
-    ISP_CHECK_ARG(Q && K && V && O && dO && lse && delta && dQ && dK && dV);
+    ISP_CHECK_ARG(Q && K && V && O && dO && lse && delta && dK && dV);
     ISP_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0 && scale > 0.f && (long)B * H <= 65535);
-    if (head_dim != HD) return ISP_ERR_UNSUPPORTED;
     ISP_CHECK_ARG(stat_ld % TB == 0 && stat_ld >= Lq);  // statistics rows padded: float4 reads of a partial last tile
     ISP_CHECK_ARG(q_stride_b % 8 == 0 && q_stride_l % 8 == 0 && q_stride_h % 8 == 0);
     ISP_CHECK_ARG(kv_stride_b % 8 == 0 && kv_stride_l % 8 == 0 && kv_stride_h % 8 == 0);
     ISP_CHECK_ARG(o_stride_b % 8 == 0 && o_stride_l % 8 == 0 && o_stride_h % 8 == 0);
     hipStream_t s = (hipStream_t)stream;
-    attn_delta_kernel<<<dim3((Lq + 255) / 256, B * H), 256, 0, s>>>((const bf16_t*)O, (const bf16_t*)dO, delta, H, Lq,
-                                                                    o_stride_b, o_stride_l, o_stride_h, stat_ld);
-    if (int rc = isp_launch_status()) return rc;
-    const Side qs{(const bf16_t*)Q, (const bf16_t*)dO, q_stride_b, q_stride_l, q_stride_h, o_stride_b, o_stride_l, o_stride_h, Lq};
-    const Side ks{(const bf16_t*)K, (const bf16_t*)V, kv_stride_b, kv_stride_l, kv_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, Lk};
-    // dK (stream1 = Q with dS) and dV (stream2 = dO with P): gradients share the K/V strides
-    if (int rc = launch_bwd<true>(ks, qs, lse, delta, stat_ld, dK, dV, kv_stride_b, kv_stride_l, kv_stride_h, B, H, scale, s))
-        return rc;
-    // dQ (stream1 = K with dS)
-    return launch_bwd<false>(qs, ks, lse, delta, stat_ld, dQ, nullptr, q_stride_b, q_stride_l, q_stride_h, B, H, scale, s);
+    if (head_dim == 64)
+        return attention_bwd_impl<64>(Q, K, V, O, dO, lse, delta, stat_ld, dQ, dK, dV, B, H, Lq, Lk, q_stride_b, q_stride_l,
+                                      q_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h,
+                                      scale, s);
+    if (head_dim == 128)
+        return attention_bwd_impl<128>(Q, K, V, O, dO, lse, delta, stat_ld, dQ, dK, dV, B, H, Lq, Lk, q_stride_b, q_stride_l,
+                                       q_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h,
+                                       scale, s);
+    return ISP_ERR_UNSUPPORTED;
 }

@@ -161,69 +161,100 @@ __global__ __launch_bounds__(256, 2) void tn_gemm_kernel(const bf16_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------
-// g = dy * (y > 0) (bf16), colsum[n] += sum_m g[m][n].  Block = 64 rows x all columns.
+// Row-streaming elementwise kernels with per-column reductions.  A block of 256 threads covers
+// ROWS_PER_BLOCK rows x all N columns: thread -> (row slot = tid / (N/8), 8 columns = tid % (N/8)),
+// so every 16-byte access is coalesced along the row; per-column partial sums are combined in LDS and
+// leave the block as ONE atomicAdd per column.
+constexpr int ROWS_PER_BLOCK = 256;
+constexpr int RED_MAX_N = 2048;  // N/8 <= 256 threads
+
+template <int NSUM, class F>
+__device__ __forceinline__ void stream_rows_colsum(long M, int N, float* const (&sums)[NSUM], F&& body) {
+    __shared__ float red[NSUM][RED_MAX_N];
+    const int nc8 = N >> 3;
+    const int slots = 256 / nc8;  // row slots per pass
+    const int slot = threadIdx.x / nc8, c8 = threadIdx.x - slot * nc8;
+    for (int i = threadIdx.x; i < NSUM * RED_MAX_N; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    if (slot < slots) {
+        float s[NSUM][8];
+#pragma unroll
+        for (int k = 0; k < NSUM; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[k][e] = 0.f;
+        const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
+        const long r1 = r0 + ROWS_PER_BLOCK < M ? r0 + ROWS_PER_BLOCK : M;
+        for (long r = r0 + slot; r < r1; r += slots) body(r, c8, s);
+#pragma unroll
+        for (int k = 0; k < NSUM; ++k)
+            if (sums[k])
+#pragma unroll
+                for (int e = 0; e < 8; ++e) atomicAdd(&red[k][c8 * 8 + e], s[k][e]);  // LDS atomics
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k)
+        if (sums[k])
+            for (int n = threadIdx.x; n < N; n += 256) atomicAdd(sums[k] + n, red[k][n]);
+}
+
+// g = dy * (y > 0) (bf16), colsum[n] += sum_m g[m][n]
 __global__ __launch_bounds__(256) void relu_mask_colsum_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                                 bf16_t* __restrict__ g, float* __restrict__ colsum,
                                                                 long M, int N) {
-    const long r0 = (long)blockIdx.x * 64;
-    for (int c8 = threadIdx.x; c8 < N / 8; c8 += blockDim.x) {
-        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (long r = r0; r < r0 + 64 && r < M; ++r) {
-            const uint4 a = *reinterpret_cast<const uint4*>(dy + r * N + c8 * 8);
-            const uint4 b = *reinterpret_cast<const uint4*>(y + r * N + c8 * 8);
-            const unsigned* pa = &a.x;
-            const unsigned* pb = &b.x;
-            unsigned o[4];
+    float* const sums[1] = {colsum};
+    stream_rows_colsum<1>(M, N, sums, [&](long r, int c8, float (&s)[1][8]) {
+        const uint4 a = *reinterpret_cast<const uint4*>(dy + r * N + c8 * 8);
+        const uint4 b = *reinterpret_cast<const uint4*>(y + r * N + c8 * 8);
+        const unsigned* pa = &a.x;
+        const unsigned* pb = &b.x;
+        unsigned o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float ylo = __uint_as_float(pb[e] << 16), yhi = __uint_as_float(pb[e] & 0xffff0000u);
-                const unsigned lo = ylo > 0.f ? (pa[e] & 0xffffu) : 0u, hi = yhi > 0.f ? (pa[e] & 0xffff0000u) : 0u;
-                o[e] = lo | hi;
-                s[2 * e] += __uint_as_float(lo << 16);
-                s[2 * e + 1] += __uint_as_float(hi);
-            }
-            *reinterpret_cast<uint4*>(g + r * N + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int e = 0; e < 4; ++e) {
+            const float ylo = __uint_as_float(pb[e] << 16), yhi = __uint_as_float(pb[e] & 0xffff0000u);
+            const unsigned lo = ylo > 0.f ? (pa[e] & 0xffffu) : 0u, hi = yhi > 0.f ? (pa[e] & 0xffff0000u) : 0u;
+            o[e] = lo | hi;
+            s[0][2 * e] += __uint_as_float(lo << 16);
+            s[0][2 * e + 1] += __uint_as_float(hi);
         }
-        if (colsum) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(colsum + c8 * 8 + e, s[e]);
-        }
-    }
+        *reinterpret_cast<uint4*>(g + r * N + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    });
 }
 
 // ---------------------------------------------------------------------------------------
 // 1x1 classifier backward fused with the ReLU mask of its input x (post-ReLU conv output):
 //   dx[m][c] = x[m][c] > 0 ? g[m] * w[c] : 0     dw[c] += sum_m g[m] * x[m][c]     db += sum_m g[m]
+//   dxsum[c] += sum_m dx[m][c]   (optional: the bias gradient of the conv that produced x)
 __global__ __launch_bounds__(256) void classifier_bwd_kernel(const float* __restrict__ gl, const bf16_t* __restrict__ x,
                                                               const float* __restrict__ w, bf16_t* __restrict__ dx,
-                                                              float* __restrict__ dw, float* __restrict__ db, long M,
-                                                              int C) {
-    const long r0 = (long)blockIdx.x * 64;
-    for (int c8 = threadIdx.x; c8 < C / 8; c8 += blockDim.x) {
-        float wv[8], s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                                                              float* __restrict__ dw, float* __restrict__ db,
+                                                              float* __restrict__ dxsum, long M, int C) {
+    float* const sums[2] = {dw, dxsum};
+    stream_rows_colsum<2>(M, C, sums, [&](long r, int c8, float (&s)[2][8]) {
+        const float gm = gl[r];
+        const uint4 b = *reinterpret_cast<const uint4*>(x + r * C + c8 * 8);
+        const float4 w0 = *reinterpret_cast<const float4*>(w + c8 * 8), w1 = *reinterpret_cast<const float4*>(w + c8 * 8 + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const unsigned* pb = &b.x;
+        unsigned o[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) wv[e] = w[c8 * 8 + e];
-        for (long r = r0; r < r0 + 64 && r < M; ++r) {
-            const float gm = gl[r];
-            const uint4 b = *reinterpret_cast<const uint4*>(x + r * C + c8 * 8);
-            const unsigned* pb = &b.x;
-            unsigned o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xlo = __uint_as_float(pb[e] << 16), xhi = __uint_as_float(pb[e] & 0xffff0000u);
-                s[2 * e] += gm * xlo;
-                s[2 * e + 1] += gm * xhi;
-                o[e] = pack2bf(xlo > 0.f ? gm * wv[2 * e] : 0.f, xhi > 0.f ? gm * wv[2 * e + 1] : 0.f);
-            }
-            *reinterpret_cast<uint4*>(dx + r * C + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int e = 0; e < 4; ++e) {
+            const float xlo = __uint_as_float(pb[e] << 16), xhi = __uint_as_float(pb[e] & 0xffff0000u);
+            s[0][2 * e] += gm * xlo;
+            s[0][2 * e + 1] += gm * xhi;
+            o[e] = pack2bf(xlo > 0.f ? gm * wv[2 * e] : 0.f, xhi > 0.f ? gm * wv[2 * e + 1] : 0.f);
+            s[1][2 * e] += __uint_as_float(o[e] << 16);
+            s[1][2 * e + 1] += __uint_as_float(o[e] & 0xffff0000u);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(dw + c8 * 8 + e, s[e]);
-    }
-    if (threadIdx.x == 0) {
+        *reinterpret_cast<uint4*>(dx + r * C + c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    });
+    if (threadIdx.x < 64) {  // db: one wave sums the block's rows of gl
+        const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
         float sg = 0.f;
-        for (long r = r0; r < r0 + 64 && r < M; ++r) sg += gl[r];
-        atomicAdd(db, sg);
+        for (long r = r0 + threadIdx.x; r < r0 + ROWS_PER_BLOCK && r < M; r += 64) sg += gl[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sg += __shfl_xor(sg, o);
+        if (threadIdx.x == 0) atomicAdd(db, sg);
     }
 }
 
@@ -322,11 +353,12 @@ __global__ __launch_bounds__(256) void bilinear_bwd_planar_kernel(const float* _
 // accumulated (gx += dx) or overwritten; a bf16 copy of the updated row feeds the next GEMM.
 // With group_out > 0 the forward dropped `skip` leading rows of each (group_out+skip)-row group
 // (the cls token, DINOv2.py:533-534): those rows receive zero.
-template <int MAXV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ gy,
+template <typename TX, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict__ x, long ld_x,
+                                                             const bf16_t* __restrict__ gy, long ld_gy,
                                                              const float* __restrict__ gamma, float* __restrict__ gx,
-                                                             bf16_t* __restrict__ gx16, long rows, int D, float eps,
-                                                             int group_out, int skip, int accumulate) {
+                                                             long ld_gx, bf16_t* __restrict__ gx16, long ld_g16, long rows,
+                                                             int D, float eps, int group_out, int skip, int accumulate) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -338,7 +370,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         rg = grp * group_out + (idx - skip);
     }
     const int nchunk = D >> 2;
-    const float* xr = x + r * D;
+    const TX* xr = x + r * ld_x;
     float4 v[MAXV], g[MAXV];
     float sum = 0.f;
 #pragma unroll
@@ -346,10 +378,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const int c = lane + i * 64;
         v[i] = g[i] = make_float4(0, 0, 0, 0);
         if (c < nchunk) {
-            v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
+            if constexpr (sizeof(TX) == 4) {
+                v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
+            } else {
+                const uint2 u = *reinterpret_cast<const uint2*>(xr + c * 4);
+                v[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                                   __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+            }
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             if (has_g) {
-                const uint2 u = *reinterpret_cast<const uint2*>(gy + rg * D + c * 4);
+                const uint2 u = *reinterpret_cast<const uint2*>(gy + rg * ld_gy + c * 4);
                 const float4 gm = *reinterpret_cast<const float4*>(gamma + c * 4);
                 g[i] = make_float4(__uint_as_float(u.x << 16) * gm.x, __uint_as_float(u.x & 0xffff0000u) * gm.y,
                                    __uint_as_float(u.y << 16) * gm.z, __uint_as_float(u.y & 0xffff0000u) * gm.w);
@@ -384,19 +422,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         sgx += __shfl_xor(sgx, o);
     }
     const float mg = sg / (float)D, mgx = sgx / (float)D;
+    // padding columns [D, ld): zero (they feed zero weight rows of the next GEMM; garbage would be NaN * 0)
+    if (!accumulate)
+        for (int c = nchunk + lane; c < (int)(ld_gx >> 2); c += 64)
+            *reinterpret_cast<float4*>(gx + r * ld_gx + c * 4) = make_float4(0, 0, 0, 0);
+    if (gx16)
+        for (int c = nchunk + lane; c < (int)(ld_g16 >> 2); c += 64)
+            *reinterpret_cast<uint2*>(gx16 + r * ld_g16 + c * 4) = make_uint2(0, 0);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nchunk) {
             float4 d = make_float4(rstd * (g[i].x - mg - v[i].x * mgx), rstd * (g[i].y - mg - v[i].y * mgx),
                                    rstd * (g[i].z - mg - v[i].z * mgx), rstd * (g[i].w - mg - v[i].w * mgx));
-            float* gp = gx + r * D + c * 4;
+            float* gp = gx + r * ld_gx + c * 4;
             if (accumulate) {
                 const float4 old = *reinterpret_cast<const float4*>(gp);
                 d.x += old.x, d.y += old.y, d.z += old.z, d.w += old.w;
             }
             *reinterpret_cast<float4*>(gp) = d;
-            if (gx16) *reinterpret_cast<uint2*>(gx16 + r * D + c * 4) = make_uint2(pack2bf(d.x, d.y), pack2bf(d.z, d.w));
+            if (gx16) *reinterpret_cast<uint2*>(gx16 + r * ld_g16 + c * 4) = make_uint2(pack2bf(d.x, d.y), pack2bf(d.z, d.w));
         }
     }
 }
@@ -425,17 +470,18 @@ extern "C" int isp_tn_gemm_bf16_atomic(const void* P, long ldp, const void* Q, l
 }
 
 extern "C" int isp_relu_mask_colsum(const void* dy, const void* y, void* g, float* colsum, long M, int N, void* stream) {
-    ISP_CHECK_ARG(dy && y && g && M > 0 && N > 0 && N % 8 == 0);
-    relu_mask_colsum_kernel<<<(unsigned)((M + 63) / 64), 256, 0, (hipStream_t)stream>>>(
+    ISP_CHECK_ARG(dy && y && g && M > 0 && N > 0 && N % 8 == 0 && N <= RED_MAX_N);
+    relu_mask_colsum_kernel<<<(unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(
         (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)g, colsum, M, N);
     return isp_launch_status();
 }
 
 extern "C" int isp_classifier_bwd(const float* grad_logits, const void* x, const float* w, void* dx, float* dw,
-                                  float* db, long M, int C, void* stream) {
+                                  float* db, float* dx_colsum, long M, int C, void* stream) {
     ISP_CHECK_ARG(grad_logits && x && w && dx && dw && db && M > 0 && C > 0 && C % 8 == 0);
-    classifier_bwd_kernel<<<(unsigned)((M + 63) / 64), 256, 0, (hipStream_t)stream>>>(
-        grad_logits, (const bf16_t*)x, w, (bf16_t*)dx, dw, db, M, C);
+    ISP_CHECK_ARG(C <= RED_MAX_N);
+    classifier_bwd_kernel<<<(unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(
+        grad_logits, (const bf16_t*)x, w, (bf16_t*)dx, dw, db, dx_colsum, M, C);
     return isp_launch_status();
 }
 
@@ -450,22 +496,40 @@ extern "C" int isp_resize_bilinear_ac_nhwc_bwd(const void* dout, void* din, int 
     return isp_launch_status();
 }
 
-extern "C" int isp_layernorm_bwd(const float* x, const void* gy, const float* gamma, float* gx, void* gx_bf16, long rows,
-                                 int D, float eps, int group_out, int skip, int accumulate, void* stream) {
-    ISP_CHECK_ARG(x && gy && gamma && gx && rows > 0 && D > 0 && D % 4 == 0 && group_out >= 0 && skip >= 0);
-    ISP_CHECK_ARG(group_out == 0 || rows % (group_out + skip) == 0);
-    hipStream_t s = (hipStream_t)stream;
+template <typename TX>
+static int launch_ln_bwd(const void* x, long ld_x, const void* gy, long ld_gy, const float* gamma, float* gx, long ld_gx,
+                         void* g16, long ld_g16, long rows, int D, float eps, int group_out, int skip, int accumulate,
+                         hipStream_t s) {
     const int nchunk = D / 4;
     dim3 grid((unsigned)((rows + 3) / 4));
-#define LNB_CASE(MV)                                                                                                    \
-    layernorm_bwd_kernel<MV><<<grid, 256, 0, s>>>(x, (const bf16_t*)gy, gamma, gx, (bf16_t*)gx_bf16, rows, D, eps, group_out, \
-                                                  skip, accumulate)
+#define LNB_CASE(MV)                                                                                                       \
+    layernorm_bwd_kernel<TX, MV><<<grid, 256, 0, s>>>((const TX*)x, ld_x, (const bf16_t*)gy, ld_gy, gamma, gx, ld_gx,     \
+                                                      (bf16_t*)g16, ld_g16, rows, D, eps, group_out, skip, accumulate)
     if (nchunk <= 64) LNB_CASE(1);
     else if (nchunk <= 128) LNB_CASE(2);
     else if (nchunk <= 256) LNB_CASE(4);
     else return ISP_ERR_UNSUPPORTED;
 #undef LNB_CASE
     return isp_launch_status();
+}
+
+extern "C" int isp_layernorm_bwd(const void* x, int x_dtype, long ld_x, const void* gy, long ld_gy, const float* gamma,
+                                 float* gx, long ld_gx, void* gx_bf16, long ld_g16, long rows, int D, float eps,
+                                 int group_out, int skip, int accumulate, void* stream) {
+    ISP_CHECK_ARG(x && gy && gamma && gx && rows > 0 && D > 0 && D % 4 == 0 && group_out >= 0 && skip >= 0);
+    ISP_CHECK_ARG(group_out == 0 || rows % (group_out + skip) == 0);
+    if (ld_x <= 0) ld_x = D;
+    if (ld_gy <= 0) ld_gy = D;
+    if (ld_gx <= 0) ld_gx = D;
+    if (ld_g16 <= 0) ld_g16 = D;
+    ISP_CHECK_ARG(ld_x >= D && ld_gy >= D && ld_gx >= D && ld_g16 >= D);
+    ISP_CHECK_ARG(ld_x % 4 == 0 && ld_gy % 4 == 0 && ld_gx % 4 == 0 && ld_g16 % 4 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == ISP_F32)
+        return launch_ln_bwd<float>(x, ld_x, gy, ld_gy, gamma, gx, ld_gx, gx_bf16, ld_g16, rows, D, eps, group_out, skip, accumulate, s);
+    if (x_dtype == ISP_BF16)
+        return launch_ln_bwd<bf16_t>(x, ld_x, gy, ld_gy, gamma, gx, ld_gx, gx_bf16, ld_g16, rows, D, eps, group_out, skip, accumulate, s);
+    return ISP_ERR_UNSUPPORTED;
 }
 
 extern "C" int isp_resize_bilinear_ac_nchw_f32_bwd(const float* dout, float* din, long planes, int h, int w, int H, int W,

@@ -278,23 +278,77 @@ def resize_bilinear_nchw_f32_bwd(gout, h, w):
     return gin
 
 
-def layernorm_bwd(x, gy, gamma, eps, gx=None, group_out=0, skip=0, want_bf16=True):
-    """gx (+)= d LayerNorm(x)/dx applied to gy.  x f32 [rows,D]; gy bf16 [rows_out,D]; gx f32 [rows,D] is
-    accumulated into when given, else created.  Returns (gx, bf16 copy of gx or None)."""
-    _need(x, torch.float32, "x")
-    _need(gy, BF16, "gy")
-    rows, D = x.shape
+def layernorm_bwd(x, gy, gamma, eps, gx=None, group_out=0, skip=0, want_bf16=True, D=None):
+    """gx (+)= d LayerNorm(x)/dx applied to gy.  x f32/bf16 [rows, ld_x] normalised over its first D columns
+    (default all); gy bf16 [rows_out, ld_gy]; gx f32 [rows, ld_x] is accumulated into when given, else created
+    (padding columns zero).  Returns (gx, bf16 copy of gx [rows, ld_x] or None)."""
+    if x.dtype not in (torch.float32, BF16):
+        raise IspError("layernorm_bwd input must be f32 or bf16")
+    _need(x, x.dtype, "x")
+    _need(gy, BF16, "gy", contiguous=False)
+    rows, ld = x.shape
+    D = ld if D is None else D
     accumulate = gx is not None
     if gx is None:
-        gx = torch.empty_like(x)
+        gx = torch.empty(rows, ld, device=x.device, dtype=torch.float32)
     _need(gx, torch.float32, "gx")
     rows_out = rows if group_out == 0 else rows // (group_out + skip) * group_out
-    if gy.shape != (rows_out, D) or gx.shape != x.shape:
+    if gy.dim() != 2 or gy.shape[0] != rows_out or gy.shape[1] < D or gy.stride(1) != 1 or gx.shape != (rows, ld):
         raise IspError("layernorm_bwd: shape mismatch")
-    g16 = torch.empty(rows, D, device=x.device, dtype=BF16) if want_bf16 else None
-    check(_lib.lib().isp_layernorm_bwd(_p(x), _p(gy), _p(gamma), _p(gx), _p(g16) if g16 is not None else None, rows, D,
+    g16 = torch.empty(rows, ld, device=x.device, dtype=BF16) if want_bf16 else None
+    check(_lib.lib().isp_layernorm_bwd(_p(x), _lib.ISP_F32 if x.dtype == torch.float32 else _lib.ISP_BF16, ld,
+                                       _p(gy), gy.stride(0), _p(gamma), _p(gx), ld,
+                                       _p(g16) if g16 is not None else None, ld, rows, D,
                                        float(eps), group_out, skip, int(accumulate), _stream()), "isp_layernorm_bwd")
     return gx, g16
+
+
+def attention_bwd(q, k, v, out, dout, lse, scale, want_dq=True):
+    """Backward of attention(): q/out/dout [B,Lq,H,hd], k/v [B,Lk,H,hd] bf16 (hd 64 or 128), lse from
+    attention_lse().  Returns (dq or None, dk, dv) shaped like q, k, v (contiguous)."""
+    hd = q.shape[3]
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
+        _need(t, BF16, n, contiguous=False)
+        if t.stride(3) != 1 or t.shape[3] != hd:
+            raise IspError(f"{n}: unit last-dim stride and equal head_dim required")
+    if k.stride() != v.stride() or out.stride() != dout.stride():
+        raise IspError("k/v and out/dout must share strides")
+    B, Lq, H, _ = q.shape
+    Lk = k.shape[1]
+    if tuple(lse.shape) != (B * H, _stat_ld(Lq)):
+        raise IspError("lse shape mismatch")
+    dq = torch.empty(B, Lq, H, hd, device=q.device, dtype=BF16) if want_dq else None
+    dk = torch.empty(B, Lk, H, hd, device=q.device, dtype=BF16)
+    dv = torch.empty_like(dk)
+    if want_dq and dq.stride() != q.stride() or dk.stride() != k.stride():
+        raise IspError("attention_bwd expects contiguous q, k, v (gradients share their strides)")
+    delta = torch.zeros_like(lse)
+    check(_lib.lib().isp_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), _p(delta), lse.shape[1],
+                                       _p(dq) if dq is not None else None, _p(dk), _p(dv), B, H, Lq, Lk, hd,
+                                       q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                                       out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()),
+          "isp_attention_bwd")
+    return dq, dk, dv
+
+
+def attention_lse(q, k, v, scale):
+    """attention() that also returns the base-2 log-sum-exp [B*H, round_up(Lq,64)] the backward needs."""
+    hd = q.shape[3]
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _need(t, BF16, n, contiguous=False)
+        if t.stride(3) != 1 or t.shape[3] != hd or hd not in (64, 128):
+            raise IspError(f"{n}: head_dim must be 64 or 128 with unit stride")
+    if k.stride() != v.stride():
+        raise IspError("k and v must share strides")
+    B, Lq, H, _ = q.shape
+    Lk = k.shape[1]
+    out = torch.empty(B, Lq, H, hd, device=q.device, dtype=BF16)
+    lse = torch.zeros(B * H, _stat_ld(Lq), device=q.device, dtype=torch.float32)
+    check(_lib.lib().isp_attention_fwd_lse(_p(q), _p(k), _p(v), _p(out), _p(lse), lse.shape[1], B, H, Lq, Lk, hd,
+                                           q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                                           out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()),
+          "isp_attention_fwd_lse")
+    return out, lse
 
 
 def attention(q, k, v, scale):
@@ -559,8 +613,9 @@ def relu_mask_colsum(dy, y, want_colsum=True):
     return g, cs
 
 
-def classifier_bwd(grad_logits, x, w):
-    """grad_logits [M] f32, x [M,C] bf16 (post-ReLU), w [C] f32 -> (dx bf16 masked by x>0, dw [C], db [1])."""
+def classifier_bwd(grad_logits, x, w, want_dx_colsum=False):
+    """grad_logits [M] f32, x [M,C] bf16 (post-ReLU), w [C] f32 -> (dx bf16 masked by x>0, dw [C], db [1])
+    (+ the column sums of dx, i.e. the bias gradient of the conv that produced x, when asked)."""
     grad_logits = _need(grad_logits.contiguous(), torch.float32, "grad_logits")
     _need(x, BF16, "x")
     C = x.shape[-1]
@@ -568,9 +623,10 @@ def classifier_bwd(grad_logits, x, w):
     dx = torch.empty_like(x)
     dw = torch.zeros(C, device=x.device, dtype=torch.float32)
     db = torch.zeros(1, device=x.device, dtype=torch.float32)
-    check(_lib.lib().isp_classifier_bwd(_p(grad_logits), _p(x), _p(w), _p(dx), _p(dw), _p(db), M, C, _stream()),
-          "isp_classifier_bwd")
-    return dx, dw, db
+    cs = torch.zeros(C, device=x.device, dtype=torch.float32) if want_dx_colsum else None
+    check(_lib.lib().isp_classifier_bwd(_p(grad_logits), _p(x), _p(w), _p(dx), _p(dw), _p(db),
+                                        _p(cs) if cs is not None else None, M, C, _stream()), "isp_classifier_bwd")
+    return (dx, dw, db, cs) if want_dx_colsum else (dx, dw, db)
 
 
 def resize_bilinear_nhwc_bwd(dout, h, w):

@@ -67,8 +67,10 @@ def test_conv_wgrad_dgrad_vs_autograd(ops, B, H, W, C, N):
     assert rel(dx.permute(0, 3, 1, 2), x.grad) < 1e-2
 
 
-def test_classifier_bwd(ops):
-    M, C = 5000, 128
+@pytest.mark.parametrize("M,C", [(5000, 128), (777, 384), (4099, 24), (1000, 1024)])
+def test_classifier_bwd(ops, M, C):
+    """C = 384 leaves idle threads in the (row slot, 8 columns) mapping, M % 256 != 0 a partial block."""
+    torch.manual_seed(C)
     x = F.relu(torch.randn(M, C, device="cuda")).to(BF)
     w = torch.randn(C, device="cuda")
     gl = torch.randn(M, device="cuda")
@@ -77,6 +79,20 @@ def test_classifier_bwd(ops):
     assert rel(dx, ref_dx) < 1e-2
     assert rel(dw, (gl[:, None] * x.float()).sum(0)) < 1e-3
     assert abs(db.item() - gl.sum().item()) < 1e-2
+    dx2, dw2, db2, cs = ops.classifier_bwd(gl, x, w, want_dx_colsum=True)
+    assert torch.equal(dx2, dx)
+    assert rel(cs, dx.float().sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("M,N", [(5000, 128), (300, 384), (1025, 8)])
+def test_relu_mask_colsum(ops, M, N):
+    torch.manual_seed(N)
+    dy = torch.randn(M, N, device="cuda").to(BF)
+    y = F.relu(torch.randn(M, N, device="cuda")).to(BF)
+    g, cs = ops.relu_mask_colsum(dy, y)
+    ref = dy.float() * (y.float() > 0)
+    assert torch.equal(g.float(), ref)
+    assert rel(cs, ref.sum(0)) < 1e-3
 
 
 @pytest.mark.parametrize("shape", [(2, 4, 5, 56, 70, 64), (1, 16, 16, 224, 224, 128)])
@@ -181,3 +197,45 @@ def test_logits_resize_backward(ops):
     x = torch.randn(3, 1, 4, 5, device="cuda", requires_grad=True)
     F.interpolate(x, (56, 70), mode="bilinear", align_corners=True).backward(g)
     assert rel(ops.resize_bilinear_nchw_f32_bwd(g, 4, 5), x.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,hd,real", [(2, 300, 130, 2, 128, 101), (1, 3136, 16, 4, 128, 37), (2, 200, 77, 3, 64, 64)])
+def test_cross_attention_backward(ops, B, Lq, Lk, H, hd, real):
+    """Lq != Lk, head_dim 128 with zero padding beyond `real` (LoftUp: 101 -> 128), dQ optional."""
+    torch.manual_seed(Lq)
+    def mk(L):
+        t = torch.randn(B, L, H, hd, device="cuda")
+        t[..., real:] = 0
+        return t.to(BF)
+    q, k, v, dout = mk(Lq), mk(Lk), mk(Lk), mk(Lq)
+    scale = real ** -0.5
+    out, lse = ops.attention_lse(q, k, v, scale)
+    assert torch.equal(out, ops.attention(q, k, v, scale))
+    dq, dk, dv = ops.attention_bwd(q, k, v, out, dout, lse, scale)
+    none_dq, dk2, dv2 = ops.attention_bwd(q, k, v, out, dout, lse, scale, want_dq=False)
+    assert none_dq is None and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    p = ((qf.permute(0, 2, 1, 3) * scale) @ kf.permute(0, 2, 3, 1)).softmax(-1)
+    (p @ vf.permute(0, 2, 1, 3)).permute(0, 2, 1, 3).backward(dout.float())
+    for name, g, r in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+        assert rel(g, r) < 2e-2, name
+        if real < hd:  # zero padding stays zero
+            assert g[..., real:].abs().max().item() == 0, name
+
+
+def test_layernorm_backward_bf16_padded(ops):
+    """bf16 input with row stride > D (LoftUp's 404 channels in 448-wide rows), strided gy."""
+    rows, D, ld = 333, 404, 448
+    torch.manual_seed(1)
+    x = torch.zeros(rows, ld, device="cuda")
+    x[:, :D] = torch.randn(rows, D, device="cuda") * 1.5 + 0.3
+    x = x.to(BF)
+    gamma = torch.randn(D, device="cuda")
+    gy_full = torch.randn(rows, ld + 64, device="cuda").to(BF)
+    gy = gy_full[:, :ld]  # row stride ld + 64
+    xr = x[:, :D].float().requires_grad_(True)
+    F.layer_norm(xr, (D,), gamma, torch.zeros(D, device="cuda"), 1e-5).backward(gy[:, :D].float())
+    gx, g16 = ops.layernorm_bwd(x, gy, gamma, 1e-5, D=D)
+    assert rel(gx[:, :D], xr.grad) < 1e-4
+    assert gx[:, D:].abs().max().item() == 0 and g16[:, D:].abs().max().item() == 0
+    assert rel(g16[:, :D], xr.grad) < 1e-2

@@ -10,8 +10,13 @@ from helpers import build_model, rand_points, seeded_
 pytestmark = pytest.mark.gpu
 
 
+UP_PARAMS = {"lift": {"lift_path": None, "n_dim": 128, "patch": 14},
+             "loftup": {"upsampler_path": None, "n_dim": 128},
+             "jbu_featup": {"backbone_type": "dinov2", "feat_dim": 128}}
+
+
 def _setup(upsampler="bilinear", injection="after_backbone"):
-    model = build_model(upsampler, injection=injection)
+    model = build_model(upsampler, injection=injection, upsampler_params=UP_PARAMS.get(upsampler))
     seeded_(model, 9)
     torch.manual_seed(2)
     image = torch.rand(2, 4, 56, 56)
@@ -55,7 +60,7 @@ def test_gradients_vs_oracle_autograd():
     assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
 
 
-@pytest.mark.parametrize("upsampler", ["bilinear", "identity"])
+@pytest.mark.parametrize("upsampler", ["bilinear", "identity", "loftup"])
 def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
     """The reference's default training mode (models/sbd/dinov2/patch-embed_*.py:40): the click
     patch-embedding gets its gradient through both frozen ViT blocks (attention, LayerNorm, GELU
@@ -88,19 +93,20 @@ def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
         print(f"{upsampler} {k:32s} rms-rel {rms:.3e}  cos {cos:.6f}")
         worst[k] = (rms, cos)
     # same bf16 / ReLU-mask argument as above; the embed_coords gradient additionally crosses two
-    # attention + MLP blocks in bf16
-    assert all(c > 0.99 for _, c in worst.values()), worst
-    assert all(r < 0.15 for r, _ in worst.values()), worst
+    # attention + MLP blocks (and, for loftup, two cross-attention + FF layers) in bf16.  LoftUp's
+    # channel-LayerNormed output puts more head activations within bf16 noise of the ReLU threshold: its
+    # head-conv gradients (which do not depend on the upsampler backward at all) sit at cos 0.987-0.99,
+    # and the embed_coords gradient that crosses the whole LoftUp + ViT backward is no worse (0.992).
+    cos_min, rms_max = (0.985, 0.17) if upsampler == "loftup" else (0.99, 0.15)
+    assert all(c > cos_min for _, c in worst.values()), worst
+    assert all(r < rms_max for r, _ in worst.values()), worst
     assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
 
 
-@pytest.mark.parametrize("upsampler,params", [
-    ("lift", {"lift_path": None, "n_dim": 128, "patch": 14}),
-    ("loftup", {"upsampler_path": None, "n_dim": 128}),
-    ("jbu_featup", {"backbone_type": "dinov2", "feat_dim": 128})])
-def test_before_backbone_training_through_learned_upsamplers_is_refused(upsampler, params):
-    """No backward exists for the learned upsamplers: asking for it must raise, not return zeros."""
-    model = build_model(upsampler, injection="before_backbone", upsampler_params=params).cuda().train()
+@pytest.mark.parametrize("upsampler", ["lift", "jbu_featup"])
+def test_before_backbone_training_through_lift_and_jbu_is_refused(upsampler):
+    """No backward exists for LiFT / FeatUp JBU: asking for it must raise, not return zeros."""
+    model = build_model(upsampler, injection="before_backbone", upsampler_params=UP_PARAMS[upsampler]).cuda().train()
     image, points = torch.rand(1, 4, 56, 56).cuda(), torch.tensor([[[5., 5., 0.], [-1., -1., -1.]]]).cuda()
     with pytest.raises(NotImplementedError):
         model(image, points)
