@@ -525,20 +525,21 @@ int launch_gemm(AL al, const void* Wt, long M, int N, int K, EP ep, hipStream_t 
 //   LDS = 2 x 42 KiB + 2 x 24 KiB = 132 KiB.
 constexpr int PT = 16, PW_ = 18, PPIX = PW_ * PW_;       // 16x16 outputs, 18x18 inputs
 constexpr int P_PIECES = (PPIX + 7) / 8 + 1;              // 42 one-KiB pieces (8 pixels x 128 B)
-constexpr int P_BYTES = P_PIECES * 1024, PBN = 192, PWB = PBN * BK * 2,
+constexpr int P_BYTES = P_PIECES * 1024,
 #ifdef ISP_P_WST3
-              P_WST = 3,
+              P_WST = 3;
 #else
-              P_WST = 2,
+              P_WST = 2;
 #endif
-              P_LDS = 2 * P_BYTES + P_WST * PWB;
 
-template <class EP>
+// TN = 16-channel tiles per wave: 6 -> 192 output channels per block (C = N = 384 heads), 8 -> 256 (N = 1024).
+template <class EP, int TN>
 __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const bf16_t* __restrict__ in,
                                                                const bf16_t* __restrict__ Wt, int H, int W, int C,
                                                                int N, int tiles_x, int tiles_y, int tiles_n, int nwg,
                                                                EP ep) {
-    constexpr int TM = 4, TN = 6, NWV = 8, PPW = (P_PIECES + NWV - 1) / NWV;  // 6 patch pieces per wave
+    constexpr int TM = 4, NWV = 8, PPW = (P_PIECES + NWV - 1) / NWV;  // 6 patch pieces per wave
+    constexpr int PBN = 2 * TN * 16, PWB = PBN * BK * 2, WPW = PBN / 8 / NWV;  // weight pieces per wave (3 or 4)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -569,17 +570,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const bf16_t* __r
         if (wid + NWV * i < P_PIECES)
             glds16((pmask >> i & 1) ? img + poff[i] + cb * BK : zero, buf + (wid + NWV * i) * 1024);
     };
-    // --- weight DMA slots: 24 pieces per stage, 3 per wave
+    // --- weight DMA slots: PBN/8 pieces per stage, WPW per wave
     const bf16_t* const wbase = Wt + (size_t)n0 * K;
-    unsigned woff[3];
+    unsigned woff[WPW];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < WPW; ++i) {
         const int row = (wid + NWV * i) * 8 + (lane >> 3);
         woff[i] = (unsigned)((n0 + row < N ? row : N - 1 - n0) * K + swz(row, lane & 7) * 8);
     }
     auto issue_w = [&](long col, char* buf) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) glds16(wbase + col + woff[i], buf + (wid + NWV * i) * 1024);
+        for (int i = 0; i < WPW; ++i) glds16(wbase + col + woff[i], buf + (wid + NWV * i) * 1024);
     };
 
     // --- fragment geometry
@@ -612,16 +613,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const bf16_t* __r
             fa[t] = *reinterpret_cast<const bf16x8*>(patch + p * 128 + swz(p, ks * 4 + fq) * 16);
         }
     };
-    auto read_w = [&](bf16x8 (&fw)[TN], const char* wb, int ks) {
+    // weight fragments are read (and consumed) in NH groups of TNH tiles: with TN = 8 a single group would not
+    // fit beside the 128 accumulator registers
+    constexpr int NH = TN > 6 ? 2 : 1, TNH = TN / NH;
+    auto read_w = [&](bf16x8 (&fw)[TNH], const char* wb, int ks, int half) {
 #pragma unroll
-        for (int t = 0; t < TN; ++t) fw[t] = *reinterpret_cast<const bf16x8*>(wb + ((w_off0 ^ (ks * 64)) + t * 2048));
+        for (int t = 0; t < TNH; ++t)
+            fw[t] = *reinterpret_cast<const bf16x8*>(wb + ((w_off0 ^ (ks * 64)) + (half * TNH + t) * 2048));
     };
-    auto mma = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fw)[TN]) {
+    auto mma = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fw)[TNH], int half) {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < TNH; ++ni)
+                acc[mi][half * TNH + ni] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][half * TNH + ni], 0, 0, 0);
     };
     auto tap_shift = [&](int tap) {
         int shift = (tap / 3 - 1) * PW_ + (tap % 3 - 1);
@@ -661,12 +667,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const bf16_t* __r
             continue;
 #endif
             const char* wb = s_w + (P_WST == 3 ? tap % 3 : s & 1) * PWB;
-            bf16x8 fa1[TM], fw[TN];
-            read_w(fw, wb, 0);
+            bf16x8 fa1[TM], fw[TNH];
+            read_w(fw, wb, 0, 0);
             read_a(fa1, patch, tap_shift(tap), 1);
-            mma(fa0, fw);
-            read_w(fw, wb, 1);
-            mma(fa1, fw);
+            mma(fa0, fw, 0);
+#pragma unroll
+            for (int half = 1; half < NH; ++half) {
+                read_w(fw, wb, 0, half);
+                mma(fa0, fw, half);
+            }
+#pragma unroll
+            for (int half = 0; half < NH; ++half) {
+                read_w(fw, wb, 1, half);
+                mma(fa1, fw, half);
+            }
             read_a(fa0, tap < 8 ? patch : patch_next, tap_shift(tap < 8 ? tap + 1 : 0), 0);
         }
     }
@@ -680,13 +694,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const bf16_t* __r
     run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
 }
 
-template <class EP>
+template <int TN, class EP>
 int launch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int C, int N, EP ep, hipStream_t s) {
+    constexpr int PBN = 2 * TN * 16, P_LDS = 2 * P_BYTES + P_WST * PBN * BK * 2;
     const int tiles_x = (W + PT - 1) / PT, tiles_y = (H + PT - 1) / PT, tiles_n = (N + PBN - 1) / PBN;
     const long nwg = (long)B * tiles_x * tiles_y * tiles_n;
-    if (nwg > 0x7fffffffL || (long)H * W * C > 0x7fffffffL || 192L * 9 * C > 0x7fffffffL) return ISP_ERR_INVALID;
+    if (nwg > 0x7fffffffL || (long)H * W * C > 0x7fffffffL || (long)PBN * 9 * C > 0x7fffffffL) return ISP_ERR_INVALID;
     static bool attr_done = false;
-    auto kern = conv3x3_patch_kernel<EP>;
+    auto kern = conv3x3_patch_kernel<EP, TN>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess)
             return ISP_ERR_LAUNCH;
@@ -698,22 +713,23 @@ int launch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int C
 }
 
 // dispatch of the epilogue kinds the patch conv supports
-inline int dispatch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int C, int N, const isp_epilogue* e,
-                               hipStream_t s) {
+template <int TN>
+int dispatch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int C, int N, const isp_epilogue* e,
+                        hipStream_t s) {
     const long M = (long)B * H * W;
     const long ldo = e->ldo > 0 ? e->ldo : N;
     switch (e->kind) {
         case ISP_EP_BIAS_BF16:
-            return launch_conv_patch(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_NONE>{(bf16_t*)e->out, e->bias, ldo}, s);
+            return launch_conv_patch<TN>(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_NONE>{(bf16_t*)e->out, e->bias, ldo}, s);
         case ISP_EP_BIAS_RELU_BF16:
-            return launch_conv_patch(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_RELU>{(bf16_t*)e->out, e->bias, ldo}, s);
+            return launch_conv_patch<TN>(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_RELU>{(bf16_t*)e->out, e->bias, ldo}, s);
         case ISP_EP_BIAS_TAPS_RELU_BF16:
             if (!e->bias || !e->pos || e->img_h <= 0 || e->img_w <= 0 || ldo != N) return ISP_ERR_INVALID;
-            return launch_conv_patch(in, Wt, B, H, W, C, N,
+            return launch_conv_patch<TN>(in, Wt, B, H, W, C, N,
                                      EpBiasTapsReluBf16{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
         case ISP_EP_RELU_DOT_PARTIAL_F32:
             if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
-            return launch_conv_patch(in, Wt, B, H, W, C, N, EpReluDotPartial{(float*)e->out, e->bias, e->gamma, M}, s);
+            return launch_conv_patch<TN>(in, Wt, B, H, W, C, N, EpReluDotPartial{(float*)e->out, e->bias, e->gamma, M}, s);
         default:
             return ISP_ERR_UNSUPPORTED;
     }
@@ -836,8 +852,11 @@ extern "C" int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int 
         al.tiles_y = (H + CFG::BM / 16 - 1) / (CFG::BM / 16);
         return dispatch_epilogue<CFG, Conv3x3A<CFG::PA>, CONV_KINDS>(al, Wt, M, N, 9 * C, ep, (hipStream_t)stream);
     };
-    if (N % 192 == 0 && !ep_forces_tile_engine()) {
-        const int rc = ep ? dispatch_conv_patch(in, Wt, B, H, W, C, N, ep, (hipStream_t)stream) : ISP_ERR_INVALID;
+    // LDS-resident-patch kernel when 192-channel blocks tile N exactly.  (A 256-channel variant, TN = 8, for
+    // N = 1024 needs ~280 VGPRs and spills; those shapes stay on the tile engine.)
+    if (!ep_forces_tile_engine() && N % 192 == 0) {
+        if (!ep) return ISP_ERR_INVALID;
+        const int rc = dispatch_conv_patch<6>(in, Wt, B, H, W, C, N, ep, (hipStream_t)stream);
         if (rc != ISP_ERR_UNSUPPORTED) return rc;
     }
     if (N % 192 == 0) return run(CfgConv192{});
