@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--n-clicks", type=int, default=20)
     ap.add_argument("--thresh", type=float, default=0.5)
     ap.add_argument("--target-iou", type=float, default=0.90)
+    ap.add_argument("--host-clicker", action="store_true",
+                    help="robot user + IoU on the host (numpy/scipy) as in the reference, instead of the device clicker")
     args = ap.parse_args()
 
     import isegprobe_amd
@@ -71,14 +73,15 @@ def main():
                               zoom_in_params={"skip_clicks": -1, "target_size": crop})
     # print_ious=True in the reference forces all n_clicks to run (inference/utils.py:254-255)
     all_ious, elapsed = evaluate_dataset(dataset, predictor, pred_thr=args.thresh, max_iou_thr=1.01,
-                                         min_clicks=1, max_clicks=args.n_clicks)
+                                         min_clicks=1, max_clicks=args.n_clicks,
+                                         device_clicker=False if args.host_clicker else None)
     noc, noc_std, over = compute_noc_metric(all_ious, [0.8, 0.85, args.target_iou], max_clicks=args.n_clicks)
     n_clicks_total = sum(len(x) for x in all_ious)
     print(f"|{'Upsampler':^22}|{'Dataset':^11}|{'NoC@80%':^9}|{'NoC@85%':^9}|{'NoC@' + str(int(args.target_iou * 100)) + '%':^9}|"
           f"{'IoU@1':^9}|{'SPC,s':^7}|{'Time':^9}|")
     print(f"|{model.upsampler.__class__.__name__:^22}|{os.path.basename(args.dataset.rstrip('/'))[:11]:^11}|"
           f"{noc[0]:^9.2f}|{noc[1]:^9.2f}|{noc[2]:^9.2f}|{np.mean([x[0] for x in all_ious]):^9.2f}|"
-          f"{elapsed / max(n_clicks_total, 1):^7.3f}|{str(timedelta(seconds=int(elapsed))):^9}|")
+          f"{elapsed / max(n_clicks_total, 1):^7.4f}|{str(timedelta(seconds=int(elapsed))):^9}|")
     if tmp:
         tmp.cleanup()
 

@@ -234,6 +234,19 @@ int isp_nhwc_bf16_to_nchw_f32(const void* in, float* out, int B, int C, long HW,
 int isp_nchw_f32_to_nhwc_bf16(const float* in, void* out, int B, int C, long HW, long stride_b, long stride_c,
                               long stride_p, void* stream);
 
+/* ---- Device-side robot user.  One call = Clicker._get_next_click (core/inference/
+ * clicker.py:58-91) + utils.get_iou (core/inference/utils.py:107-120) for one prediction, on masks resident in HBM:
+ * pred / gt / not_ignore (nullable = all ones) / not_clicked are uint8 [H,W] (0/1).  out[8] int32 (device):
+ * {is_positive, row, col, max squared interior distance of the FN region, of the FP region, |pred&gt&ni|, |(pred|gt)&ni|, 0}.
+ * Exact integer EDT of the 1-pixel zero-padded masks (what cv2.distanceTransform(DIST_L2, maskSize 0) computes before
+ * its final sqrt), already-clicked pixels zeroed, larger maximum wins, first maximum in row-major order.
+ * workspace: isp_robot_click_workspace_bytes(H, W) bytes.  not_clicked is NOT modified (the caller records clicks). */
+long isp_robot_click_workspace_bytes(int H, int W);
+int isp_robot_click(const void* pred, const void* gt, const void* not_ignore, const void* not_clicked, int H, int W,
+                    void* workspace, int* out, void* stream);
+/* mask[i] = probs[i] > thr (uint8), evaluation.py:74 */
+int isp_threshold_u8(const float* probs, void* mask, float thr, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

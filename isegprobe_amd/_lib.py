@@ -55,6 +55,9 @@ SIGNATURES = {
     "isp_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
     "isp_attention_fwd_lse": [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
     "isp_attention_bwd": [_vp] * 7 + [_l] + [_vp] * 3 + [_i] * 5 + [_l] * 9 + [_f, _vp],
+    "isp_robot_click_workspace_bytes": [_i, _i],
+    "isp_robot_click": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "isp_threshold_u8": [_vp, _vp, _f, _l, _vp],
     "isp_resize_bilinear_ac_nchw_f32_bwd": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
     "isp_layernorm_bwd": [_vp, _i, _l, _vp, _l, _vp, _vp, _l, _vp, _l, _l, _i, _f, _i, _i, _i, _vp],
     "isp_resize_bilinear_ac_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -82,6 +85,9 @@ SIGNATURES = {
 _lib = None
 
 
+LONG_RETURNS = {"isp_robot_click_workspace_bytes"}
+
+
 def lib():
     """Load (once) and return the bound library; raises if it is not built."""
     global _lib
@@ -95,7 +101,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_long if name in LONG_RETURNS else ctypes.c_int
         if handle.isp_abi_version() != ABI_VERSION:
             raise IspError(f"ABI mismatch: library {handle.isp_abi_version()} != binding {ABI_VERSION}")
         _lib = handle

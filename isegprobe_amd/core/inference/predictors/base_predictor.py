@@ -58,6 +58,11 @@ class BasePredictor(object):
                 self.net = self.click_models[model_indx]
 
     def get_prediction(self, clicker: Clicker, prev_mask: torch.Tensor = None) -> np.ndarray:
+        return self.get_prediction_device(clicker, prev_mask).cpu().numpy()
+
+    def get_prediction_device(self, clicker: Clicker, prev_mask: torch.Tensor = None) -> torch.Tensor:
+        """get_prediction without the device->host copy: the [H0, W0] f32 probability map stays in HBM
+        (consumed by DeviceClicker.evaluate_prediction)."""
         clicks_list = clicker.get_clicks()
         self._select_click_model(clicker, clicks_list)
         input_image = self.original_image
@@ -70,9 +75,9 @@ class BasePredictor(object):
         prediction = self._resize_logits(pred_logits, image_nd.size()[2:])  # base_predictor.py:95-97
         prediction = self._inverse_transforms(prediction)
         if self.zoom_in is not None and self.zoom_in.check_possible_recalculation():
-            return self.get_prediction(clicker)
+            return self.get_prediction_device(clicker)
         self.prev_prediction = prediction
-        return prediction.cpu().numpy()[0, 0]
+        return prediction[0, 0]
 
     @staticmethod
     def _resize_logits(logits, size):

@@ -1,0 +1,159 @@
+// Device-side robot user: next click + IoU of one prediction, without leaving the GPU.
+//
+// Replaces, per click of the NoC loop, Clicker._get_next_click (reference core/inference/clicker.py:58-91:
+// FN / FP masks, exact Euclidean distance transform of the 1-pixel zero-padded masks via
+// cv2.distanceTransform(DIST_L2, maskSize 0), zeroing of already-clicked pixels, "larger maximum wins",
+// first maximum in row-major order) and utils.get_iou (core/inference/utils.py:107-120), which the
+// reference runs on the host after two device->host copies of the probability map (base_predictor.py:108,
+// evaluation.py:73-76).
+//
+// Everything is integer: the squared EDT is exact in int32, sqrt is monotonic, so comparing squared
+// distances gives the same click as comparing OpenCV's float32 distances.
+//   1. columns: g[m][y][x] = vertical distance from (y,x) to the nearest zero of mask m in column x,
+//      with virtual zeros at y = -1 and y = H (the reference's 1-pixel padding); IoU counts on the way.
+//   2. rows:    d2(y,x) = min_x' (x-x')^2 + g[m][y][x']^2 with virtual zeros at x' = -1 and x' = W; the
+//      scan walks outwards from x and stops once (x-x')^2 >= best.  Masked by not_clicked, packed as
+//      (d2 << 32 | ~index) and max-reduced: largest distance, then smallest row-major index.
+//   3. decide:  positive click iff max(FN) > max(FP) (clicker.py:84), write the result record.
+#include "isp_common.h"
+
+namespace {
+
+constexpr int MAXW = 8192;
+
+__device__ __forceinline__ bool in_mask(int m, unsigned char pred, unsigned char gt, unsigned char ni) {
+    return m == 0 ? (gt && !pred && ni) : (!gt && pred && ni);  // 0: false negatives, 1: false positives
+}
+
+__global__ __launch_bounds__(256) void clicker_columns_kernel(const unsigned char* __restrict__ pred,
+                                                              const unsigned char* __restrict__ gt,
+                                                              const unsigned char* __restrict__ ni, int* __restrict__ g,
+                                                              unsigned long long* __restrict__ keys,
+                                                              int* __restrict__ counts, int H, int W) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    if (x >= W) return;
+    int* gm = g + (size_t)m * H * W;
+    int d = 0, inter = 0, uni = 0;
+    for (int y = 0; y < H; ++y) {  // distance to the nearest zero above (virtual zero row at y = -1)
+        const size_t i = (size_t)y * W + x;
+        const unsigned char p = pred[i], t = gt[i], n = ni ? ni[i] : 1;
+        d = in_mask(m, p, t, n) ? d + 1 : 0;
+        gm[i] = d;
+        if (m == 0) {
+            inter += (p && t && n);
+            uni += ((p || t) && n);
+        }
+    }
+    d = 0;
+    for (int y = H - 1; y >= 0; --y) {  // ... and below (virtual zero row at y = H)
+        const size_t i = (size_t)y * W + x;
+        const int up = gm[i];
+        d = up ? d + 1 : 0;
+        gm[i] = up < d ? up : d;
+    }
+    if (m == 0) {
+        atomicAdd(counts, inter);
+        atomicAdd(counts + 1, uni);
+    }
+}
+
+__global__ __launch_bounds__(256) void clicker_rows_kernel(const int* __restrict__ g,
+                                                           const unsigned char* __restrict__ not_clicked,
+                                                           unsigned long long* __restrict__ keys, int H, int W) {
+    __shared__ int g2[MAXW];
+    __shared__ unsigned long long best_key[4];
+    const int y = blockIdx.x, m = blockIdx.y;
+    const int* gr = g + ((size_t)m * H + y) * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        const int v = gr[x];
+        g2[x] = v * v;
+    }
+    __syncthreads();
+    unsigned long long key = 0;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        int best = g2[x];
+        if (best > 0) {
+            // virtual zero columns at -1 and W bound the search radius
+            const int lb = (x + 1) * (x + 1), rb = (W - x) * (W - x);
+            best = best < lb ? best : lb;
+            best = best < rb ? best : rb;
+            for (int r = 1; r * r < best; ++r) {
+                if (x - r >= 0) {
+                    const int c = r * r + g2[x - r];
+                    best = c < best ? c : best;
+                }
+                if (x + r < W) {
+                    const int c = r * r + g2[x + r];
+                    best = c < best ? c : best;
+                }
+            }
+        }
+        const unsigned idx = (unsigned)(y * W + x);
+        const unsigned d2 = not_clicked[idx] ? (unsigned)best : 0u;
+        const unsigned long long k = ((unsigned long long)d2 << 32) | (unsigned long long)(0xffffffffu - idx);
+        key = k > key ? k : key;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0) best_key[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) key = best_key[i] > key ? best_key[i] : key;
+        atomicMax(keys + m, key);
+    }
+}
+
+__global__ void clicker_decide_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ counts, int W,
+                                      int* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned fn_d2 = (unsigned)(keys[0] >> 32), fp_d2 = (unsigned)(keys[1] >> 32);
+    const int positive = fn_d2 > fp_d2;  // clicker.py:84 (ties -> negative click)
+    const unsigned idx = 0xffffffffu - (unsigned)(keys[positive ? 0 : 1] & 0xffffffffu);
+    out[0] = positive;
+    out[1] = (int)(idx / (unsigned)W);
+    out[2] = (int)(idx % (unsigned)W);
+    out[3] = (int)fn_d2;
+    out[4] = (int)fp_d2;
+    out[5] = counts[0];  // |pred & gt & not_ignore|
+    out[6] = counts[1];  // |(pred | gt) & not_ignore|
+    out[7] = 0;
+}
+
+__global__ __launch_bounds__(256) void threshold_kernel(const float* __restrict__ probs, unsigned char* __restrict__ mask,
+                                                        float thr, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mask[i] = probs[i] > thr;
+}
+
+}  // namespace
+
+extern "C" long isp_robot_click_workspace_bytes(int H, int W) {
+    if (H <= 0 || W <= 0) return ISP_ERR_INVALID;
+    return 2L * H * W * 4 + 64;  // g[2][H][W] int32 + keys[2] + counts[2]
+}
+
+extern "C" int isp_threshold_u8(const float* probs, void* mask, float thr, long n, void* stream) {
+    ISP_CHECK_ARG(probs && mask && n > 0);
+    threshold_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(probs, (unsigned char*)mask, thr, n);
+    return isp_launch_status();
+}
+
+extern "C" int isp_robot_click(const void* pred, const void* gt, const void* not_ignore, const void* not_clicked, int H,
+                               int W, void* workspace, int* out, void* stream) {
+    ISP_CHECK_ARG(pred && gt && not_clicked && workspace && out && H > 0 && W > 0 && W <= MAXW);
+    ISP_CHECK_ARG((long)H * W < 0x7fffffffL && (long)H + W < 30000);  // squared distances stay in int32
+    hipStream_t s = (hipStream_t)stream;
+    int* g = (int*)workspace;
+    unsigned long long* keys = (unsigned long long*)((char*)workspace + 2L * H * W * 4);
+    int* counts = (int*)(keys + 2);
+    if (hipMemsetAsync(keys, 0, 32, s) != hipSuccess) return ISP_ERR_LAUNCH;
+    clicker_columns_kernel<<<dim3((W + 255) / 256, 2), 256, 0, s>>>((const unsigned char*)pred, (const unsigned char*)gt,
+                                                                    (const unsigned char*)not_ignore, g, keys, counts, H, W);
+    clicker_rows_kernel<<<dim3(H, 2), 256, 0, s>>>(g, (const unsigned char*)not_clicked, keys, H, W);
+    clicker_decide_kernel<<<1, 64, 0, s>>>(keys, counts, W, out);
+    return isp_launch_status();
+}

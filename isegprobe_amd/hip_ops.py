@@ -636,3 +636,32 @@ def resize_bilinear_nhwc_bwd(dout, h, w):
     check(_lib.lib().isp_resize_bilinear_ac_nhwc_bwd(_p(dout), _p(din), B, h, w, H, W, C, _stream()),
           "isp_resize_bilinear_ac_nhwc_bwd")
     return din
+
+
+def threshold_u8(probs, thr):
+    """uint8 mask = probs > thr (evaluation.py:74), probs f32 of any shape."""
+    probs = _need(probs.contiguous(), torch.float32, "probs")
+    mask = torch.empty(probs.shape, device=probs.device, dtype=torch.uint8)
+    check(_lib.lib().isp_threshold_u8(_p(probs), _p(mask), float(thr), probs.numel(), _stream()), "isp_threshold_u8")
+    return mask
+
+
+def robot_click(pred, gt, not_ignore, not_clicked, workspace=None):
+    """Next robot click + IoU counts for uint8 [H,W] device masks (see isp_robot_click).  Returns the int32[8]
+    DEVICE record {is_positive, row, col, fn_max_d2, fp_max_d2, intersection, union, 0} and the workspace."""
+    for t, n in ((pred, "pred"), (gt, "gt"), (not_clicked, "not_clicked")):
+        _need(t, torch.uint8, n)
+    if not_ignore is not None:
+        _need(not_ignore, torch.uint8, "not_ignore")
+    H, W = gt.shape
+    if pred.shape != gt.shape or not_clicked.shape != gt.shape or (not_ignore is not None and not_ignore.shape != gt.shape):
+        raise IspError("robot_click: mask shapes differ")
+    need = _lib.lib().isp_robot_click_workspace_bytes(H, W)
+    if need < 0:
+        check(int(need), "isp_robot_click_workspace_bytes")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=gt.device, dtype=torch.uint8)
+    out = torch.empty(8, device=gt.device, dtype=torch.int32)
+    check(_lib.lib().isp_robot_click(_p(pred), _p(gt), _p(not_ignore) if not_ignore is not None else None,
+                                     _p(not_clicked), H, W, _p(workspace), _p(out), _stream()), "isp_robot_click")
+    return out, workspace
