@@ -5,13 +5,55 @@ import numpy as np
 import torch
 
 from .... import hip_ops as ops
+from ...model._guidance_cache import guidance_scope
 from ..clicker import Click, Clicker
 from ..transforms import AddHorizontalFlip, BaseTransform, LimitLongestSide, SigmoidForPred
 
 
+class _ClickGraph:
+    """One captured HIP graph of ``net(image, points)`` for a fixed input geometry: the per-click forward is
+    ~150 short launches at batch 2, i.e. launch-bound; replaying a graph removes the host from the loop.
+    Inputs are copied into static buffers; `points` is padded with (-1,-1,-1) rows to a fixed capacity
+    (ignored by the click-map kernel, so the result is identical).  Guidance-only upsampler work must be
+    resident in the pointer-stable guidance cache before capture and is refreshed eagerly by the caller."""
+
+    def __init__(self, net, image, points, capacity, token):
+        B = image.shape[0]
+        self.capacity = capacity
+        self.image = image.clone()
+        self.points = torch.full((B, 2 * capacity, 3), -1.0, device=image.device, dtype=torch.float32)
+        self._load_points(points)
+        side = torch.cuda.Stream(device=image.device)
+        side.wait_stream(torch.cuda.current_stream(image.device))
+        with torch.cuda.stream(side), guidance_scope(token):  # warm-up: attributes, packed weights, caches
+            for _ in range(2):
+                net(self.image, self.points)
+        torch.cuda.current_stream(image.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), guidance_scope(token):
+            self.out = net(self.image, self.points)["instances"]
+
+    def _load_points(self, points):
+        P = points.shape[1] // 2
+        self.points.fill_(-1.0)
+        self.points[:, :P] = points[:, :P]
+        self.points[:, self.capacity:self.capacity + P] = points[:, P:]
+
+    def replay(self, image, points):
+        self.image.copy_(image)
+        self._load_points(points)
+        self.graph.replay()
+        return self.out
+
+
 class BasePredictor(object):
     def __init__(self, model, device: torch.device, net_clicks_limit: int = None, with_flip: bool = False,
-                 zoom_in: BaseTransform = None, max_size: int = None, **kwargs) -> None:
+                 zoom_in: BaseTransform = None, max_size: int = None, hip_graphs: bool = None, **kwargs) -> None:
+        """``hip_graphs`` (default: env ISEGPROBE_HIP_GRAPHS) replays the per-click network call from a captured
+        HIP graph; results are identical to the eager path (tests/test_inference_gpu.py)."""
+        import os
+        self.hip_graphs = bool(int(os.environ.get("ISEGPROBE_HIP_GRAPHS", "0"))) if hip_graphs is None else hip_graphs
+        self._graphs = {}
         self.with_flip = with_flip
         self.net_clicks_limit = net_clicks_limit
         self.original_image = None
@@ -49,6 +91,7 @@ class BasePredictor(object):
         if len(self.original_image.shape) == 3:
             self.original_image = self.original_image.unsqueeze(0)
         self.prev_prediction = torch.zeros_like(self.original_image[:, :1, :, :])
+        self._guidance_token = object()  # new image: guidance-only upsampler work must be redone
 
     def _select_click_model(self, clicker, clicks_list):
         if self.click_models is not None:
@@ -110,7 +153,34 @@ class BasePredictor(object):
         return self.net.get_lowres_highres_feats(image_nd, self.get_points_nd(clicks_lists))
 
     def _get_prediction(self, image_nd, clicks_lists, is_image_changed):
-        return self.net(image_nd, self.get_points_nd(clicks_lists))["instances"]
+        # The RGB planes the upsamplers see are a function of (input image, crops applied by the transforms);
+        # while that tuple is unchanged their click-independent work is reused.
+        token = (id(self), getattr(self, "_guidance_token", None),
+                 tuple(getattr(t, "applied_roi", None) for t in self.transforms))
+        points = self.get_points_nd(clicks_lists)
+        if self.hip_graphs and image_nd.is_cuda:
+            return self._graphed(image_nd, points, token)
+        with guidance_scope(token):
+            return self.net(image_nd, points)["instances"]
+
+    def _graphed(self, image_nd, points, token):
+        P = points.shape[1] // 2
+        key = (id(self.net), tuple(image_nd.shape))
+        g = self._graphs.get(key)
+        if g is None or g.capacity < P:
+            if g is None and len(self._graphs) >= 4:  # images of many sizes without zoom-in: bound the graph pool
+                self._graphs.pop(next(iter(self._graphs)))
+            capacity = max(24, 2 * P) if g is None else max(2 * g.capacity, P)
+            g = self._graphs[key] = _ClickGraph(self.net, image_nd, points, capacity, token)
+            g.token = token
+        elif g.token != token:
+            # the guidance changed (new image / zoom-in ROI): one eager pass refreshes the click-independent
+            # upsampler work INTO the cache's existing storage (the captured graph keeps pointing at it) and is
+            # itself this click's result
+            g.token = token
+            with guidance_scope(token):
+                return self.net(image_nd, points)["instances"]
+        return g.replay(image_nd, points).clone()
 
     def _batch_infer(self, batch_image_tensor, batch_clickers, prev_mask=None):
         if prev_mask is None:

@@ -34,6 +34,7 @@ class ZoomIn(BaseTransform):
     def _transform(self, image_nd, clicks_lists):
         assert image_nd.shape[0] == 1 and len(clicks_lists) == 1
         self.image_changed = False
+        self.applied_roi = None  # the crop this call actually applied (None: image passed through)
         clicks_list = clicks_lists[0]
         if len(clicks_list) <= self.skip_clicks:
             return image_nd, clicks_lists
@@ -55,6 +56,7 @@ class ZoomIn(BaseTransform):
             self._object_roi = current_object_roi
             self.image_changed = True
         self._roi_image = get_roi_image_nd(image_nd, self._object_roi, self.target_size)
+        self.applied_roi = tuple(int(v) for v in self._object_roi)
         return self._roi_image.to(image_nd.device), [self._transform_clicks(clicks_list)]
 
     def inv_transform(self, prob_map):

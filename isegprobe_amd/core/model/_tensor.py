@@ -45,6 +45,13 @@ class PackedCache:
         self._key = None
         self._val = None
 
+    def tensors_of(self, enumerate_tensors):
+        """The tensor list to watch, enumerated once: Parameter / buffer objects of a module tree are stable
+        (load_state_dict, .to(), optimizers update them in place), walking the tree per forward is not free."""
+        if getattr(self, "_watch", None) is None:
+            self._watch = list(enumerate_tensors())
+        return self._watch
+
     def get(self, tensors, build):
         key = tuple((t.data_ptr(), t._version, t.device) for t in tensors)
         if key != self._key:

@@ -135,7 +135,11 @@ class DINOv2Featurizer(nn.Module):
 
     # ------------------------------------------------------------------ weight packing
     def _params(self):
-        return list(self.model.parameters())
+        # the Parameter objects of a module tree are stable (load_state_dict / .to() / optimizers update them in
+        # place); walking the tree on every forward costs ~0.8 ms at batch 2
+        if getattr(self, "_param_list", None) is None:
+            self._param_list = list(self.model.parameters())
+        return self._param_list
 
     def packed(self):
         def build():

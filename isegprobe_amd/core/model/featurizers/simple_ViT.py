@@ -94,7 +94,7 @@ class SimpleViTFeaturizer(nn.Module):
                     f2_w=ff.net[3].weight.detach().to(BF16).contiguous(), f2_b=f(ff.net[3].bias)))
             P["tn_w"], P["tn_b"] = f(self.transformer.norm.weight), f(self.transformer.norm.bias)
             return P
-        return self._packed.get(list(self.parameters()), build)
+        return self._packed.get(self._packed.tensors_of(self.parameters), build)
 
     def forward(self, img: torch.Tensor) -> torch.Tensor:
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

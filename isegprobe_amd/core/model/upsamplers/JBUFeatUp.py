@@ -16,6 +16,7 @@ import torch.nn as nn
 from .... import hip_ops as ops
 from ...utils.log import logger
 from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16
+from .._guidance_cache import GuidanceCache
 from . import BaseUpsampler
 
 FEAT_DIMS = {"dinov2": 384, "dino16": 384, "vit": 384, "maskclip": 512, "clip": 512, "resnet50": 2048}
@@ -34,6 +35,7 @@ class JBULearnedRange(nn.Module):
                                         nn.Conv2d(d2, d2, 1, 1))
         self.sigma_spatial = nn.Parameter(torch.tensor(1.0))
         self._packed = PackedCache()
+        self._gcache = GuidanceCache()
 
     def packed(self):
         def build():
@@ -51,14 +53,22 @@ class JBULearnedRange(nn.Module):
                         w3=f(self.range_proj[3].weight.flatten(1)), b3=f(self.range_proj[3].bias),
                         f0w=f0w, f0b=f0b, f3w=f3w, f3b=f3b,
                         temp=float(self.range_temp.item()), sigma=float(self.sigma_spatial.item()))
-        return self._packed.get(list(self.parameters()), build)
+        return self._packed.get(self._packed.tensors_of(self.parameters), build)
 
-    def run(self, source_nhwc, guidance_small):
+    def kernels(self, guidance, GH, GW):
+        """Composite (bicubic-x2 o 7x7) kernels of this stage: a function of the guidance only, so the click loop
+        reuses them while the image / zoom-in ROI is unchanged (_guidance_cache)."""
         P = self.packed()
-        B, GH, GW = guidance_small.shape[0], guidance_small.shape[2], guidance_small.shape[3]
-        proj = ops.jbu_range_proj(guidance_small, P["w0"], P["b0"], P["w3"], P["b3"])
-        # composite (bicubic-x2 o 7x7) kernels on the low-res grid, applied by MFMA: no x2 map in HBM
-        kc = ops.jbu_kernels(proj, guidance_small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"])
+
+        def build():
+            small = ops.adaptive_avg_pool(guidance, GH, GW)
+            proj = ops.jbu_range_proj(small, P["w0"], P["b0"], P["w3"], P["b3"])
+            return ops.jbu_kernels(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"])
+        return self._gcache.get(guidance, id(P), (GH, GW), build)
+
+    def run(self, source_nhwc, guidance):
+        # composite kernels on the low-res grid, applied by MFMA: no x2 map in HBM
+        kc = self.kernels(guidance, source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2)
         return ops.jbu_apply(source_nhwc, kc)
 
 
@@ -78,8 +88,7 @@ class JBUStack(nn.Module):
         x = to_nhwc_bf16(source)
         guidance = guidance.float().contiguous()
         for up in (self.up1, self.up2, self.up3, self.up4):
-            small = ops.adaptive_avg_pool(guidance, x.shape[1] * 2, x.shape[2] * 2)
-            x = up.run(x, small)
+            x = up.run(x, guidance)
         return nchw_view(x)
 
     def fixup_affine(self):
@@ -93,8 +102,7 @@ class JBUStack(nn.Module):
         x = to_nhwc_bf16(source)
         guidance = guidance.float().contiguous()
         for up in (self.up1, self.up2, self.up3, self.up4):
-            small = ops.adaptive_avg_pool(guidance, x.shape[1] * 2, x.shape[2] * 2)
-            x = up.run(x, small)
+            x = up.run(x, guidance)
         conv = self.fixup_proj[1]
         w, b = self._packed.get((conv.weight, conv.bias),
                                 lambda: (conv.weight.detach().flatten(1).to(BF16).contiguous(),

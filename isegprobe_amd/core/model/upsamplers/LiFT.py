@@ -18,6 +18,7 @@ import torch.nn as nn
 from .... import hip_ops as ops
 from ...utils.log import logger
 from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16
+from .._guidance_cache import GuidanceCache
 from . import BaseUpsampler
 
 
@@ -73,6 +74,7 @@ class LiFTUpsampler(BaseUpsampler):
         else:
             logger.info("LiFTUpsampler: no checkpoint at lift_path, keeping random init")
         self._packed = PackedCache()
+        self._gcache = GuidanceCache()
 
     def packed(self):
         def build():
@@ -110,7 +112,7 @@ class LiFTUpsampler(BaseUpsampler):
             ob[:C] = L.outc.bias.detach().float()
             P["out_w"], P["out_b"] = ow.to(BF16).contiguous(), ob
             return P
-        params = list(self.lift.parameters()) + [b for n, b in self.lift.named_buffers() if "running" in n]
+        params = self._packed.tensors_of(lambda: list(self.lift.parameters()) + [b for n, b in self.lift.named_buffers() if "running" in n])
         return self._packed.get(params, build)
 
     def forward(self, source, guidance):
@@ -120,10 +122,12 @@ class LiFTUpsampler(BaseUpsampler):
         x = to_nhwc_bf16(source)
         B, h, w, C = x.shape
         g = guidance.float().contiguous()
-        i1 = ops.conv3x3_s2_c32(g, P["ic1a_w"], P["ic1a_b"])
-        i1 = ops.conv3x3_s2_c32(i1, P["ic1b_w"], P["ic1b_b"])
-        i1 = ops.adaptive_max_pool_nhwc(i1, 2 * h, 2 * w)                    # [B,2h,2w,32]
-        i2 = ops.conv3x3_s2_c32(i1, P["ic2_w"], P["ic2_b"])                   # [B,h,w,32]
+        def pyramid():  # image-only (LiFT.py:109-111): reused across clicks while the image is unchanged
+            a = ops.conv3x3_s2_c32(g, P["ic1a_w"], P["ic1a_b"])
+            a = ops.conv3x3_s2_c32(a, P["ic1b_w"], P["ic1b_b"])
+            a = ops.adaptive_max_pool_nhwc(a, 2 * h, 2 * w)                   # [B,2h,2w,32]
+            return a, ops.conv3x3_s2_c32(a, P["ic2_w"], P["ic2_b"])            # [B,h,w,32]
+        i1, i2 = self._gcache.get(g, id(P), ("pyr", h, w), pyramid)
         xin = torch.zeros(B, h, w, P["cu_in_p"], device=x.device, dtype=BF16)  # cat([x, imgs_2]) + zero pad
         xin[..., :C] = x
         xin[..., C:C + 32] = i2

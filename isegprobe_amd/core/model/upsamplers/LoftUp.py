@@ -27,6 +27,7 @@ import torch.nn as nn
 from .... import hip_ops as ops
 from ...utils.log import logger
 from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16
+from .._guidance_cache import GuidanceCache
 from . import BaseUpsampler
 
 
@@ -130,6 +131,7 @@ class LoftUpUpsampler(BaseUpsampler):
         super().__init__()
         self.upsampler = load_loftup_checkpoint(upsampler_path, n_dim, lr_pe_type, lr_size)
         self._packed = PackedCache()
+        self._gcache = GuidanceCache()
         self._pe_cache = {}
 
     # ---- weight packing (bf16, padded, BN folded)
@@ -206,7 +208,7 @@ class LoftUpUpsampler(BaseUpsampler):
             P["fln_w"], P["fln_b"], P["fln_eps"] = f32(lu.final_conv[1].weight), f32(lu.final_conv[1].bias), lu.final_conv[1].eps
             self._pe_cache.clear()
             return P
-        params = list(self.upsampler.parameters()) + [b for n, b in self.upsampler.named_buffers() if "running" in n]
+        params = self._packed.tensors_of(lambda: list(self.upsampler.parameters()) + [b for n, b in self.upsampler.named_buffers() if "running" in n])
         return self._packed.get(params, build)
 
     def _lr_pe(self, h, w, device):
@@ -247,19 +249,25 @@ class LoftUpUpsampler(BaseUpsampler):
         kv[:, :, :C] = ops.layernorm(src.view(-1, C), P["cn_w"], P["cn_b"], P["cn_eps"]).view(B, T, C)
         kv[:, :, C:c] = self._lr_pe(h, w, src.device)
         kv = kv.view(B * T, cp)
-        # ---- queries: Fourier features -> ChannelNorm -> 2 x (conv3x3 + folded BN + ReLU)
-        mm = ops.minmax_nchw(guidance)
-        x = ops.loftup_fourier_cn(guidance, mm, P["freqs"], P["bias_sin"], P["bias_cos"], P["fc_cn_w"], P["fc_cn_b"],
-                                  P["fin_p"], P["fc_cn_eps"])
-        x = ops.conv3x3(x, P["conv1_w"], P["conv1_b"], "relu")
-        x = ops.conv3x3(x, P["conv2_w"], P["conv2_b"], "relu").view(M, cp)
+        # ---- queries: Fourier features -> ChannelNorm -> 2 x (conv3x3 + folded BN + ReLU).  Guidance-only: the
+        # click loop reuses them (and the first layer's query projection) while the image is unchanged.
+        def image_queries():
+            mm = ops.minmax_nchw(guidance)
+            f = ops.loftup_fourier_cn(guidance, mm, P["freqs"], P["bias_sin"], P["bias_cos"], P["fc_cn_w"], P["fc_cn_b"],
+                                      P["fin_p"], P["fc_cn_eps"])
+            f = ops.conv3x3(f, P["conv1_w"], P["conv1_b"], "relu")
+            return ops.conv3x3(f, P["conv2_w"], P["conv2_b"], "relu").view(M, cp)
+        x = self._gcache.get(guidance, id(P), "x0", image_queries)
         scale = P["hd"] ** -0.5
         if save is not None:
             save.update(kv=kv, layers=[], geom=(B, h, w, C, H, W))
-        for L in P["layers"]:
-            qn = ops.layernorm(x, L["nq_w"], L["nq_b"], L["nq_eps"], D=c, ld_out=cp)
+        for li, L in enumerate(P["layers"]):
+            def project_q(x=x, L=L):
+                qn = ops.layernorm(x, L["nq_w"], L["nq_b"], L["nq_eps"], D=c, ld_out=cp)
+                return ops.linear(qn, L["wq"], L["bq"]).view(B, H * W, heads, hdp)
+            # the first layer's queries see the image only (x is still x0)
+            q = self._gcache.get(guidance, id(P), "q0", project_q) if li == 0 else project_q()
             kn = ops.layernorm(kv, L["nkv_w"], L["nkv_b"], L["nkv_eps"], D=c, ld_out=cp)
-            q = ops.linear(qn, L["wq"], L["bq"]).view(B, H * W, heads, hdp)
             k = ops.linear(kn, L["wk"], L["bk"]).view(B, T, heads, hdp)
             v = ops.linear(kn, L["wv"], L["bv"]).view(B, T, heads, hdp)
             if save is None:

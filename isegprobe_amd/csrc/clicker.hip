@@ -25,37 +25,60 @@ __device__ __forceinline__ bool in_mask(int m, unsigned char pred, unsigned char
     return m == 0 ? (gt && !pred && ni) : (!gt && pred && ni);  // 0: false negatives, 1: false positives
 }
 
-__global__ __launch_bounds__(256) void clicker_columns_kernel(const unsigned char* __restrict__ pred,
-                                                              const unsigned char* __restrict__ gt,
-                                                              const unsigned char* __restrict__ ni, int* __restrict__ g,
-                                                              unsigned long long* __restrict__ keys,
-                                                              int* __restrict__ counts, int H, int W) {
+// One thread per column, both masks at once.  The scan is a serial chain over rows, so the byte loads of
+// CH rows are issued together into registers before the chain consumes them (otherwise every row costs one
+// full memory latency: 447 us for 480 x 640 before, vs the ~10 us the traffic needs).
+__global__ __launch_bounds__(64) void clicker_columns_kernel(const unsigned char* __restrict__ pred,
+                                                             const unsigned char* __restrict__ gt,
+                                                             const unsigned char* __restrict__ ni, int* __restrict__ g,
+                                                             int* __restrict__ counts, int H, int W) {
+    constexpr int CH = 16;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int m = blockIdx.y;
     if (x >= W) return;
-    int* gm = g + (size_t)m * H * W;
-    int d = 0, inter = 0, uni = 0;
-    for (int y = 0; y < H; ++y) {  // distance to the nearest zero above (virtual zero row at y = -1)
-        const size_t i = (size_t)y * W + x;
-        const unsigned char p = pred[i], t = gt[i], n = ni ? ni[i] : 1;
-        d = in_mask(m, p, t, n) ? d + 1 : 0;
-        gm[i] = d;
-        if (m == 0) {
-            inter += (p && t && n);
-            uni += ((p || t) && n);
+    int* g0 = g;                      // false negatives
+    int* g1 = g + (size_t)H * W;      // false positives
+    int d0 = 0, d1 = 0, inter = 0, uni = 0;
+    for (int yb = 0; yb < H; yb += CH) {  // distance to the nearest zero above (virtual zero row at y = -1)
+        unsigned char p[CH], t[CH], n[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int y = yb + k < H ? yb + k : H - 1;
+            const size_t i = (size_t)y * W + x;
+            p[k] = pred[i], t[k] = gt[i], n[k] = ni ? ni[i] : 1;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (yb + k >= H) break;
+            const size_t i = (size_t)(yb + k) * W + x;
+            d0 = in_mask(0, p[k], t[k], n[k]) ? d0 + 1 : 0;
+            d1 = in_mask(1, p[k], t[k], n[k]) ? d1 + 1 : 0;
+            g0[i] = d0;
+            g1[i] = d1;
+            inter += (p[k] && t[k] && n[k]);
+            uni += ((p[k] || t[k]) && n[k]);
         }
     }
-    d = 0;
-    for (int y = H - 1; y >= 0; --y) {  // ... and below (virtual zero row at y = H)
-        const size_t i = (size_t)y * W + x;
-        const int up = gm[i];
-        d = up ? d + 1 : 0;
-        gm[i] = up < d ? up : d;
+    d0 = d1 = 0;
+    for (int yb = H - 1; yb >= 0; yb -= CH) {  // ... and below (virtual zero row at y = H)
+        int u0[CH], u1[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int y = yb - k >= 0 ? yb - k : 0;
+            const size_t i = (size_t)y * W + x;
+            u0[k] = g0[i], u1[k] = g1[i];
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (yb - k < 0) break;
+            const size_t i = (size_t)(yb - k) * W + x;
+            d0 = u0[k] ? d0 + 1 : 0;
+            d1 = u1[k] ? d1 + 1 : 0;
+            g0[i] = u0[k] < d0 ? u0[k] : d0;
+            g1[i] = u1[k] < d1 ? u1[k] : d1;
+        }
     }
-    if (m == 0) {
-        atomicAdd(counts, inter);
-        atomicAdd(counts + 1, uni);
-    }
+    atomicAdd(counts, inter);
+    atomicAdd(counts + 1, uni);
 }
 
 __global__ __launch_bounds__(256) void clicker_rows_kernel(const int* __restrict__ g,
@@ -151,8 +174,8 @@ extern "C" int isp_robot_click(const void* pred, const void* gt, const void* not
     unsigned long long* keys = (unsigned long long*)((char*)workspace + 2L * H * W * 4);
     int* counts = (int*)(keys + 2);
     if (hipMemsetAsync(keys, 0, 32, s) != hipSuccess) return ISP_ERR_LAUNCH;
-    clicker_columns_kernel<<<dim3((W + 255) / 256, 2), 256, 0, s>>>((const unsigned char*)pred, (const unsigned char*)gt,
-                                                                    (const unsigned char*)not_ignore, g, keys, counts, H, W);
+    clicker_columns_kernel<<<(W + 63) / 64, 64, 0, s>>>((const unsigned char*)pred, (const unsigned char*)gt,
+                                                        (const unsigned char*)not_ignore, g, counts, H, W);
     clicker_rows_kernel<<<dim3(H, 2), 256, 0, s>>>(g, (const unsigned char*)not_clicked, keys, H, W);
     clicker_decide_kernel<<<1, 64, 0, s>>>(keys, counts, W, out);
     return isp_launch_status();

@@ -15,7 +15,9 @@ BF16 = torch.bfloat16
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the caller's current stream (graph capture included); the raw accessor is ~8x cheaper than
+    # torch.cuda.current_stream() and this runs once per launch
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _p(t):

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     text = open(os.path.join(ROOT, "include", "isegprobe_hip.h")).read()
-    return sorted(set(re.findall(r"^int\s+(isp_\w+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|long)\s+(isp_\w+)\s*\(", text, flags=re.M)))
 
 
 def test_header_symbols_are_exported_and_bound():

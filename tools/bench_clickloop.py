@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Per-click time of the NoC loop (flip pair, zoom-in at S^2) for one synthetic image: device clicker,
+guidance cache on/off via ISEGPROBE_NO_GUIDANCE_CACHE.  usage: bench_clickloop.py [upsampler] [S]"""
+import logging
+import os
+import sys
+import time
+import numpy as np
+import torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+logging.getLogger("root").setLevel(logging.WARNING)
+from helpers import S14, build_model, seeded_
+from isegprobe_amd.core.inference.evaluation import evaluate_sample
+from isegprobe_amd.core.inference.predictors import get_predictor
+
+up = sys.argv[1] if len(sys.argv) > 1 else "jbu_featup"
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 448
+params = {"jbu_featup": {"backbone_type": "dinov2"}, "loftup": {"upsampler_path": None, "n_dim": 384},
+          "lift": {"lift_path": None, "n_dim": 384, "patch": 14}}.get(up)
+model = seeded_(build_model(up, vit=S14, img=(S, S), upsampler_params=params), 1).cuda().eval()
+rng = np.random.default_rng(0)
+image = rng.integers(0, 255, (480, 640, 3), dtype=np.uint8)
+yy, xx = np.mgrid[:480, :640]
+gt = (((yy - 240) / 150) ** 2 + ((xx - 300) / 200) ** 2 <= 1).astype(np.int32)
+predictor = None
+for rep in range(3):
+    predictor = predictor or get_predictor(model, "NoBRS", torch.device("cuda"), prob_thresh=0.5,
+                              zoom_in_params={"skip_clicks": -1, "target_size": (S, S)},
+                              predictor_params={"hip_graphs": bool(int(os.environ.get("ISEGPROBE_HIP_GRAPHS", "0")))})
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    clicks, ious, _ = evaluate_sample(image, gt, predictor, max_iou_thr=1.01, pred_thr=0.5, max_clicks=20)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print(f"{up} {S}x{S} graphs={os.environ.get('ISEGPROBE_HIP_GRAPHS', '0')} cache={'off' if os.environ.get('ISEGPROBE_NO_GUIDANCE_CACHE') else 'on'}: "
+      f"{dt / len(ious) * 1e3:.2f} ms/click over {len(ious)} clicks")
