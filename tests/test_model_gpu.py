@@ -102,6 +102,38 @@ def test_s14_bilinear_vs_oracle(size, B):
     assert _mask_agreement(y, ref) == 1.0
 
 
+@pytest.mark.parametrize("up,size,params", [
+    ("jbu_featup", 448, {"backbone_type": "dinov2"}),                 # BASELINE configs[1] = the bench workload
+    ("loftup", 224, {"upsampler_path": None, "n_dim": 384}),           # configs[2] at the reference's crop size
+    ("lift", 224, {"lift_path": None, "n_dim": 384, "patch": 14})])
+def test_s14_learned_upsamplers_vs_oracle(up, size, params):
+    """Full-size DINOv2-S/14 + {FeatUp JBU @448^2, LoftUp @224^2, LiFT @224^2} + ConvSegHead(384,2,1), seeded
+    weights, one image, against the CPU oracle: north_star's bf16 gate |hip - ref| <= 1e-2 + 1e-2 |ref| and
+    identical masks away from the threshold."""
+    from oracle import model as omodel
+    model = build_model(up, vit=S14, img=(size, size), upsampler_params=params)
+    seeded_(model, 321)
+    with torch.no_grad():
+        model.backbone.model.pos_embed.mul_(0.3)
+    w = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(11)
+    image = torch.rand(1, 4, size, size)
+    image[:, 3] = (image[:, 3] > 0.8).float()
+    points = torch.from_numpy(rand_points(np.random.default_rng(11), 1, 24, size, size))
+    cfg = dict(patch=14, depth=12, heads=6, upsampler=up, injection="before_backbone",
+               with_prev_mask=True, use_disks=True, norm_radius=5)
+    torch.set_num_threads(16)
+    ref = omodel.forward(image, points, w, cfg)
+    with torch.no_grad():
+        y = model.cuda()(image.cuda(), points.cuda())["instances"].cpu()
+    err = (y - ref).abs()
+    print(f"S/14+{up}@{size}: max|logit err| = {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g}, "
+          f"logit range = {ref.min():.3f}..{ref.max():.3f} rms {ref.pow(2).mean().sqrt():.3f}, "
+          f"mask agreement {_mask_agreement(y, ref):.6f}")
+    assert _close(y, ref), err.max().item()
+    assert _mask_agreement(y, ref) == 1.0
+
+
 @pytest.mark.parametrize("fold", [True, False])
 def test_tiny_jbu_model_vs_oracle(fold):
     """DINOv2(tiny) + FeatUp JBU + ConvSegHead vs the oracle, with and without folding the JBU
