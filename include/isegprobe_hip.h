@@ -222,6 +222,10 @@ int isp_fuse_flip_sigmoid(const float* logits, float* probs, long n, int H, int 
  * isp_conv3x3_nhwc_bf16 with the 180-degree rotated, transposed weights. */
 int isp_tn_gemm_bf16_atomic(const void* P, long ldp, const void* Q, long ldq, float* out, long ldo, long M, int N, int J,
                             int shift_H, int shift_W, int shift_dy, int shift_dx, int splits, void* stream);
+/* dW[n][(ky*3+kx)*C + c] += sum_pixels g[b,y,x,n] * x[b,y+ky-1,x+kx-1,c]: the 3x3 conv weight gradient with all nine
+ * taps formed from one staged input patch (g [B,H,W,N], x [B,H,W,C] bf16 NHWC; dW fp32 [N][9*C], caller-zeroed,
+ * fp32 atomics).  Autograd of ConvModule.conv.weight, heads/conv_heads.py:51-73 under trainer.py:219-226. */
+int isp_conv3x3_wgrad_bf16_atomic(const void* g, const void* x, float* dw, int B, int H, int W, int C, int N, void* stream);
 int isp_relu_mask_colsum(const void* dy, const void* y, void* g, float* colsum, long M, int N, void* stream);
 /* dx_colsum (nullable, [C], caller-zeroed): += column sums of dx = bias gradient of the conv that produced x */
 int isp_classifier_bwd(const float* grad_logits, const void* x, const float* w, void* dx, float* dw, float* db,

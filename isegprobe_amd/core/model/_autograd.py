@@ -43,9 +43,7 @@ def _conv3x3_grads(x, g, weight, need_dx):
     B, H, W, C = x.shape
     N = weight.shape[0]
     M = B * H * W
-    dw = torch.zeros(N, 9 * C, device=x.device, dtype=torch.float32)
-    for t in range(9):  # one pixel-reduction GEMM per tap, implicit im2col of x
-        ops.tn_gemm_atomic(g.view(M, N), x.view(M, C), dw[:, t * C:(t + 1) * C], shift=(H, W, t // 3 - 1, t % 3 - 1))
+    dw = ops.conv3x3_wgrad(g, x)  # all nine taps from one staged patch per 8x8-pixel tile
     dweight = dw.view(N, 3, 3, C).permute(0, 3, 1, 2).contiguous()
     dx = None
     if need_dx:  # data gradient = the same conv kernel with rotated, transposed weights

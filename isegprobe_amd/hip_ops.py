@@ -604,6 +604,21 @@ def tn_gemm_atomic(P, Q, out, shift=None, splits=None):
     return out
 
 
+def conv3x3_wgrad(g, x):
+    """Weight gradient of conv3x3 (stride 1, pad 1): g [B,H,W,N], x [B,H,W,C] bf16 NHWC -> [N, 9*C] f32 in the
+    layout of conv.weight.permute(0,2,3,1) (all nine taps from one staged input patch per 8x8 pixel tile)."""
+    _need(g, BF16, "g")
+    _need(x, BF16, "x")
+    B, H, W, N = g.shape
+    C = x.shape[3]
+    if x.shape[:3] != g.shape[:3]:
+        raise IspError("conv3x3_wgrad: g and x must share [B,H,W]")
+    dw = torch.zeros(N, 9 * C, device=g.device, dtype=torch.float32)
+    check(_lib.lib().isp_conv3x3_wgrad_bf16_atomic(_p(g), _p(x), _p(dw), B, H, W, C, N, _stream()),
+          "isp_conv3x3_wgrad_bf16_atomic")
+    return dw
+
+
 def relu_mask_colsum(dy, y, want_colsum=True):
     _need(dy, BF16, "dy")
     _need(y, BF16, "y")

@@ -62,9 +62,30 @@ def test_conv_wgrad_dgrad_vs_autograd(ops, B, H, W, C, N):
         ops.tn_gemm_atomic(g.view(M, N), x_n.view(M, C), dw[:, t * C:(t + 1) * C], shift=(H, W, t // 3 - 1, t % 3 - 1))
     dw_ref = w.grad.permute(0, 2, 3, 1).reshape(N, 9 * C)
     assert rel(dw, dw_ref) < 1e-2
+    dw9 = ops.conv3x3_wgrad(g, x_n)  # all nine taps from one staged 10x10 patch per 8x8 tile
+    assert rel(dw9, dw_ref) < 1e-2
     w_rot = w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * N).to(BF).contiguous()  # [C][ky][kx][N]
     dx = ops.conv3x3(g, w_rot, None, None)
     assert rel(dx.permute(0, 3, 1, 2), x.grad) < 1e-2
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(1, 8, 8, 64, 128), (2, 19, 13, 72, 40), (1, 64, 72, 384, 384)])
+def test_conv_wgrad_fused_taps_asymmetric(ops, B, H, W, C, N):
+    """Structured (non-random) operands so that a transposed fragment, a wrong tap shift or a wrong tile
+    origin gives an O(1) error: g is one-hot per pixel in a pixel-dependent channel, x a smooth ramp.
+    Sizes include ragged spatial tiles (19x13) and channel counts that are not tile multiples (72, 40)."""
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+    g = torch.zeros(B, H, W, N, device="cuda")
+    for b in range(B):
+        g[b].view(H * W, N)[torch.arange(H * W, device="cuda"), ((ys * 7 + xs * 3 + b) % N).flatten()] = 1.0
+    x = ((ys * 5 + xs * 11)[None, :, :, None] % 23 + torch.arange(C, device="cuda")[None, None, None, :] % 7 - 12).float() / 8
+    x = x.expand(B, H, W, C).contiguous()
+    dw = ops.conv3x3_wgrad(g.to(BF), x.to(BF))
+    xr = x.permute(0, 3, 1, 2).contiguous()
+    wr = torch.zeros(N, C, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(xr, wr, padding=1).backward(g.permute(0, 3, 1, 2).contiguous())
+    ref = wr.grad.permute(0, 2, 3, 1).reshape(N, 9 * C)
+    assert rel(dw, ref) < 2e-3
 
 
 @pytest.mark.parametrize("M,C", [(5000, 128), (777, 384), (4099, 24), (1000, 1024)])
