@@ -116,10 +116,14 @@ class LiFTUpsampler(BaseUpsampler):
         return self._packed.get(params, build)
 
     def forward(self, source, guidance):
-        self._refuse_source_grad(source)
         """LiFT(imgs=guidance, x=source) (LiFT.py:106-122, :145-146) -> [B, C, 2h, 2w]."""
-        P = self.packed()
         x = to_nhwc_bf16(source)
+        if torch.is_grad_enabled() and x.requires_grad:  # training with clicks injected before the upsampler
+            return nchw_view(_LiFTFn.apply(x, guidance, self))
+        return nchw_view(self._run(x, guidance, None))
+
+    def _run(self, x, guidance, save):
+        P = self.packed()
         B, h, w, C = x.shape
         g = guidance.float().contiguous()
         def pyramid():  # image-only (LiFT.py:109-111): reused across clicks while the image is unchanged
@@ -136,7 +140,57 @@ class LiFTUpsampler(BaseUpsampler):
         cat = torch.zeros(B, 2 * h, 2 * w, P["cat_p"], device=x.device, dtype=BF16)
         cat.view(B, h, 2, w, 2, P["cat_p"])[..., :n] = up.view(B, h, w, 2, 2, n).permute(0, 1, 3, 2, 4, 5)  # pixel shuffle
         cat[..., n:n + 32] = i1
-        y = ops.conv3x3(cat, P["dc1_w"], P["dc1_b"], "relu")
-        y = ops.conv3x3(y, P["dc2_w"], P["dc2_b"], "relu")
-        out = ops.linear(y.view(-1, P["half_p"]), P["out_w"], P["out_b"])
-        return nchw_view(out.view(B, 2 * h, 2 * w, -1)[..., :C])
+        y1 = ops.conv3x3(cat, P["dc1_w"], P["dc1_b"], "relu")
+        y2 = ops.conv3x3(y1, P["dc2_w"], P["dc2_b"], "relu")
+        out = ops.linear(y2.view(-1, P["half_p"]), P["out_w"], P["out_b"])
+        if save is not None:
+            save.update(y1=y1, y2=y2)
+        return out.view(B, 2 * h, 2 * w, -1)[..., :C]
+
+    def _bwd_weights(self):
+        P = self.packed()
+        if "bwd" not in P:
+            def rot(wt, cin_p):  # forward [Np][ky][kx][Cp] -> data-gradient conv weights [Cp][2-ky][2-kx][Np]
+                npad = wt.shape[0]
+                return wt.view(npad, 3, 3, cin_p).flip(1, 2).permute(3, 1, 2, 0).reshape(cin_p, 9 * npad).contiguous()
+            t = lambda w: w.float().t().contiguous().to(BF16)
+            P["bwd"] = dict(out=t(P["out_w"]), dc2=rot(P["dc2_w"], P["half_p"]), dc1=rot(P["dc1_w"], P["cat_p"]),
+                            up=t(P["up_w"]))
+        return P["bwd"]
+
+    def _backward(self, saved, g_out, h, w):
+        """d out / d source applied to g_out [B,2h,2w,C] bf16 (frozen weights; eval BatchNorm is folded, so the
+        chain is 1x1 conv^T -> [ReLU mask, 3x3 conv^T] x 2 -> pixel un-shuffle -> ConvTranspose^T; LiFT.py:30-44,113-122)."""
+        P, Wt = self.packed(), self._bwd_weights()
+        B, C, n = g_out.shape[0], P["C"], P["cu_out"]
+        M = B * 4 * h * w
+        cpad = P["out_w"].shape[0]
+        if cpad != C:
+            gp = torch.zeros(M, cpad, device=g_out.device, dtype=BF16)
+            gp[:, :C] = g_out.reshape(M, C)
+        else:
+            gp = g_out.reshape(M, C).contiguous()
+        g2, _ = ops.relu_mask_colsum(ops.linear(gp, Wt["out"]), saved["y2"].view(M, -1), want_colsum=False)
+        g1 = ops.conv3x3(g2.view(B, 2 * h, 2 * w, -1), Wt["dc2"], None, None)
+        g1, _ = ops.relu_mask_colsum(g1.view(M, -1), saved["y1"].view(M, -1), want_colsum=False)
+        g_cat = ops.conv3x3(g1.view(B, 2 * h, 2 * w, -1), Wt["dc1"], None, None)          # [B,2h,2w,cat_p]
+        g_up = g_cat.view(B, h, 2, w, 2, -1)[..., :n].permute(0, 1, 3, 2, 4, 5).reshape(B * h * w, 4 * n).contiguous()
+        g_xin = ops.linear(g_up, Wt["up"])                                                 # [B*h*w, cu_in_p]
+        return g_xin.view(B, h, w, -1)[..., :C].contiguous()
+
+
+class _LiFTFn(torch.autograd.Function):
+    """LiFTUpsampler as one autograd node: gradient w.r.t. the LR features only (frozen weights)."""
+
+    @staticmethod
+    def forward(ctx, src, guidance, module):
+        saved = {}
+        out = module._run(src.detach(), guidance.detach(), saved)
+        ctx.module, ctx.saved, ctx.hw = module, saved, src.shape[1:3]
+        return out.contiguous()
+
+    @staticmethod
+    def backward(ctx, g_out):
+        g = ctx.module._backward(ctx.saved, g_out.contiguous(), *ctx.hw)
+        ctx.saved = None
+        return g, None, None

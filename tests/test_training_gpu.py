@@ -60,7 +60,7 @@ def test_gradients_vs_oracle_autograd():
     assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
 
 
-@pytest.mark.parametrize("upsampler", ["bilinear", "identity", "loftup"])
+@pytest.mark.parametrize("upsampler", ["bilinear", "identity", "loftup", "lift"])
 def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
     """The reference's default training mode (models/sbd/dinov2/patch-embed_*.py:40): the click
     patch-embedding gets its gradient through both frozen ViT blocks (attention, LayerNorm, GELU
@@ -103,9 +103,9 @@ def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
     assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
 
 
-@pytest.mark.parametrize("upsampler", ["lift", "jbu_featup"])
-def test_before_backbone_training_through_lift_and_jbu_is_refused(upsampler):
-    """No backward exists for LiFT / FeatUp JBU: asking for it must raise, not return zeros."""
+@pytest.mark.parametrize("upsampler", ["jbu_featup"])
+def test_before_backbone_training_through_jbu_is_refused(upsampler):
+    """No backward exists for FeatUp JBU: asking for it must raise, not return zeros."""
     model = build_model(upsampler, injection="before_backbone", upsampler_params=UP_PARAMS[upsampler]).cuda().train()
     image, points = torch.rand(1, 4, 56, 56).cuda(), torch.tensor([[[5., 5., 0.], [-1., -1., -1.]]]).cuda()
     with pytest.raises(NotImplementedError):
