@@ -251,6 +251,17 @@ int isp_robot_click(const void* pred, const void* gt, const void* not_ignore, co
 /* mask[i] = probs[i] > thr (uint8), evaluation.py:74 */
 int isp_threshold_u8(const float* probs, void* mask, float thr, long n, void* stream);
 
+/* ---- Train-time click simulation on the device: get_next_points, core/training/
+ * trainer.py:575-618.  pred [B,1,H,W] f32 probabilities, gt [B,1,H,W] f32 (> 0.5 = object), points [B,2P,3] f32
+ * updated IN PLACE at slot (P - click_indx) for a positive / (2P - click_indx) for a negative click with
+ * (row, col, click_indx); rand32 [B] uint32 (device) = the caller's uniform draw, index = (rand32 * n) >> 32 among the
+ * n pixels with dt > max/2 in row-major order (the reference: np.random.randint(0, n)).  dt = OpenCV's 5x5 chamfer
+ * DIST_L2 transform (16.16 fixed point, costs 1 / 1.4 / 2.1969) of the zero-padded FN / FP masks.  H + 2 <= 1024.
+ * workspace: isp_next_points_workspace_bytes(B, H, W) bytes.  No host synchronisation. */
+long isp_next_points_workspace_bytes(int B, int H, int W);
+int isp_next_points(const float* pred, const float* gt, float* points, const unsigned* rand32, int B, int H, int W, int P,
+                    int click_indx, float pred_thresh, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

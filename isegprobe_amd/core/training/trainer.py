@@ -9,41 +9,30 @@
 The reference wraps the net in DistributedDataParallel; here the collective is explicit and sits
 between backward and the optimizer step, on the gradient step only.  Dataset readers, augmentation,
 samplers, logging and checkpoint cadence are outside this path.
-Click simulation: the reference picks a random interior point of the largest error region using
-OpenCV's 5x5 chamfer distance transform; OpenCV is not a dependency, so the exact Euclidean
-transform (scipy) is used -- the sampled point differs, the training signal is the same in kind."""
+Click simulation (get_next_points) runs on the device: OpenCV's 5x5 chamfer DIST_L2 transform (the
+reference's cv2.distanceTransform(mask, DIST_L2, 5)) restated as a wavefront kernel, polarity choice and
+uniform draw included -- no device->host copy per simulated click."""
 import random
 from typing import Dict
 
 import numpy as np
 import torch
-from scipy.ndimage import distance_transform_edt
 
+from ... import hip_ops as ops
 from ..utils import distributed as D
 from .losses import NormalizedFocalLossSigmoid
 
 
-def get_next_points(pred, gt, points, click_indx, pred_thresh=0.49, rng=np.random):
-    """trainer.py:577-618: add one corrective click per sample at slot (num_points - click_indx)."""
-    assert click_indx > 0
-    pred = pred.detach().float().cpu().numpy()[:, 0]
-    gt = gt.detach().cpu().numpy()[:, 0] > 0.5
-    fn_mask = np.pad(np.logical_and(gt, pred < pred_thresh), ((0, 0), (1, 1), (1, 1)), "constant")
-    fp_mask = np.pad(np.logical_and(~gt, pred > pred_thresh), ((0, 0), (1, 1), (1, 1)), "constant")
-    num_points = points.size(1) // 2
-    points = points.clone()
-    for b in range(fn_mask.shape[0]):
-        fn_dt = distance_transform_edt(fn_mask[b])[1:-1, 1:-1]
-        fp_dt = distance_transform_edt(fp_mask[b])[1:-1, 1:-1]
-        fn_max, fp_max = fn_dt.max(), fp_dt.max()
-        is_positive = fn_max > fp_max
-        dt = fn_dt if is_positive else fp_dt
-        indices = np.argwhere(dt > max(fn_max, fp_max) / 2.0)
-        if len(indices) > 0:
-            r, c = indices[rng.randint(0, len(indices))]
-            slot = (num_points if is_positive else 2 * num_points) - click_indx
-            points[b, slot, 0], points[b, slot, 1], points[b, slot, 2] = float(r), float(c), float(click_indx)
-    return points
+def get_next_points(pred, gt, points, click_indx, pred_thresh=0.49, rng=np.random, workspace=None):
+    """Train-time click simulation (trainer.py:575-618) on the device: FN / FP masks of `pred`, OpenCV's 5x5
+    chamfer DIST_L2 transform of the zero-padded masks, larger maximum picks the polarity, uniform draw among the
+    pixels with dt > max/2.  Nothing is copied to the host; the only host work is drawing one 32-bit integer per
+    sample from `rng` (where the reference calls np.random.randint(0, n) once it knows n)."""
+    if not pred.is_cuda:
+        raise RuntimeError("get_next_points runs on the GPU (no CPU fallback)")
+    draws = torch.from_numpy(rng.randint(0, 2 ** 32, size=pred.shape[0], dtype=np.int64))
+    out, _ = ops.next_points(pred, gt, points, click_indx, draws, pred_thresh, workspace)
+    return out
 
 
 class DataParallelTrainer:

@@ -682,3 +682,24 @@ def robot_click(pred, gt, not_ignore, not_clicked, workspace=None):
     check(_lib.lib().isp_robot_click(_p(pred), _p(gt), _p(not_ignore) if not_ignore is not None else None,
                                      _p(not_clicked), H, W, _p(workspace), _p(out), _stream()), "isp_robot_click")
     return out, workspace
+
+
+def next_points(pred, gt, points, click_indx, rand32, pred_thresh=0.49, workspace=None):
+    """Device get_next_points (trainer.py:575-618): returns an updated CLONE of points [B,2P,3] and the workspace.
+    pred / gt [B,1,H,W] f32 on the GPU, rand32 [B] int64/uint32-valued tensor (the uniform draws)."""
+    pred = _need(pred.contiguous(), torch.float32, "pred")
+    gt = _need(gt.float().contiguous(), torch.float32, "gt")
+    points = _need(points.clone().contiguous(), torch.float32, "points")
+    B, _, H, W = pred.shape
+    if gt.shape != pred.shape or points.shape[0] != B or points.shape[2] != 3 or points.shape[1] % 2:
+        raise IspError("next_points: shape mismatch")
+    # low 32 bits of each draw; the kernel reinterprets the int32 storage as uint32
+    r32 = (rand32.to(device=pred.device, dtype=torch.int64) & 0xffffffff).to(torch.int32).contiguous()
+    need = _lib.lib().isp_next_points_workspace_bytes(B, H, W)
+    if need < 0:
+        check(int(need), "isp_next_points_workspace_bytes")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=pred.device, dtype=torch.uint8)
+    check(_lib.lib().isp_next_points(_p(pred), _p(gt), _p(points), _p(r32), B, H, W, points.shape[1] // 2,
+                                     int(click_indx), float(pred_thresh), _p(workspace), _stream()), "isp_next_points")
+    return points, workspace

@@ -129,3 +129,47 @@ def test_trainer_step_reduces_loss():
     assert not torch.equal(before["head.convs.0.conv.weight"], after["head.convs.0.conv.weight"])
     assert not torch.equal(before["embed_coords.proj.weight"], after["embed_coords.proj.weight"])
     assert torch.equal(before["backbone.model.blocks.0.attn.qkv.weight"], after["backbone.model.blocks.0.attn.qkv.weight"])
+
+
+# ------------------------------------------------------------------ device click simulation
+@pytest.mark.parametrize("B,H,W,P", [(2, 56, 70, 3), (3, 224, 224, 24), (1, 300, 448, 5), (2, 17, 9, 2)])
+def test_device_next_points_matches_oracle(B, H, W, P):
+    """get_next_points on the device == the oracle (C restatement of OpenCV's 5x5 chamfer transform + the
+    reference's selection logic, trainer.py:575-618) for the same uniform draws: identical points tensors.
+    16 different draws per case walk through the whole {dt > max/2} set, so every distance matters."""
+    from isegprobe_amd import hip_ops as ops
+    from oracle import click_simulation as osim
+    rng = np.random.default_rng(H * W + B)
+    yy, xx = np.mgrid[:H, :W]
+
+    def blobs(n):
+        m = np.zeros((B, 1, H, W), np.float32)
+        for b in range(B):
+            for _ in range(n):
+                cy, cx = rng.integers(0, H), rng.integers(0, W)
+                ry, rx = rng.integers(2, max(3, H // 2)), rng.integers(2, max(3, W // 2))
+                m[b, 0] += ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1
+        return np.minimum(m, 1)
+    gt = blobs(2)
+    pred = np.clip(blobs(2) * 0.8 + rng.random((B, 1, H, W)).astype(np.float32) * 0.3, 0, 1).astype(np.float32)
+    pred[0, 0, : H // 3] = gt[0, 0, : H // 3]  # a band of perfect prediction
+    points = -np.ones((B, 2 * P, 3), np.float32)
+    ws = None
+    for trial in range(16):
+        click_indx = 1 + trial % P
+        draws = rng.integers(0, 2 ** 32, size=B, dtype=np.int64)
+        if trial == 0:
+            draws[:] = 2 ** 32 - 1  # last inner pixel
+        if trial == 1:
+            draws[:] = 0            # first inner pixel
+        ref = osim.get_next_points(pred, gt, points, click_indx, draws)
+        got, ws = ops.next_points(torch.from_numpy(pred).cuda(), torch.from_numpy(gt).cuda(),
+                                  torch.from_numpy(points).cuda(), click_indx, torch.from_numpy(draws), workspace=ws)
+        assert np.array_equal(got.cpu().numpy(), ref), (trial, got.cpu().numpy(), ref)
+        points = ref
+    # a sample whose prediction is perfect has no inner pixel: its row of points must stay untouched
+    perfect = (gt > 0.5).astype(np.float32)
+    ref = osim.get_next_points(perfect, gt, points, 1, np.zeros(B, np.int64))
+    got, _ = ops.next_points(torch.from_numpy(perfect).cuda(), torch.from_numpy(gt).cuda(),
+                             torch.from_numpy(points).cuda(), 1, torch.zeros(B, dtype=torch.int64))
+    assert np.array_equal(got.cpu().numpy(), ref) and np.array_equal(ref, points)

@@ -15,6 +15,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 up = sys.argv[2] if len(sys.argv) > 2 else "bilinear"
 inj = sys.argv[3] if len(sys.argv) > 3 else "before_backbone"
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 448
+ITERS = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # simulated corrective clicks (no-grad forwards) per step
 params = {"loftup": {"upsampler_path": None, "n_dim": 384}}.get(up)
 model = seeded_(build_model(up, injection=inj, vit=S14, img=(S, S), upsampler_params=params), 1).cuda()
 torch.manual_seed(0)
@@ -25,13 +26,13 @@ points = torch.from_numpy(rand_points(np.random.default_rng(0), B, 24, S, S)).cu
 batch = {"images": image, "instances": gt, "points": points}
 trainer = DataParallelTrainer(model, lr=1e-4)
 for _ in range(2):
-    trainer.step(batch, num_iters=0)
+    trainer.step(batch, num_iters=ITERS)
 torch.cuda.synchronize()
 n = 5
 t0 = time.perf_counter()
 for _ in range(n):
-    loss = trainer.step(batch, num_iters=0)
+    loss = trainer.step(batch, num_iters=ITERS)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
-print(f"train step B={B} {up} {inj} {S}x{S}: {ms:.1f} ms/step = {B / ms * 1e3:.1f} img/s, loss {loss.item():.4f}, "
+print(f"train step B={B} {up} {inj} {S}x{S} sim-clicks={ITERS}: {ms:.1f} ms/step = {B / ms * 1e3:.1f} img/s, loss {loss.item():.4f}, "
       f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
