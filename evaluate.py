@@ -21,7 +21,9 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--dataset", default=None, help="GrabCut/Berkeley-layout directory")
+    ap.add_argument("--dataset", default=None, help="dataset root directory")
+    ap.add_argument("--dataset-name", default="GrabCut",
+                    help="reader: GrabCut | Berkeley | DAVIS | COCO_MVal | SBD | SBD_Train | PascalVOC (inference/utils.py:86-104)")
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N synthetic GrabCut-layout samples")
     ap.add_argument("--checkpoint", default=None, help="reference-format checkpoint {'state_dict','config'}")
     ap.add_argument("--arch", default="dinov2_vits14")
@@ -30,12 +32,13 @@ def main():
     ap.add_argument("--n-clicks", type=int, default=20)
     ap.add_argument("--thresh", type=float, default=0.5)
     ap.add_argument("--target-iou", type=float, default=0.90)
+    ap.add_argument("--logs", default=None, help="directory for the results table / IoU pickles (default: a temp dir)")
     ap.add_argument("--host-clicker", action="store_true",
                     help="robot user + IoU on the host (numpy/scipy) as in the reference, instead of the device clicker")
     args = ap.parse_args()
 
     import isegprobe_amd
-    from isegprobe_amd.core.inference.datasets import GrabCutLayoutDataset, write_synthetic_grabcut
+    from isegprobe_amd.core.inference.datasets import get_dataset, write_synthetic_grabcut
     from isegprobe_amd.core.inference.evaluation import evaluate_dataset
     from isegprobe_amd.core.inference.predictors import get_predictor
     from isegprobe_amd.core.inference.utils import compute_noc_metric
@@ -68,20 +71,21 @@ def main():
         args.dataset = str(write_synthetic_grabcut(tmp.name, args.synthetic))
     if not args.dataset:
         raise SystemExit("give --dataset or --synthetic N")
-    dataset = GrabCutLayoutDataset(args.dataset)
+    dataset = get_dataset(args.dataset_name, args.dataset)
     predictor = get_predictor(model, "NoBRS", device, prob_thresh=args.thresh,
                               zoom_in_params={"skip_clicks": -1, "target_size": crop})
     # print_ious=True in the reference forces all n_clicks to run (inference/utils.py:254-255)
     all_ious, elapsed = evaluate_dataset(dataset, predictor, pred_thr=args.thresh, max_iou_thr=1.01,
                                          min_clicks=1, max_clicks=args.n_clicks,
                                          device_clicker=False if args.host_clicker else None)
-    noc, noc_std, over = compute_noc_metric(all_ious, [0.8, 0.85, args.target_iou], max_clicks=args.n_clicks)
-    n_clicks_total = sum(len(x) for x in all_ious)
-    print(f"|{'Upsampler':^22}|{'Dataset':^11}|{'NoC@80%':^9}|{'NoC@85%':^9}|{'NoC@' + str(int(args.target_iou * 100)) + '%':^9}|"
-          f"{'IoU@1':^9}|{'SPC,s':^7}|{'Time':^9}|")
-    print(f"|{model.upsampler.__class__.__name__:^22}|{os.path.basename(args.dataset.rstrip('/'))[:11]:^11}|"
-          f"{noc[0]:^9.2f}|{noc[1]:^9.2f}|{noc[2]:^9.2f}|{np.mean([x[0] for x in all_ious]):^9.2f}|"
-          f"{elapsed / max(n_clicks_total, 1):^7.4f}|{str(timedelta(seconds=int(elapsed))):^9}|")
+    # the reference's table / log files (inference/utils.py:174-246,365-543); SPC printed with 4 digits as well
+    from isegprobe_amd.core.inference.utils import save_iou_analysis_data, save_results
+    logs = args.logs or tempfile.mkdtemp(prefix="isegprobe_eval_")
+    results = save_results(model.upsampler.__class__.__name__, args.dataset_name, logs, (all_ious, elapsed),
+                           eval_mode=args.eval_mode, n_clicks=args.n_clicks, target_iou=1.01, print_ious=True,
+                           save_ious=True)
+    save_iou_analysis_data(args.dataset_name, logs, (all_ious, elapsed), eval_mode=args.eval_mode, n_clicks=args.n_clicks)
+    print(f"SPC {elapsed / max(sum(len(x) for x in all_ious), 1):.4f} s; logs, IoU pickles: {logs}")
     if tmp:
         tmp.cleanup()
 

@@ -25,3 +25,101 @@ def compute_noc_metric(all_ious: List[np.ndarray], iou_thrs: List[float], max_cl
         noc_std.append(scores.std())
         over_max.append((scores == max_clicks).sum())
     return noc_list, noc_std, over_max
+
+
+def get_time_metrics(all_ious: List[np.ndarray], elapsed_time: float) -> Tuple[float, float]:
+    """Seconds per click / per image (core/inference/utils.py:149-161)."""
+    return elapsed_time / sum(map(len, all_ious)), elapsed_time / len(all_ious)
+
+
+def get_results_table(noc_list, over_max_list, brs_type, dataset_name, mean_spc, elapsed_time, iou_first, n_clicks=20,
+                      model_name=None, upsampler_type=None, single_model_eval=True):
+    """The evaluation table of the reference, column for column (core/inference/utils.py:174-246): returns
+    (header, row, metrics dict).  Log files written from it are interchangeable with the reference's."""
+    from datetime import timedelta
+    up_row = f"{upsampler_type:^20}|" if upsampler_type is not None else f'{"":^20}|'
+    first_col = f'{"BRS Type":^13}|' if single_model_eval else f'{"Ckpt":^13}|'
+    table_header = (f'|{"Upsampler Type":^20}|' + first_col + f'{"Dataset":^11}|{"NoC@80%":^9}|{"NoC@85%":^9}|{"NoC@90%":^9}|'
+                    f'{"IoU@1":^9}|{">=" + str(n_clicks) + "@85%":^9}|{">=" + str(n_clicks) + "@90%":^9}|{"SPC,s":^7}|{"Time":^9}|')
+    width = len(table_header)
+    header = f"Eval results for model: {model_name}\n" if single_model_eval and model_name is not None else ""
+    header += "-" * width + "\n" + table_header + "\n" + "-" * width
+    eval_time = str(timedelta(seconds=int(elapsed_time)))
+    q = f'{"?":^9}|'
+    row = f"|{up_row}{brs_type:^13}|{dataset_name:^11}|{noc_list[0]:^9.2f}|"
+    row += f"{noc_list[1]:^9.2f}|" if len(noc_list) > 1 else q
+    row += f"{noc_list[2]:^9.2f}|" if len(noc_list) > 2 else q
+    row += f"{iou_first:^9.2f}|"
+    row += f"{over_max_list[1]:^9}|" if len(noc_list) > 1 else q
+    row += f"{over_max_list[2]:^9}|" if len(noc_list) > 2 else q
+    row += f"{mean_spc:^7.3f}|{eval_time:^9}|"
+    metrics = {"NoC@80%": noc_list[0], "NoC@85%": noc_list[1] if len(noc_list) > 1 else -1,
+               "NoC@90%": noc_list[2] if len(noc_list) > 2 else -1,
+               f">={n_clicks}@85%": over_max_list[1] if len(noc_list) > 1 else -1,
+               f">={n_clicks}@90%": over_max_list[2] if len(noc_list) > 2 else -1, "SPC,s": mean_spc, "Time": eval_time}
+    return header, row, metrics
+
+
+def save_results(upsampler_type, dataset_name, logs_path, dataset_results, eval_mode="fixed224", mode="NoBRS", n_clicks=20,
+                 target_iou=0.90, print_ious=True, logs_prefix="", row_name="NoBRS", save_ious=False, print_header=True,
+                 single_model_eval=True):
+    """core/inference/utils.py:365-505 without the hydra config object: prints the table row (+ the per-click mIoU list
+    when print_ious), appends it to ``<logs_path>/<prefix><eval_mode>_<mode>_<n_clicks>.txt`` and optionally pickles the
+    per-object IoU arrays to ``<logs_path>/ious/<prefix>/<dataset>_<eval_mode>_<mode>_<n_clicks>.pkl``."""
+    import pickle
+    from pathlib import Path
+    logs_path = Path(logs_path)
+    all_ious, elapsed = dataset_results
+    mean_spc, _ = get_time_metrics(all_ious, elapsed)
+    thrs = np.arange(0.8, min(0.95, target_iou) + 0.001, 0.05).tolist()
+    noc, _, over = compute_noc_metric(all_ious, iou_thrs=thrs, max_clicks=n_clicks)
+    iou_first = np.array([x[0] for x in all_ious]).mean(0)
+    model_name = logs_path.stem if not logs_prefix else f"{logs_path.name}:{logs_prefix}"
+    header, row, results = get_results_table(noc, over, row_name, dataset_name, mean_spc, elapsed, iou_first, n_clicks,
+                                             model_name, upsampler_type, single_model_eval)
+    if print_ious:
+        k = min(len(x) for x in all_ious)
+        mean_ious = np.array([x[:k] for x in all_ious]).mean(axis=0)
+        row += "; " + " ".join(f"mIoU@{c}={mean_ious[c - 1]:.2%};" for c in range(1, 21) if c <= k)
+        pct = [round(float(v) * 100, 2) for v in mean_ious]
+        results.update({f"mIoU@{c}": pct[c - 1] for c in range(1, 21) if c <= k})
+        results["miou_list"] = [pct[c - 1] for c in range(1, 21) if c <= k]
+        results["clicks_list"] = [c for c in range(1, 21) if c <= k]
+    if print_header:
+        print(header)
+    print(row)
+    if save_ious:
+        d = logs_path / "ious" / (logs_prefix or "")
+        d.mkdir(parents=True, exist_ok=True)
+        with open(d / f"{dataset_name}_{eval_mode}_{mode}_{n_clicks}.pkl", "wb") as fp:
+            pickle.dump(all_ious, fp)
+    prefix = (logs_prefix + "_" + ("" if single_model_eval else f"{dataset_name}_")) if logs_prefix else ""
+    logs_path.mkdir(parents=True, exist_ok=True)
+    log = logs_path / f"{prefix}{eval_mode}_{mode}_{n_clicks}.txt"
+    if log.exists():
+        with open(log, "a") as f:
+            f.write(row + "\n")
+    else:
+        with open(log, "w") as f:
+            if print_header:
+                f.write(header + "\n")
+            f.write(row + "\n")
+    return results
+
+
+def save_iou_analysis_data(dataset_name, logs_path, dataset_results, eval_mode="fixed224", mode="NoBRS", n_clicks=20,
+                           logs_prefix="", model_name=None):
+    """The pickle plot_iou_vs_clicks consumes (core/inference/utils.py:508-543):
+    ``<logs_path>/plots/<prefix><dataset>_<eval_mode>_<mode>_<n_clicks>.pickle`` = {dataset_name, model_name, all_ious}."""
+    import pickle
+    from pathlib import Path
+    logs_path = Path(logs_path)
+    all_ious, _ = dataset_results
+    prefix = (logs_prefix + "_" if logs_prefix else "") + dataset_name + "_"
+    if model_name is None:
+        model_name = logs_path.stem if not logs_prefix else f"{logs_path.name}:{logs_prefix}"
+    path = logs_path / "plots" / f"{prefix}{eval_mode}_{mode}_{n_clicks}.pickle"
+    path.parent.mkdir(parents=True, exist_ok=True)
+    with path.open("wb") as f:
+        pickle.dump({"dataset_name": dataset_name, "model_name": f"{model_name}_{mode}", "all_ious": all_ious}, f)
+    return path

@@ -97,5 +97,5 @@ def test_grabcut_layout_reader(tmp_path):
     assert len(ds) == 3
     s = ds.get_sample(1)
     assert s.image.shape == (60, 80, 3) and s.image.dtype == np.uint8
-    m = s.gt_mask(1)
-    assert set(np.unique(m)) == {-1, 0, 1} and s.objects_ids == [1]
+    m = s.gt_mask(0)  # objects_ids are positions, as in the reference's DSample (data_sample.py:161-167)
+    assert set(np.unique(m)) == {-1, 0, 1} and s.objects_ids == [0]
