@@ -203,14 +203,22 @@ class ViTTrunkFn(torch.autograd.Function):
         attention bwd -> qkv^T -> LN bwd, accumulating into an fp32 gradient stream."""
 
     @staticmethod
-    def forward(ctx, x0, packed, heads, B, T, eps):
+    def forward(ctx, x0, packed, heads, B, T, eps, last_keys=False):
+        """last_keys: stop inside the last block and return its attention KEYS (cls dropped, channel = d*heads + head),
+        the dense feature the reference's DINO ViT featurizer uses (DINO.py:582-590, feat_type="key")."""
         L = T + 1
         x = x0.detach().clone()
         saved = []
-        for blk in packed["blocks"]:
+        nblk = len(packed["blocks"])
+        for i, blk in enumerate(packed["blocks"]):
             x_in = x.clone()
             h1 = ops.layernorm(x, blk["n1w"], blk["n1b"], eps)
             qkv = ops.linear(h1, blk["qkv_w"], blk["qkv_b"])
+            if last_keys and i == nblk - 1:
+                D = heads * 64
+                k = qkv.view(B, L, 3, heads, 64)[:, 1:, 1]
+                ctx.saved, ctx.x_final, ctx.packed, ctx.geom = saved, x_in, packed, (heads, B, T, eps, True)
+                return k.permute(0, 1, 3, 2).reshape(B * T, D).contiguous()
             att, lse = ops.attention_packed_qkv_lse(qkv, B, L, heads, 64 ** -0.5)
             ops.linear_residual_(x, att, blk["proj_w"], blk["proj_b"], blk["ls1"])
             x_mid = x.clone()
@@ -219,7 +227,7 @@ class ViTTrunkFn(torch.autograd.Function):
             ops.linear_residual_(x, hid, blk["fc2_w"], blk["fc2_b"], blk["ls2"])
             saved.append((x_in, qkv, att, lse, x_mid, pre))
         feats = ops.layernorm(x, packed["nw"], packed["nb"], eps, group_out=T, skip=1, rows_out=B * T)
-        ctx.saved, ctx.x_final, ctx.packed, ctx.geom = saved, x, packed, (heads, B, T, eps)
+        ctx.saved, ctx.x_final, ctx.packed, ctx.geom = saved, x, packed, (heads, B, T, eps, False)
         return feats
 
     @staticmethod
@@ -237,11 +245,24 @@ class ViTTrunkFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gfeats):
-        heads, B, T, eps = ctx.geom
+        heads, B, T, eps, last_keys = ctx.geom
         L = T + 1
         P = ctx.packed
-        gx, g16 = ops.layernorm_bwd(ctx.x_final, gfeats.contiguous().view(B * T, -1), P["nw"], eps, group_out=T, skip=1)
-        for blk, (x_in, qkv, att, lse, x_mid, pre) in zip(reversed(P["blocks"]), reversed(ctx.saved)):
+        blocks = P["blocks"]
+        if last_keys:
+            # keys = LN1(x) Wk^T + bk of the last block, channel-permuted with the cls row dropped
+            D = heads * 64
+            blk = blocks[-1]
+            if "bwd_k" not in blk:
+                blk["bwd_k"] = blk["qkv_w"].float()[D:2 * D].t().contiguous().to(BF16)
+            g_k = torch.zeros(B, L, D, device=gfeats.device, dtype=BF16)
+            g_k[:, 1:] = gfeats.contiguous().view(B, T, 64, heads).permute(0, 1, 3, 2).reshape(B, T, D)
+            g_h1 = ops.linear(g_k.view(B * L, D), blk["bwd_k"])
+            gx, g16 = ops.layernorm_bwd(ctx.x_final, g_h1, blk["n1w"], eps)
+            blocks = blocks[:-1]
+        else:
+            gx, g16 = ops.layernorm_bwd(ctx.x_final, gfeats.contiguous().view(B * T, -1), P["nw"], eps, group_out=T, skip=1)
+        for blk, (x_in, qkv, att, lse, x_mid, pre) in zip(reversed(blocks), reversed(ctx.saved)):
             W = ViTTrunkFn._bwd_weights(blk)
             g_pre = ops.linear_mul_dgelu(g16, W["fc2"], pre)             # d/d(fc1 out), LayerScale + gelu' fused
             g_h2 = ops.linear(g_pre, W["fc1"])
@@ -251,7 +272,7 @@ class ViTTrunkFn(torch.autograd.Function):
             g_h1 = ops.linear(g_qkv, W["qkv"])
             gx, g16 = ops.layernorm_bwd(x_in, g_h1, blk["n1w"], eps, gx=gx)
         ctx.saved = None
-        return gx, None, None, None, None, None
+        return gx, None, None, None, None, None, None
 
 
 class TokenInjectFn(torch.autograd.Function):

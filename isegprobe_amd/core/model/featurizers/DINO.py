@@ -12,7 +12,7 @@ import torch
 
 from .... import hip_ops as ops
 from ...utils.log import logger
-from .._autograd import TokenAddFn
+from .._autograd import TokenAddFn, TokenInjectFn, ViTTrunkFn
 from .._tensor import BF16, nchw_view
 from .DINOv2 import LN_EPS, DinoVisionTransformer, DINOv2Featurizer
 
@@ -62,8 +62,18 @@ class DINOFeaturizer(DINOv2Featurizer):
         mode = self.feats_injection_mode
         inject = additional_features is not None
         wants_grad = torch.is_grad_enabled() and inject and additional_features.requires_grad
-        if wants_grad and mode == "before_backbone":
-            raise NotImplementedError("training through the frozen ViT (before_backbone) is not built")
+        if wants_grad and mode == "before_backbone":  # the reference's training mode (models/sbd/vit/patch-embed_noup.py:43)
+            if D // heads != 64:
+                raise NotImplementedError("the attention backward is built for head_dim 64")
+            with torch.no_grad():
+                Wimg, bimg = self._image_weights()
+                A = ops.patchify(img.float().contiguous(), None, None, p, Wimg.shape[1])
+                xs, T = self._embed(A, Wimg, bimg, b, H, W)
+            if tuple(additional_features.shape) != (b, T, D):
+                raise AssertionError(f"x.shape: {(b, T, D)}, additional_features.shape: {tuple(additional_features.shape)}")
+            x0 = TokenInjectFn.apply(xs, additional_features, b, T)
+            feats = ViTTrunkFn.apply(x0, self.packed(), heads, b, T, LN_EPS, self.feat_type == "key")
+            return nchw_view(feats.view(b, h, w, D))
         with torch.no_grad():
             Wimg, bimg = self._image_weights()
             A = ops.patchify(img.float().contiguous(), None, None, p, Wimg.shape[1])

@@ -173,3 +173,36 @@ def test_device_next_points_matches_oracle(B, H, W, P):
     got, _ = ops.next_points(torch.from_numpy(perfect).cuda(), torch.from_numpy(gt).cuda(),
                              torch.from_numpy(points).cuda(), 1, torch.zeros(B, dtype=torch.int64))
     assert np.array_equal(got.cpu().numpy(), ref) and np.array_equal(ref, points)
+
+
+@pytest.mark.parametrize("feat_type", ["key", "token"])
+def test_dino_vit_before_backbone_click_gradient(golden, feat_type):
+    """DINO ViT featurizer (models/sbd/vit/patch-embed_noup.py: feat_type="key", before_backbone): gradient of a
+    random linear functional of the dense features w.r.t. the injected click tokens, HIP backward (for "key": through
+    the last block's LayerNorm + K projection only, then the earlier blocks) vs autograd of the CPU oracle."""
+    from conftest import weights_from
+    from isegprobe_amd.core.utils.model_builder import ModelBuilder
+    from oracle.vit import dino_features
+    g = golden("dino_tiny")
+    f = ModelBuilder().load_featurizer("vit", dict(arch="vit_small", patch_size=16, feat_type=feat_type,
+                                                   feats_injection_mode="before_backbone",
+                                                   vit_kwargs=dict(img_size=64, embed_dim=128, depth=2, num_heads=2)))
+    f.model.load_state_dict(weights_from(g, "w"))
+    f = f.cuda().eval()
+    tag = f"{feat_type}_before_backbone"
+    x, clicks = torch.from_numpy(g[tag + "_x"]), torch.from_numpy(g[tag + "_clicks"])
+    torch.manual_seed(3)
+    w = {k: v for k, v in weights_from(g, "w").items()}
+    c_ref = clicks.clone().requires_grad_(True)
+    y_ref = dino_features(x, w, patch=16, depth=2, heads=2, feat_type=feat_type, click_tokens=c_ref)
+    coef = torch.randn_like(y_ref)
+    (y_ref * coef).sum().backward()
+    c_hip = clicks.clone().cuda().requires_grad_(True)
+    y = f(x.cuda(), c_hip)
+    assert (y.float().cpu() - y_ref.detach()).abs().max().item() < 3e-2 * max(1.0, y_ref.abs().max().item())
+    (y.float() * coef.cuda()).sum().backward()
+    got, ref = c_hip.grad.cpu(), c_ref.grad
+    cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+    rms = (got - ref).pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item()
+    print(f"dino {feat_type}: cos {cos:.6f} rms-rel {rms:.3e}")
+    assert cos > 0.999 and rms < 3e-2
