@@ -1,15 +1,15 @@
-// Backward kernels for the trainable tail of the path (seg head, resize, click patch-embed):
-// what loss.backward() needs when the clicks are injected after the frozen backbone
-// (reference core/training/trainer.py:224 on models/*/patch-embed_*.py with
-// feats_injection_mode="after_backbone").  The before-backbone mode additionally needs the
-// backward of the frozen ViT / upsampler (activation gradients only) -- not built yet.
+// Backward kernels of the trainable tail of the path (seg head, resize, click patch-embed) and the row /
+// elementwise pieces of the frozen-trunk backward: what loss.backward() (reference core/training/trainer.py:224 on
+// models/*/patch-embed_*.py) needs besides the GEMM / conv engine (gemm.hip), the fused nine-tap conv weight
+// gradient (conv_wgrad.hip) and the attention backward (attention_bwd.hip).
 //
 //   isp_tn_gemm_bf16_atomic   Out[n][j] += sum_m P[m][n] * Q[m'][j]   (weight gradients: both
 //                             operands are pixel-major, the reduction runs over pixels; Q rows
 //                             optionally shifted by a 3x3 tap = implicit im2col for conv wgrad)
 //   isp_relu_mask_colsum      g = dy * (y > 0), bias gradient = column sums of g
 //   isp_classifier_bwd        dx = (x > 0) * g[m] * w[c], dw, db of the 1x1 classifier
-//   isp_resize_bilinear_ac_nhwc_bwd   adjoint of the align_corners bilinear resize
+//   isp_resize_bilinear_ac_nhwc_bwd / _nchw_f32_bwd   adjoints of the align_corners bilinear resizes
+//   isp_layernorm_bwd         d LayerNorm / dx with recomputed statistics, accumulating into the fp32 gradient stream
 #include "isp_common.h"
 
 namespace {

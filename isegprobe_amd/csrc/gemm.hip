@@ -525,12 +525,8 @@ int launch_gemm(AL al, const void* Wt, long M, int N, int K, EP ep, hipStream_t 
 //   LDS = 2 x 42 KiB + 2 x 24 KiB = 132 KiB.
 constexpr int PT = 16, PW_ = 18, PPIX = PW_ * PW_;       // 16x16 outputs, 18x18 inputs
 constexpr int P_PIECES = (PPIX + 7) / 8 + 1;              // 42 one-KiB pieces (8 pixels x 128 B)
-constexpr int P_BYTES = P_PIECES * 1024,
-#ifdef ISP_P_WST3
-              P_WST = 3;
-#else
-              P_WST = 2;
-#endif
+constexpr int P_BYTES = P_PIECES * 1024;
+constexpr int P_WST = 2;  // weight ring depth (a 3-stage ring fetched two K-steps ahead measured the same)
 
 // TN = 16-channel tiles per wave: 6 -> 192 output channels per block (C = N = 384 heads), 8 -> 256 (N = 1024).
 template <class EP, int TN>
@@ -600,7 +596,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < PPW; ++i) issue_patch(i, 0, smem);
     issue_w(0, s_w);
-    if (P_WST == 3) issue_w(C, s_w + PWB);
 
     // A fragments of K-half 0 of the NEXT K-step are read before that step's barrier (the patch is
     // already resident; only the weight tile needs the barrier), so that after the barrier the first
@@ -647,26 +642,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const bf16_t* __r
         const bool more = cb + 1 < cblocks;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap, ++s) {
-            if (P_WST == 3 && s + 1 < nsteps)  // the 3 weight loads of K-step s+1 are the youngest in flight
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef ISP_ABLATE_NO_BARRIER
             __builtin_amdgcn_s_barrier();
 #endif
 #ifndef ISP_ABLATE_NO_DMA  // timing experiments only
             if (tap < PPW && more) issue_patch(tap, cb + 1, patch_next);  // next patch: one piece / wave / step
-            if (s + P_WST - 1 < nsteps) {  // weight tile P_WST-1 K-steps ahead (issued last: see the vmcnt above)
-                constexpr int ahead = P_WST - 1;
-                const long col = tap + ahead < 9 ? (long)(tap + ahead) * C + (long)cb * BK
-                                                 : (long)(tap + ahead - 9) * C + (long)(cb + 1) * BK;
-                issue_w(col, s_w + (P_WST == 3 ? (tap + ahead) % 3 : (s + ahead) & 1) * PWB);  // 9 % 3 == 0
+            if (s + 1 < nsteps) {  // weight tile of the next K-step: (cb, tap+1) or (cb+1, 0)
+                const long col = tap < 8 ? (long)(tap + 1) * C + (long)cb * BK : (long)(cb + 1) * BK;
+                issue_w(col, s_w + ((s + 1) & 1) * PWB);
             }
 #endif
 #ifdef ISP_ABLATE_NO_MFMA
             continue;
 #endif
-            const char* wb = s_w + (P_WST == 3 ? tap % 3 : s & 1) * PWB;
+            const char* wb = s_w + (s & 1) * PWB;
             bf16x8 fa1[TM], fw[TNH];
             read_w(fw, wb, 0, 0);
             read_a(fa1, patch, tap_shift(tap), 1);
@@ -808,11 +798,20 @@ int dispatch_epilogue(AL al, const void* Wt, long M, int N, int K, const isp_epi
 extern "C" int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* ep,
                              void* stream) {
     ISP_CHECK_ARG(A && Wt && lda >= K && lda % 8 == 0);
-    DenseA<Cfg128::PA> al;
-    al.A = (const bf16_t*)A;
-    al.lda = lda;
-    al.M = M;
-    return dispatch_epilogue<Cfg128, DenseA<Cfg128::PA>, 0xe7fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
+    auto run = [&](auto cfg) {
+        using CFG = decltype(cfg);
+        DenseA<CFG::PA> al;
+        al.A = (const bf16_t*)A;
+        al.lda = lda;
+        al.M = M;
+        return dispatch_epilogue<CFG, DenseA<CFG::PA>, 0xe7fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
+    };
+    // Operand tiles are staged L2 -> LDS and that path tops out near 7 TB/s chip-wide, so the 128x128 tile
+    // (64 FLOP per staged byte) caps these short-K GEMMs near 450 TFLOP/s: measured 417-454 on LoftUp's
+    // M = 1.6 M-row layers.  With >= 512 row tiles of 256 the 8-wave 256x192 tile (110 FLOP/B) runs them at
+    // 460-556 even when N is not a multiple of 192; ViT-sized problems (M = 33 k) lose 10 % on it and stay on 128x128.
+    if ((M + 255) / 256 >= 512 && N >= 384) return run(CfgConv192{});
+    return run(Cfg128{});
 }
 
 // A/B switch for experiments: ISEGPROBE_CONV_ENGINE=tile selects the generic tile engine for every conv
