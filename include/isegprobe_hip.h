@@ -73,6 +73,8 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
 #define ISP_EP_BIAS_QGELU_BF16 9 /* out bf16 = quick_gelu(v + bias) = x*sigmoid(1.702x)   CLIP MLP, maskclip/model.py:231-233 */
 #define ISP_EP_BIAS_GELU_SAVE_BF16 10 /* training forward of Mlp.fc1: out bf16 = gelu_erf(v + bias) and out2 bf16 = v + bias
                                        * (the pre-activation the backward needs; mlp.py:34-40 under autograd) */
+#define ISP_EP_BIAS_QGELU_SAVE_BF16 12 /* as 10 with QuickGELU (CLIP ResidualAttentionBlock.mlp, maskclip/model.py:231-233) */
+#define ISP_EP_MUL_DQGELU_BF16 13      /* as 11 with QuickGELU' */
 #define ISP_EP_MUL_DGELU_BF16 11 /* backward of GELU fused into the fc2 data-gradient GEMM: out bf16 = v * gelu'(res),
                                   * res bf16 = the saved pre-activation (row stride ldo) */
 

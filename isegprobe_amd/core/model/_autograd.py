@@ -192,6 +192,48 @@ class PatchEmbedFn(torch.autograd.Function):
         return None, dw[:, :K].reshape(weight.shape).contiguous(), db[:, 0].contiguous(), None, None
 
 
+def _block_forward_saving(x, blk, heads, B, L, eps, act):
+    """One pre-LN transformer block on the fp32 residual stream x (updated in place), keeping what its backward
+    needs.  blk keys: n1w n1b qkv_w qkv_b proj_w proj_b ls1 n2w n2b fc1_w fc1_b fc2_w fc2_b ls2."""
+    x_in = x.clone()
+    h1 = ops.layernorm(x, blk["n1w"], blk["n1b"], eps)
+    qkv = ops.linear(h1, blk["qkv_w"], blk["qkv_b"])
+    att, lse = ops.attention_packed_qkv_lse(qkv, B, L, heads, 64 ** -0.5)
+    ops.linear_residual_(x, att, blk["proj_w"], blk["proj_b"], blk["ls1"])
+    x_mid = x.clone()
+    h2 = ops.layernorm(x, blk["n2w"], blk["n2b"], eps)
+    hid, pre = ops.linear_gelu_save(h2, blk["fc1_w"], blk["fc1_b"], act)
+    ops.linear_residual_(x, hid, blk["fc2_w"], blk["fc2_b"], blk["ls2"])
+    return (x_in, qkv, att, lse, x_mid, pre)
+
+
+def _block_bwd_weights(blk):
+    """Transposed (data-gradient) weight copies, LayerScale folded in, cached beside the packed weights."""
+    if "bwd" not in blk:
+        def t(w, gamma=None):  # forward y = x W^T (W [N,K]); backward gx = gy W -> gemm weight [K,N]
+            w = w.float()
+            if gamma is not None:
+                w = w * gamma[:, None]
+            return w.t().contiguous().to(BF16)
+        blk["bwd"] = dict(fc2=t(blk["fc2_w"], blk["ls2"]), fc1=t(blk["fc1_w"]), proj=t(blk["proj_w"], blk["ls1"]),
+                          qkv=t(blk["qkv_w"]))
+    return blk["bwd"]
+
+
+def _block_backward(gx, g16, blk, saved, heads, B, L, eps, act):
+    """Activation gradient through one block: (gx fp32 stream gradient, its bf16 copy) at the block output ->
+    the same pair at the block input."""
+    x_in, qkv, att, lse, x_mid, pre = saved
+    W = _block_bwd_weights(blk)
+    g_pre = ops.linear_mul_dgelu(g16, W["fc2"], pre, act)             # d/d(fc1 out), LayerScale + act' fused
+    g_h2 = ops.linear(g_pre, W["fc1"])
+    gx, g16 = ops.layernorm_bwd(x_mid, g_h2, blk["n2w"], eps, gx=gx)
+    g_att = ops.linear(g16, W["proj"])
+    g_qkv = ops.attention_packed_qkv_bwd(qkv, att, g_att, lse, B, L, heads, 64 ** -0.5)
+    g_h1 = ops.linear(g_qkv, W["qkv"])
+    return ops.layernorm_bwd(x_in, g_h1, blk["n1w"], eps, gx=gx)
+
+
 class ViTTrunkFn(torch.autograd.Function):
     """Frozen DINOv2-style trunk on the residual stream: ``x0`` [B*(T+1), D] fp32 (patch + cls +
     pos-embed tokens, click tokens already added on rows 1..T of each image) -> final-norm features
@@ -211,37 +253,17 @@ class ViTTrunkFn(torch.autograd.Function):
         saved = []
         nblk = len(packed["blocks"])
         for i, blk in enumerate(packed["blocks"]):
-            x_in = x.clone()
-            h1 = ops.layernorm(x, blk["n1w"], blk["n1b"], eps)
-            qkv = ops.linear(h1, blk["qkv_w"], blk["qkv_b"])
             if last_keys and i == nblk - 1:
                 D = heads * 64
+                h1 = ops.layernorm(x, blk["n1w"], blk["n1b"], eps)
+                qkv = ops.linear(h1, blk["qkv_w"], blk["qkv_b"])
                 k = qkv.view(B, L, 3, heads, 64)[:, 1:, 1]
-                ctx.saved, ctx.x_final, ctx.packed, ctx.geom = saved, x_in, packed, (heads, B, T, eps, True)
+                ctx.saved, ctx.x_final, ctx.packed, ctx.geom = saved, x.clone(), packed, (heads, B, T, eps, True)
                 return k.permute(0, 1, 3, 2).reshape(B * T, D).contiguous()
-            att, lse = ops.attention_packed_qkv_lse(qkv, B, L, heads, 64 ** -0.5)
-            ops.linear_residual_(x, att, blk["proj_w"], blk["proj_b"], blk["ls1"])
-            x_mid = x.clone()
-            h2 = ops.layernorm(x, blk["n2w"], blk["n2b"], eps)
-            hid, pre = ops.linear_gelu_save(h2, blk["fc1_w"], blk["fc1_b"])
-            ops.linear_residual_(x, hid, blk["fc2_w"], blk["fc2_b"], blk["ls2"])
-            saved.append((x_in, qkv, att, lse, x_mid, pre))
+            saved.append(_block_forward_saving(x, blk, heads, B, L, eps, "gelu"))
         feats = ops.layernorm(x, packed["nw"], packed["nb"], eps, group_out=T, skip=1, rows_out=B * T)
         ctx.saved, ctx.x_final, ctx.packed, ctx.geom = saved, x, packed, (heads, B, T, eps, False)
         return feats
-
-    @staticmethod
-    def _bwd_weights(blk):
-        """Transposed (data-gradient) weight copies, LayerScale folded in, cached beside the packed weights."""
-        if "bwd" not in blk:
-            def t(w, gamma=None):  # forward y = x W^T (W [N,K]); backward gx = gy W -> gemm weight [K,N]
-                w = w.float()
-                if gamma is not None:
-                    w = w * gamma[:, None]
-                return w.t().contiguous().to(BF16)
-            blk["bwd"] = dict(fc2=t(blk["fc2_w"], blk["ls2"]), fc1=t(blk["fc1_w"]), proj=t(blk["proj_w"], blk["ls1"]),
-                              qkv=t(blk["qkv_w"]))
-        return blk["bwd"]
 
     @staticmethod
     def backward(ctx, gfeats):
@@ -262,17 +284,53 @@ class ViTTrunkFn(torch.autograd.Function):
             blocks = blocks[:-1]
         else:
             gx, g16 = ops.layernorm_bwd(ctx.x_final, gfeats.contiguous().view(B * T, -1), P["nw"], eps, group_out=T, skip=1)
-        for blk, (x_in, qkv, att, lse, x_mid, pre) in zip(reversed(blocks), reversed(ctx.saved)):
-            W = ViTTrunkFn._bwd_weights(blk)
-            g_pre = ops.linear_mul_dgelu(g16, W["fc2"], pre)             # d/d(fc1 out), LayerScale + gelu' fused
-            g_h2 = ops.linear(g_pre, W["fc1"])
-            gx, g16 = ops.layernorm_bwd(x_mid, g_h2, blk["n2w"], eps, gx=gx)
-            g_att = ops.linear(g16, W["proj"])
-            g_qkv = ops.attention_packed_qkv_bwd(qkv, att, g_att, lse, B, L, heads, 64 ** -0.5)
-            g_h1 = ops.linear(g_qkv, W["qkv"])
-            gx, g16 = ops.layernorm_bwd(x_in, g_h1, blk["n1w"], eps, gx=gx)
+        for blk, sv in zip(reversed(blocks), reversed(ctx.saved)):
+            gx, g16 = _block_backward(gx, g16, blk, sv, heads, B, L, eps, "gelu")
         ctx.saved = None
         return gx, None, None, None, None, None, None
+
+
+class MaskCLIPTrunkFn(torch.autograd.Function):
+    """Frozen CLIP ViT trunk of the MaskCLIP featurizer (maskclip/model.py:251-263,321-430): tokens (+ clicks, cls,
+    pos-embed) -> ln_pre -> L-1 residual blocks (QuickGELU) -> value path of the last block (out_proj(v_proj(ln_1 x)),
+    no residual) -> cls drop + ln_post -> projection.  Activation gradients only (all weights frozen)."""
+
+    @staticmethod
+    def forward(ctx, x0, P, heads, B, T, out_dim):
+        L, eps = T + 1, 1e-5
+        x0 = x0.detach()
+        x = ops.layernorm(x0, P["pre_w"], P["pre_b"], eps, out_dtype=torch.float32)
+        saved = [_block_forward_saving(x, blk, heads, B, L, eps, "quick_gelu") for blk in P["blocks"][:-1]]
+        last = P["blocks"][-1]
+        a = ops.layernorm(x, last["n1w"], last["n1b"], eps)
+        vout = ops.linear(ops.linear(a, last["v_w"], last["v_b"]), last["proj_w"], last["proj_b"])
+        post = ops.layernorm(vout, P["post_w"], P["post_b"], eps, group_out=T, skip=1, rows_out=B * T)
+        feats = ops.linear(post, P["proj"], None)
+        ctx.saved, ctx.tensors, ctx.P, ctx.geom = saved, (x0, x, vout), P, (heads, B, T, out_dim)
+        return feats[:, :out_dim].contiguous()
+
+    @staticmethod
+    def backward(ctx, gfeats):
+        heads, B, T, out_dim = ctx.geom
+        L, eps, P = T + 1, 1e-5, ctx.P
+        x0, x_last, vout = ctx.tensors
+        last = P["blocks"][-1]
+        if "bwd_tail" not in P:
+            t = lambda w: w.float().t().contiguous().to(BF16)
+            P["bwd_tail"] = dict(proj=t(P["proj"]), out=t(last["proj_w"]), v=t(last["v_w"]))
+        Wt = P["bwd_tail"]
+        n_out = P["proj"].shape[0]
+        g = torch.zeros(B * T, n_out, device=gfeats.device, dtype=BF16)
+        g[:, :out_dim] = gfeats
+        g_post = ops.linear(g, Wt["proj"])
+        _, g_vout = ops.layernorm_bwd(vout, g_post, P["post_w"], eps, group_out=T, skip=1)
+        g_a = ops.linear(ops.linear(g_vout, Wt["out"]), Wt["v"])
+        gx, g16 = ops.layernorm_bwd(x_last, g_a, last["n1w"], eps)
+        for blk, sv in zip(reversed(P["blocks"][:-1]), reversed(ctx.saved)):
+            gx, g16 = _block_backward(gx, g16, blk, sv, heads, B, L, eps, "quick_gelu")
+        g0, _ = ops.layernorm_bwd(x0, g16, P["pre_w"], eps, want_bf16=False)  # ln_pre
+        ctx.saved = ctx.tensors = None
+        return g0, None, None, None, None, None
 
 
 class TokenInjectFn(torch.autograd.Function):

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .... import hip_ops as ops
 from ...utils.log import logger
-from .._autograd import TokenAddFn
+from .._autograd import MaskCLIPTrunkFn, TokenAddFn, TokenInjectFn
 from .._tensor import BF16, PackedCache, nchw_view
 
 CLIP_ARCHS = {"ViT-B/16": dict(input_resolution=224, patch_size=16, width=768, layers=12, heads=12, output_dim=512)}
@@ -106,6 +106,9 @@ class MaskCLIPFeaturizer(nn.Module):
                     out_w=b16(blk.attn.out_proj.weight), out_b=f32(blk.attn.out_proj.bias),
                     fc_w=b16(blk.mlp.c_fc.weight), fc_b=f32(blk.mlp.c_fc.bias),
                     pj_w=b16(blk.mlp.c_proj.weight), pj_b=f32(blk.mlp.c_proj.bias)))
+                d = blocks[-1]  # aliases in the key names the shared transformer-block backward expects
+                d.update(n1w=d["l1w"], n1b=d["l1b"], n2w=d["l2w"], n2b=d["l2b"], proj_w=d["out_w"], proj_b=d["out_b"],
+                         fc1_w=d["fc_w"], fc1_b=d["fc_b"], fc2_w=d["pj_w"], fc2_b=d["pj_b"], ls1=None, ls2=None)
             n_out = _pad64(v.output_dim)
             proj = torch.zeros(n_out, D, device=wp.device, dtype=BF16)
             proj[:v.output_dim] = v.proj.detach().t().to(BF16)
@@ -144,9 +147,19 @@ class MaskCLIPFeaturizer(nn.Module):
         before = additional_features is not None and mode == "before_backbone"
         after = additional_features is not None and mode == "after_backbone"
         wants_grad = torch.is_grad_enabled() and additional_features is not None and additional_features.requires_grad
-        if wants_grad and before:
-            raise NotImplementedError("training through the frozen ViT (before_backbone) is not built")
         P = self.packed()
+        if wants_grad and before:  # the reference's training mode (models/sbd/maskclip/patch-embed_noup.py:41)
+            with torch.no_grad():
+                table, cls_row = self._pos(w, h, H, W)  # (reference quirk: rows/cols swapped on this route, see below)
+                A = ops.patchify(x.float().contiguous(), None, None, p, P["patch_w"].shape[1])
+                xs = torch.empty(b * (T + 1), D, device=x.device, dtype=torch.float32)
+                ops.gemm(A, P["patch_w"], ops._epilogue(ops._lib.EP_TOKENS_F32, xs, D, P["zero_b"], None, table, T))
+                xs.view(b, T + 1, D)[:, 0].copy_(cls_row)
+            if tuple(additional_features.shape) != (b, T, D):
+                raise AssertionError(f"x.shape: {(b, T, D)}, additional_features.shape: {tuple(additional_features.shape)}")
+            x0 = TokenInjectFn.apply(xs, additional_features, b, T)
+            feats = MaskCLIPTrunkFn.apply(x0, P, heads, b, T, v.output_dim)
+            return nchw_view(feats.view(b, h, w, v.output_dim))
         with torch.no_grad():
             # Reference quirk kept: the before_backbone route interpolates the pos-embed grid with rows and
             # columns swapped (model.py:389,402-404 vs :322,341); identical for square inputs.

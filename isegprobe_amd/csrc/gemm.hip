@@ -165,7 +165,20 @@ struct EpBiasActBf16 {  // out[m][n] = bf16(act(v + bias[n]))
     }
 };
 
-struct EpBiasGeluSaveBf16 {  // out = gelu(v + bias), pre = v + bias (kept for the backward)
+__device__ __forceinline__ float act_fwd(int act, float x) {
+    return act == ACT_QGELU ? x / (1.0f + __expf(-1.702f * x)) : gelu_erf(x);
+}
+__device__ __forceinline__ float act_grad(int act, float x) {
+    if (act == ACT_QGELU) {  // d/dx x sigmoid(1.702 x) = s + 1.702 x s (1 - s)
+        const float sg = 1.0f / (1.0f + __expf(-1.702f * x));
+        return sg + 1.702f * x * sg * (1.0f - sg);
+    }
+    const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));  // gelu'(x) = Phi(x) + x phi(x)
+    return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+template <int ACT>
+struct EpBiasGeluSaveBf16 {  // out = act(v + bias), pre = v + bias (kept for the backward); act = GELU or QuickGELU
     bf16_t* out;
     bf16_t* pre;
     const float* bias;
@@ -175,11 +188,12 @@ struct EpBiasGeluSaveBf16 {  // out = gelu(v + bias), pre = v + bias (kept for t
         const float r[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
         *reinterpret_cast<uint2*>(pre + (size_t)m * ldo + n) = make_uint2(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]));
         *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) =
-            make_uint2(pack2bf(gelu_erf(r[0]), gelu_erf(r[1])), pack2bf(gelu_erf(r[2]), gelu_erf(r[3])));
+            make_uint2(pack2bf(act_fwd(ACT, r[0]), act_fwd(ACT, r[1])), pack2bf(act_fwd(ACT, r[2]), act_fwd(ACT, r[3])));
     }
 };
 
-struct EpMulDGeluBf16 {  // out = v * gelu'(pre):  gelu'(x) = Phi(x) + x phi(x)
+template <int ACT>
+struct EpMulDGeluBf16 {  // out = v * act'(pre)
     bf16_t* out;
     const bf16_t* pre;
     long ldo;
@@ -189,11 +203,7 @@ struct EpMulDGeluBf16 {  // out = v * gelu'(pre):  gelu'(x) = Phi(x) + x phi(x)
                             bf2f((bf16_t)(raw.y >> 16))};
         float r[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float cdf = 0.5f * (1.0f + fast_erf(x[j] * 0.70710678118654752440f));
-            const float pdf = 0.39894228040143267794f * __expf(-0.5f * x[j] * x[j]);
-            r[j] = v[j] * (cdf + x[j] * pdf);
-        }
+        for (int j = 0; j < 4; ++j) r[j] = v[j] * act_grad(ACT, x[j]);
         *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = make_uint2(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]));
     }
 };
@@ -781,12 +791,22 @@ int dispatch_epilogue(AL al, const void* Wt, long M, int N, int K, const isp_epi
         case ISP_EP_BIAS_GELU_SAVE_BF16:
             if constexpr (!((KINDS >> ISP_EP_BIAS_GELU_SAVE_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
             if (!e->out2) return ISP_ERR_INVALID;
-            return launch_gemm<CFG>(al, Wt, M, N, K, EpBiasGeluSaveBf16{(bf16_t*)e->out, (bf16_t*)e->out2, e->bias, ldo}, s);
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpBiasGeluSaveBf16<ACT_GELU>{(bf16_t*)e->out, (bf16_t*)e->out2, e->bias, ldo}, s);
+            }
+        case ISP_EP_BIAS_QGELU_SAVE_BF16:
+            if constexpr (!((KINDS >> ISP_EP_BIAS_QGELU_SAVE_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            if (!e->out2) return ISP_ERR_INVALID;
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpBiasGeluSaveBf16<ACT_QGELU>{(bf16_t*)e->out, (bf16_t*)e->out2, e->bias, ldo}, s);
             }
         case ISP_EP_MUL_DGELU_BF16:
             if constexpr (!((KINDS >> ISP_EP_MUL_DGELU_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
             if (!e->res) return ISP_ERR_INVALID;
-            return launch_gemm<CFG>(al, Wt, M, N, K, EpMulDGeluBf16{(bf16_t*)e->out, (const bf16_t*)e->res, ldo}, s);
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpMulDGeluBf16<ACT_GELU>{(bf16_t*)e->out, (const bf16_t*)e->res, ldo}, s);
+            }
+        case ISP_EP_MUL_DQGELU_BF16:
+            if constexpr (!((KINDS >> ISP_EP_MUL_DQGELU_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
+            if (!e->res) return ISP_ERR_INVALID;
+            return launch_gemm<CFG>(al, Wt, M, N, K, EpMulDGeluBf16<ACT_QGELU>{(bf16_t*)e->out, (const bf16_t*)e->res, ldo}, s);
             }
         default:
             return ISP_ERR_UNSUPPORTED;
@@ -804,7 +824,7 @@ extern "C" int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, in
         al.A = (const bf16_t*)A;
         al.lda = lda;
         al.M = M;
-        return dispatch_epilogue<CFG, DenseA<CFG::PA>, 0xe7fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
+        return dispatch_epilogue<CFG, DenseA<CFG::PA>, 0x3e7fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
     };
     // Operand tiles are staged L2 -> LDS and that path tops out near 7 TB/s chip-wide, so the 128x128 tile
     // (64 FLOP per staged byte) caps these short-K GEMMs near 450 TFLOP/s: measured 417-454 on LoftUp's

@@ -117,25 +117,26 @@ def linear(A, Wt, bias=None, act=None, out_dtype=BF16):
     return out
 
 
-def linear_gelu_save(A, Wt, bias):
-    """Training forward of Mlp.fc1 (mlp.py:34-40): returns (gelu(pre), pre), pre = A Wt^T + bias, both bf16."""
+def linear_gelu_save(A, Wt, bias, act="gelu"):
+    """Training forward of Mlp.fc1 (mlp.py:34-40): returns (act(pre), pre), pre = A Wt^T + bias, both bf16;
+    act = "gelu" (exact erf) or "quick_gelu" (CLIP)."""
     N = Wt.shape[0]
     out = torch.empty(A.shape[0], N, device=A.device, dtype=BF16)
     pre = torch.empty_like(out)
-    ep = _epilogue(_lib.EP_BIAS_GELU_SAVE_BF16, out, N, bias)
+    ep = _epilogue({"gelu": _lib.EP_BIAS_GELU_SAVE_BF16, "quick_gelu": _lib.EP_BIAS_QGELU_SAVE_BF16}[act], out, N, bias)
     ep.out2 = pre.data_ptr()
     gemm(A, Wt, ep)
     return out, pre
 
 
-def linear_mul_dgelu(A, Wt, pre):
-    """(A Wt^T) * gelu'(pre): the fc2 data gradient with the GELU backward fused; pre bf16 [M,N]."""
+def linear_mul_dgelu(A, Wt, pre, act="gelu"):
+    """(A Wt^T) * act'(pre): the fc2 data gradient with the GELU / QuickGELU backward fused; pre bf16 [M,N]."""
     _need(pre, BF16, "pre")
     N = Wt.shape[0]
     if tuple(pre.shape) != (A.shape[0], N):
         raise IspError("pre-activation shape mismatch")
     out = torch.empty(A.shape[0], N, device=A.device, dtype=BF16)
-    gemm(A, Wt, _epilogue(_lib.EP_MUL_DGELU_BF16, out, N, res=pre))
+    gemm(A, Wt, _epilogue({"gelu": _lib.EP_MUL_DGELU_BF16, "quick_gelu": _lib.EP_MUL_DQGELU_BF16}[act], out, N, res=pre))
     return out
 
 

@@ -206,3 +206,34 @@ def test_dino_vit_before_backbone_click_gradient(golden, feat_type):
     rms = (got - ref).pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item()
     print(f"dino {feat_type}: cos {cos:.6f} rms-rel {rms:.3e}")
     assert cos > 0.999 and rms < 3e-2
+
+
+def test_maskclip_before_backbone_click_gradient(golden):
+    """MaskCLIP featurizer (models/sbd/maskclip/patch-embed_noup.py: before_backbone): gradient w.r.t. the injected
+    click tokens through ln_pre, two QuickGELU blocks, the last block's value path, ln_post and the projection,
+    vs autograd of the CPU oracle."""
+    from conftest import weights_from
+    from isegprobe_amd.core.utils.model_builder import ModelBuilder
+    from oracle.vit import maskclip_features
+    g = golden("maskclip_tiny")
+    f = ModelBuilder().load_featurizer("mask_clip", dict(model_name="tiny", feats_injection_mode="before_backbone",
+                                                          visual_kwargs=dict(input_resolution=64, patch_size=16, width=128,
+                                                                             layers=3, heads=2, output_dim=64)))
+    f.model.load_state_dict(weights_from(g, "w"))
+    f = f.cuda().eval()
+    x, clicks = torch.from_numpy(g["before_backbone_x"]), torch.from_numpy(g["before_backbone_clicks"])
+    w = weights_from(g, "w")
+    c_ref = clicks.clone().requires_grad_(True)
+    y_ref = maskclip_features(x, w, patch=16, heads=2, click_tokens=c_ref, injection="before_backbone")
+    torch.manual_seed(5)
+    coef = torch.randn_like(y_ref)
+    (y_ref * coef).sum().backward()
+    c_hip = clicks.clone().cuda().requires_grad_(True)
+    y = f(x.cuda(), c_hip)
+    assert (y.float().cpu() - y_ref.detach()).abs().max().item() < 3e-2 * max(1.0, y_ref.abs().max().item())
+    (y.float() * coef.cuda()).sum().backward()
+    got, ref = c_hip.grad.cpu(), c_ref.grad
+    cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+    rms = (got - ref).pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item()
+    print(f"maskclip: cos {cos:.6f} rms-rel {rms:.3e}")
+    assert cos > 0.999 and rms < 3e-2
