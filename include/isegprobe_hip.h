@@ -150,6 +150,12 @@ int isp_layernorm_bwd(const void* x, int x_dtype, long ld_x, const void* gy, lon
                       long ld_gx, void* gx_bf16, long ld_g16, long rows, int D, float eps, int group_out, int skip,
                       int accumulate, void* stream);
 
+/* ---- LayerNorm affine gradients (a TRAINED LayerNorm: the simple-ViT click encoder, simple_ViT.py:18-155):
+ * dgamma[c] += sum_r gy[r][c] * xhat[r][c], dbeta[c] += sum_r gy[r][c]; x fp32 or bf16 (row stride ld_x), gy bf16 (row
+ * stride ld_gy); dgamma / dbeta fp32 [D], caller-zeroed (atomics). */
+int isp_layernorm_wgrad(const void* x, int x_dtype, long ld_x, const void* gy, long ld_gy, float* dgamma, float* dbeta,
+                        long rows, int D, float eps, void* stream);
+
 /* ---- Adjoint of isp_resize_bilinear_ac_nchw_f32 for planar fp32 maps: din [planes,h,w] = R^T dout [planes,H,W].
  * The logits resize of iseg_base_model.py:75-80 under autograd (identity / LiFT-sized upsampler outputs). */
 int isp_resize_bilinear_ac_nchw_f32_bwd(const float* dout, float* din, long planes, int h, int w, int H, int W,

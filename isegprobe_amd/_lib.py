@@ -62,6 +62,7 @@ SIGNATURES = {
     "isp_robot_click": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "isp_threshold_u8": [_vp, _vp, _f, _l, _vp],
     "isp_resize_bilinear_ac_nchw_f32_bwd": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
+    "isp_layernorm_wgrad": [_vp, _i, _l, _vp, _l, _vp, _vp, _l, _i, _f, _vp],
     "isp_layernorm_bwd": [_vp, _i, _l, _vp, _l, _vp, _vp, _l, _vp, _l, _l, _i, _f, _i, _i, _i, _vp],
     "isp_resize_bilinear_ac_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_resize_bilinear_ac_nchw_f32": [_vp, _vp, _l, _i, _i, _i, _i, _l, _vp],

@@ -344,6 +344,51 @@ __global__ __launch_bounds__(256) void bilinear_bwd_planar_kernel(const float* _
     din[idx] = acc;
 }
 
+// LayerNorm affine gradients: dgamma[c] += sum_r gy[r][c] * xhat[r][c], dbeta[c] += sum_r gy[r][c] (statistics
+// recomputed).  Block = 32 rows: every wave first reduces mean / rstd of 8 rows into LDS, then the threads sweep the
+// columns.  Needed only where a LayerNorm is TRAINED (the simple-ViT click encoder, simple_ViT.py:18-155).
+template <typename TX>
+__global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const TX* __restrict__ x, long ld_x,
+                                                              const bf16_t* __restrict__ gy, long ld_gy,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              long rows, int D, float eps) {
+    __shared__ float s_mean[32], s_rstd[32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.x * 32;
+    auto ld = [&](long r, int c) -> float {
+        if constexpr (sizeof(TX) == 4) return x[r * ld_x + c];
+        else return bf2f(x[r * ld_x + c]);
+    };
+    for (int k = 0; k < 8; ++k) {
+        const long r = r0 + wv * 8 + k;
+        float sum = 0.f, sq = 0.f;
+        if (r < rows) {
+            for (int c = lane; c < D; c += 64) sum += ld(r, c);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum / (float)D;
+            for (int c = lane; c < D; c += 64) {
+                const float d = ld(r, c) - mean;
+                sq += d * d;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            if (lane == 0) s_mean[wv * 8 + k] = mean, s_rstd[wv * 8 + k] = 1.0f / sqrtf(sq / (float)D + eps);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float dg = 0.f, db = 0.f;
+        for (int k = 0; k < 32 && r0 + k < rows; ++k) {
+            const float g = bf2f(gy[(r0 + k) * ld_gy + c]);
+            dg += g * (ld(r0 + k, c) - s_mean[k]) * s_rstd[k];
+            db += g;
+        }
+        atomicAdd(dgamma + c, dg);
+        atomicAdd(dbeta + c, db);
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -540,5 +585,22 @@ extern "C" int isp_resize_bilinear_ac_nchw_f32_bwd(const float* dout, float* din
     const long total = planes * h * w;
     bilinear_bwd_planar_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(dout, din, h, w, H, W, sy,
                                                                                                sx, total);
+    return isp_launch_status();
+}
+
+extern "C" int isp_layernorm_wgrad(const void* x, int x_dtype, long ld_x, const void* gy, long ld_gy, float* dgamma,
+                                   float* dbeta, long rows, int D, float eps, void* stream) {
+    ISP_CHECK_ARG(x && gy && dgamma && dbeta && rows > 0 && D > 0);
+    if (ld_x <= 0) ld_x = D;
+    if (ld_gy <= 0) ld_gy = D;
+    ISP_CHECK_ARG(ld_x >= D && ld_gy >= D);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((rows + 31) / 32);
+    if (x_dtype == ISP_F32)
+        layernorm_wgrad_kernel<float><<<grid, 256, 0, s>>>((const float*)x, ld_x, (const bf16_t*)gy, ld_gy, dgamma, dbeta, rows, D, eps);
+    else if (x_dtype == ISP_BF16)
+        layernorm_wgrad_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, ld_x, (const bf16_t*)gy, ld_gy, dgamma, dbeta, rows, D, eps);
+    else
+        return ISP_ERR_UNSUPPORTED;
     return isp_launch_status();
 }

@@ -306,6 +306,40 @@ def layernorm_bwd(x, gy, gamma, eps, gx=None, group_out=0, skip=0, want_bf16=Tru
     return gx, g16
 
 
+def layernorm_wgrad(x, gy, eps, D=None):
+    """(dgamma, dbeta) [D] f32 of LayerNorm over the first D columns of x [rows, ld] (f32 / bf16) given gy bf16."""
+    if x.dtype not in (torch.float32, BF16):
+        raise IspError("layernorm_wgrad input must be f32 or bf16")
+    _need(x, x.dtype, "x")
+    _need(gy, BF16, "gy", contiguous=False)
+    rows, ld = x.shape
+    D = ld if D is None else D
+    if gy.dim() != 2 or gy.shape[0] != rows or gy.shape[1] < D or gy.stride(1) != 1:
+        raise IspError("layernorm_wgrad: shape mismatch")
+    dg = torch.zeros(D, device=x.device, dtype=torch.float32)
+    db = torch.zeros(D, device=x.device, dtype=torch.float32)
+    check(_lib.lib().isp_layernorm_wgrad(_p(x), _lib.ISP_F32 if x.dtype == torch.float32 else _lib.ISP_BF16, ld, _p(gy),
+                                         gy.stride(0), _p(dg), _p(db), rows, D, float(eps), _stream()), "isp_layernorm_wgrad")
+    return dg, db
+
+
+def linear_wgrad(g, a, want_bias=True):
+    """Weight (and bias) gradient of y = a W^T + b: dW [N,K] = g^T a (pixel-reduction GEMM), db [N] = column sums of g.
+    g [M,N], a [M,K] bf16."""
+    _need(g, BF16, "g")
+    _need(a, BF16, "a")
+    N, K = g.shape[1], a.shape[1]
+    dw = torch.zeros(N, K, device=g.device, dtype=torch.float32)
+    tn_gemm_atomic(g, a, dw)
+    db = None
+    if want_bias:
+        ones = torch.ones(g.shape[0], 8, device=g.device, dtype=BF16)
+        acc = torch.zeros(N, 8, device=g.device, dtype=torch.float32)
+        tn_gemm_atomic(g, ones, acc)
+        db = acc[:, 0].contiguous()
+    return dw, db
+
+
 def attention_bwd(q, k, v, out, dout, lse, scale, want_dq=True):
     """Backward of attention(): q/out/dout [B,Lq,H,hd], k/v [B,Lk,H,hd] bf16 (hd 64 or 128), lse from
     attention_lse().  Returns (dq or None, dk, dv) shaped like q, k, v (contiguous)."""
