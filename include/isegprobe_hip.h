@@ -195,6 +195,10 @@ int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, con
                     float sigma_spatial, int B, int GH, int GW, void* stream);
 int isp_jbu_apply(const void* src_nhwc_bf16, const void* kc_bf16, void* out_nhwc_bf16, int B, int h, int w, int C,
                   void* stream);
+/* Adjoint of isp_jbu_apply w.r.t. the source: gsrc [B,h,w,C] = A(kc)^T gout [B,2h,2w,C] (kc depends on the guidance only).
+ * What autograd does for FeatUp's JBU stage when the probe trains through it (models/sbd/dinov2/patch-embed_jbu.py). */
+int isp_jbu_apply_bwd(const void* gout_nhwc_bf16, const void* kc_bf16, void* gsrc_nhwc_bf16, int B, int h, int w, int C,
+                      void* stream);
 
 /* ---- LoftUp front end: MinMaxScaler statistics (batch-global per-channel min/max,
  * loftup/layers.py:61-71; workspace >= C*B*64*2 floats) and the fused ImplicitFeaturizer

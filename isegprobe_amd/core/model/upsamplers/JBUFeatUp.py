@@ -130,5 +130,39 @@ class JBUFeatUpUpsampler(BaseUpsampler):
         self.eval()
 
     def forward(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
-        self._refuse_source_grad(source)
+        x = to_nhwc_bf16(source)
+        if torch.is_grad_enabled() and x.requires_grad:  # training with clicks injected before the upsampler
+            return nchw_view(_JBUFn.apply(x, guidance, self.upsampler))
         return self.upsampler(source, guidance)
+
+
+class _JBUFn(torch.autograd.Function):
+    """JBUStack as one autograd node.  Every stage is LINEAR in the source (its composite kernels depend on the
+    guidance only) and so is the fix-up z = x + 0.1 (W x + b): the backward is the adjoint chain
+    g <- g + 0.1 W^T g, then four adjoint applies with the saved kernels."""
+
+    @staticmethod
+    def forward(ctx, src, guidance, stack):
+        x = src.detach()
+        g = guidance.detach().float().contiguous()
+        kcs = []
+        for up in (stack.up1, stack.up2, stack.up3, stack.up4):
+            kc = up.kernels(g, x.shape[1] * 2, x.shape[2] * 2)
+            kcs.append(kc)
+            x = ops.jbu_apply(x, kc)
+        conv = stack.fixup_proj[1]
+        w = conv.weight.detach().flatten(1).to(BF16).contiguous()
+        B, H, W, C = x.shape
+        y = ops.linear_axpy_res(x.view(-1, C), w, conv.bias.detach().float().contiguous(), x.view(-1, C), 0.1)
+        ctx.kcs, ctx.wT = kcs, conv.weight.detach().flatten(1).t().contiguous().to(BF16)
+        return y.view(B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        B, H, W, C = g_out.shape
+        g = g_out.contiguous().view(-1, C)
+        g = ops.linear_axpy_res(g, ctx.wT, None, g, 0.1).view(B, H, W, C)  # (I + 0.1 W)^T
+        for kc in reversed(ctx.kcs):
+            g = ops.jbu_apply_bwd(g, kc)
+        ctx.kcs = None
+        return g, None, None

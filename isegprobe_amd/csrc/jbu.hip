@@ -427,6 +427,67 @@ extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* k
     return isp_launch_status();
 }
 
+// --------------------------------------------------------------------------------------
+// Adjoint of jbu_apply w.r.t. the source (the kernels kc depend on the guidance only):
+//   gsrc[b,sy,sx,:] = sum over output pixels (y,x) and taps (ry,rx) with clamp(base_y(y)+ry) == sy and
+//                     clamp(base_x(x)+rx) == sx of kc[b,y,x][ry][(base_x(x)+rx) & 15] * gout[b,y,x,:].
+// Only rows y in [2sy-8, 2sy+7] (cols alike) can reach (sy,sx); away from the border each contributes one tap, at the
+// border the clamped taps pile up on the edge pixel.  Gather form, one wave per source pixel, a lane owns 8 channels,
+// the tap weight is wave-uniform.  Training only (models/sbd/dinov2/patch-embed_jbu.py), not tuned.
+namespace {
+__global__ __launch_bounds__(256) void jbu_apply_bwd_kernel(const bf16_t* __restrict__ gout, const bf16_t* __restrict__ kc,
+                                                            bf16_t* __restrict__ gsrc, int h, int w, int C) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sx = blockIdx.x * 4 + wv, sy = blockIdx.y, b = blockIdx.z;
+    if (sx >= w) return;
+    const int GH = 2 * h, GW = 2 * w;
+    const int y_lo = max(0, 2 * sy - 8), y_hi = min(GH - 1, 2 * sy + 7);
+    const int x_lo = max(0, 2 * sx - 8), x_hi = min(GW - 1, 2 * sx + 7);
+    for (int c0 = lane * 8; c0 < C; c0 += 512) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int y = y_lo; y <= y_hi; ++y) {
+            const int by = ((y - 4) >> 1) - 1;
+            // taps ry with clamp(by + ry, 0, h-1) == sy
+            int ry0 = sy - by, ry1 = sy - by;
+            if (sy == 0) ry0 = 0;
+            if (sy == h - 1) ry1 = 7;
+            ry0 = max(ry0, 0), ry1 = min(ry1, 7);
+            if (ry0 > ry1) continue;
+            for (int x = x_lo; x <= x_hi; ++x) {
+                const int bx = ((x - 4) >> 1) - 1;
+                int rx0 = sx - bx, rx1 = sx - bx;
+                if (sx == 0) rx0 = 0;
+                if (sx == w - 1) rx1 = 7;
+                rx0 = max(rx0, 0), rx1 = min(rx1, 7);
+                if (rx0 > rx1) continue;
+                const bf16_t* kp = kc + (((size_t)b * GH + y) * GW + x) * 128;
+                float wgt = 0.f;
+                for (int ry = ry0; ry <= ry1; ++ry)
+                    for (int rx = rx0; rx <= rx1; ++rx) wgt += bf2f(kp[ry * 16 + ((bx + rx) & 15)]);
+                const uint4 g = *reinterpret_cast<const uint4*>(gout + (((size_t)b * GH + y) * GW + x) * C + c0);
+                const unsigned* q = &g.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += wgt * __uint_as_float(q[e] << 16);
+                    acc[2 * e + 1] += wgt * __uint_as_float(q[e] & 0xffff0000u);
+                }
+            }
+        }
+        *reinterpret_cast<uint4*>(gsrc + (((size_t)b * h + sy) * w + sx) * C + c0) =
+            make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+    }
+}
+}  // namespace
+
+extern "C" int isp_jbu_apply_bwd(const void* gout_nhwc_bf16, const void* kc_bf16, void* gsrc_nhwc_bf16, int B, int h, int w,
+                                 int C, void* stream) {
+    ISP_CHECK_ARG(gout_nhwc_bf16 && kc_bf16 && gsrc_nhwc_bf16 && B > 0 && h >= 2 && w >= 2 && C > 0 && C % 8 == 0);
+    ISP_CHECK_ARG(B <= 65535 && h <= 65535);
+    jbu_apply_bwd_kernel<<<dim3((w + 3) / 4, h, B), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)gout_nhwc_bf16, (const bf16_t*)kc_bf16, (bf16_t*)gsrc_nhwc_bf16, h, w, C);
+    return isp_launch_status();
+}
+
 extern "C" int isp_jbu_apply(const void* src_nhwc_bf16, const void* kc_bf16, void* out_nhwc_bf16, int B, int h, int w,
                              int C, void* stream) {
     ISP_CHECK_ARG(src_nhwc_bf16 && kc_bf16 && out_nhwc_bf16 && B > 0 && h >= 2 && w >= 2 && C > 0 && C % ACC == 0);

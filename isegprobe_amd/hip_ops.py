@@ -551,6 +551,18 @@ def jbu_apply(src, kc):
     return out
 
 
+def jbu_apply_bwd(gout, kc):
+    """Adjoint of jbu_apply w.r.t. src: gout [B,2h,2w,C] bf16, kc [B,2h,2w,8,16] bf16 -> [B,h,w,C] bf16."""
+    _need(gout, BF16, "gout")
+    _need(kc, BF16, "kc")
+    B, GH, GW, C = gout.shape
+    if kc.shape != (B, GH, GW, 8, 16) or GH % 2 or GW % 2:
+        raise IspError("jbu_apply_bwd: shape mismatch")
+    gsrc = torch.empty(B, GH // 2, GW // 2, C, device=gout.device, dtype=BF16)
+    check(_lib.lib().isp_jbu_apply_bwd(_p(gout), _p(kc), _p(gsrc), B, GH // 2, GW // 2, C, _stream()), "isp_jbu_apply_bwd")
+    return gsrc
+
+
 def linear_axpy_res(A, Wt, bias, res, alpha):
     """bf16: res + alpha * (A Wt^T + bias)."""
     _need(res, BF16, "res")

@@ -260,3 +260,30 @@ def test_layernorm_backward_bf16_padded(ops):
     assert rel(gx[:, :D], xr.grad) < 1e-4
     assert gx[:, D:].abs().max().item() == 0 and g16[:, D:].abs().max().item() == 0
     assert rel(g16[:, :D], xr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("B,h,w,C", [(2, 4, 5, 64), (1, 8, 8, 128), (1, 16, 12, 192)])
+def test_jbu_apply_adjoint(ops, B, h, w, C):
+    """<A x, g> == <x, A^T g> for the composite-kernel apply (borders included: clamped taps pile up on edge pixels),
+    plus explicit columns of A (apply on a one-hot source) against the matching entries of A^T g."""
+    torch.manual_seed(h * w)
+    kc = torch.rand(B, 2 * h, 2 * w, 8, 16, device="cuda") / 8
+    # the kernel format: of the 16 circular column slots only the 8 of the pixel's window [base_x, base_x + 8) are non-zero
+    xs = torch.arange(2 * w, device="cuda")
+    bx = ((xs - 4) >> 1) - 1
+    live = torch.zeros(2 * w, 16, device="cuda")
+    for rx in range(8):
+        live[xs, (bx + rx) & 15] = 1
+    kc = (kc * live[None, None, :, None, :]).to(BF)
+    x = torch.randn(B, h, w, C, device="cuda").to(BF)
+    g = torch.randn(B, 2 * h, 2 * w, C, device="cuda").to(BF)
+    Ax = ops.jbu_apply(x, kc).float()
+    ATg = ops.jbu_apply_bwd(g, kc).float()
+    lhs, rhs = (Ax * g.float()).sum().item(), (x.float() * ATg).sum().item()
+    assert abs(lhs - rhs) < 2e-2 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+    for (sy, sx) in ((0, 0), (h - 1, w - 1), (h // 2, w // 2), (0, w // 2)):
+        e = torch.zeros(B, h, w, C, device="cuda", dtype=BF)
+        e[0, sy, sx, 3] = 1.0
+        col = ops.jbu_apply(e, kc)[0, :, :, 3].float()            # column (sy, sx) of A for batch 0, channel 3
+        want = (col * g[0, :, :, 3].float()).sum().item()
+        assert abs(ATg[0, sy, sx, 3].item() - want) < 2e-2 * max(1.0, abs(want)), (sy, sx)

@@ -60,7 +60,7 @@ def test_gradients_vs_oracle_autograd():
     assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
 
 
-@pytest.mark.parametrize("upsampler", ["bilinear", "identity", "loftup", "lift"])
+@pytest.mark.parametrize("upsampler", ["bilinear", "identity", "loftup", "lift", "jbu_featup"])
 def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
     """The reference's default training mode (models/sbd/dinov2/patch-embed_*.py:40): the click
     patch-embedding gets its gradient through both frozen ViT blocks (attention, LayerNorm, GELU
@@ -101,34 +101,6 @@ def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
     assert all(c > cos_min for _, c in worst.values()), worst
     assert all(r < rms_max for r, _ in worst.values()), worst
     assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
-
-
-@pytest.mark.parametrize("upsampler", ["jbu_featup"])
-def test_before_backbone_training_through_jbu_is_refused(upsampler):
-    """No backward exists for FeatUp JBU: asking for it must raise, not return zeros."""
-    model = build_model(upsampler, injection="before_backbone", upsampler_params=UP_PARAMS[upsampler]).cuda().train()
-    image, points = torch.rand(1, 4, 56, 56).cuda(), torch.tensor([[[5., 5., 0.], [-1., -1., -1.]]]).cuda()
-    with pytest.raises(NotImplementedError):
-        model(image, points)
-
-
-def test_trainer_step_reduces_loss():
-    from isegprobe_amd.core.training.trainer import DataParallelTrainer
-    model, image, points = _setup()
-    model = model.cuda()
-    gt = torch.zeros(2, 1, 56, 56)
-    gt[:, :, 10:40, 15:45] = 1
-    batch = {"images": image[:, :3].cuda(), "instances": gt.cuda(), "points": points.cuda()}
-    trainer = DataParallelTrainer(model, lr=1e-3)
-    assert trainer.bucket.nbytes() == sum(p.numel() for p in model.parameters() if p.requires_grad) * 4
-    before = {k: v.clone() for k, v in model.state_dict().items()}
-    losses = [trainer.step(batch, num_iters=1 if i == 0 else 0).item() for i in range(8)]
-    print("losses", [round(l, 4) for l in losses])
-    assert losses[-1] < losses[0]
-    after = model.state_dict()
-    assert not torch.equal(before["head.convs.0.conv.weight"], after["head.convs.0.conv.weight"])
-    assert not torch.equal(before["embed_coords.proj.weight"], after["embed_coords.proj.weight"])
-    assert torch.equal(before["backbone.model.blocks.0.attn.qkv.weight"], after["backbone.model.blocks.0.attn.qkv.weight"])
 
 
 # ------------------------------------------------------------------ device click simulation (SURVEY.md 8(f) rank 3)

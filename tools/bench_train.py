@@ -16,7 +16,8 @@ up = sys.argv[2] if len(sys.argv) > 2 else "bilinear"
 inj = sys.argv[3] if len(sys.argv) > 3 else "before_backbone"
 S = int(sys.argv[4]) if len(sys.argv) > 4 else 448
 ITERS = int(sys.argv[5]) if len(sys.argv) > 5 else 0  # simulated corrective clicks (no-grad forwards) per step
-params = {"loftup": {"upsampler_path": None, "n_dim": 384}}.get(up)
+params = {"loftup": {"upsampler_path": None, "n_dim": 384}, "jbu_featup": {"backbone_type": "dinov2"},
+          "lift": {"lift_path": None, "n_dim": 384, "patch": 14}}.get(up)
 model = seeded_(build_model(up, injection=inj, vit=S14, img=(S, S), upsampler_params=params), 1).cuda()
 torch.manual_seed(0)
 image = torch.rand(B, 3, S, S, device="cuda")
