@@ -5,8 +5,9 @@ Hydra config + a model script; this one keeps the same roles with plain argument
     python train.py --steps 20                                   # single GPU
     python -m torch.distributed.run --nproc-per-node 8 train.py  # data parallel, RCCL over xGMI
 
-Each rank builds the same model (frozen DINOv2 backbone + frozen upsampler, trainable embed_coords +
-head), draws its own shard of the (synthetic, SBD-shaped) minibatch, and takes optimisation steps
+`--model` names one of the reference's model scripts (models/sbd/<family>/<script>.py: backbone, click-injection
+mode, click encoder, upsampler and head exactly as configured there).  Each rank builds the same model (frozen
+backbone + frozen upsampler, trainable embed_coords + head), draws its own shard of the (synthetic, SBD-shaped) minibatch, and takes optimisation steps
 with ONE flat-bucket gradient all-reduce per step (core/training/trainer.py).  Real datasets are
 outside the dense-feature path: plug any iterable of
 {"images" [B,3,H,W], "instances" [B,1,H,W], "points" [B,2P,3]} batches into DataParallelTrainer."""
@@ -36,13 +37,52 @@ def synthetic_batch(B, S, rng, P=24, device="cuda"):
             "points": torch.from_numpy(pts).to(device)}
 
 
+def model_configs(name, size, arch="dinov2_vits14", upsampler=None, injection=None):
+    """backbone / embed_coords / head / upsampler configs of the reference's model scripts
+    (models/sbd/{dinov2,vit,maskclip}/*.py: define_modules_cfg)."""
+    S = (size, size)
+    dim = {"dinov2_vits14": 384, "dinov2_vitb14": 768, "dinov2_vitl14": 1024}[arch]
+    patch_embed = lambda p, d: {"type": "patchEmbed", "params": dict(img_size=S, patch_size=(p, p), embed_dim=d)}
+    head = lambda c: {"type": "convhead", "params": dict(in_channels=c, num_layers=2, num_classes=1)}
+    dinov2 = lambda inj: {"type": "dinov2", "params": {"arch": arch, "feats_injection_mode": injection or inj}}
+    ups = {"bilinear": {"type": "bilinear", "params": None}, "noup": {"type": "identity", "params": None},
+           "jbu": {"type": "jbu_featup", "params": dict(backbone_type="dinov2", use_norm=True, feat_dim=dim)},
+           "lift": {"type": "lift", "params": dict(lift_path=None, n_dim=dim, patch=14)},
+           "loftup": {"type": "loftup", "params": dict(upsampler_path=None, n_dim=dim, lr_pe_type="sine", lr_size=16)}}
+    family, _, script = name.replace("models/sbd/", "").replace(".py", "").partition("/")
+    if family == "dinov2" and script.startswith("patch-embed_"):
+        cfg = dict(backbone_cfg=dinov2("before_backbone"), embed_coords_cfg=patch_embed(14, dim), head_cfg=head(dim),
+                   upsampler_cfg=ups[script.split("_", 1)[1]])
+    elif family == "dinov2" and script == "simple-vit_noup":
+        cfg = dict(backbone_cfg=dinov2("after_backbone"), head_cfg=head(dim), upsampler_cfg=ups["noup"],
+                   embed_coords_cfg={"type": "simple_vit", "params": dict(img_size=list(S), patch_size=(14, 14), embed_dim=dim,
+                                                                           depth=6, heads=8, mlp_dim=2048, channels=3, dim_head=64)})
+    elif family == "vit" and script == "patch-embed_noup":
+        cfg = dict(backbone_cfg={"type": "vit", "params": dict(arch="vit_small_patch16_224", patch_size=16, feat_type="key",
+                                                               feats_injection_mode=injection or "before_backbone")},
+                   embed_coords_cfg=patch_embed(16, 384), head_cfg=head(384), upsampler_cfg=ups["noup"])
+    elif family == "maskclip" and script == "patch-embed_noup":
+        cfg = dict(backbone_cfg={"type": "mask_clip", "params": dict(model_name="ViT-B/16",
+                                                                     feats_injection_mode=injection or "before_backbone")},
+                   embed_coords_cfg=patch_embed(16, 768), head_cfg=head(512), upsampler_cfg=ups["noup"])
+    else:
+        raise SystemExit(f"unknown model script {name!r}")
+    if upsampler is not None:
+        cfg["upsampler_cfg"] = ups.get(upsampler, {"type": upsampler, "params": None})
+    return cfg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (reference train_cfg.yaml:18)")
     ap.add_argument("--size", type=int, default=224, help="crop size (reference train_cfg.yaml:22)")
     ap.add_argument("--arch", default="dinov2_vits14")
-    ap.add_argument("--upsampler", default="bilinear")
+    ap.add_argument("--model", default="dinov2/patch-embed_bilinear",
+                    help="reference model script: dinov2/patch-embed_{bilinear,jbu,lift,loftup,noup}, dinov2/simple-vit_noup, "
+                         "vit/patch-embed_noup, maskclip/patch-embed_noup (reference: +exp.model_path=models/sbd/<this>.py)")
+    ap.add_argument("--upsampler", default=None, help="override the script's upsampler")
+    ap.add_argument("--injection", default=None, help="override feats_injection_mode (before_backbone | after_backbone)")
     ap.add_argument("--lr", type=float, default=5e-5)
     args = ap.parse_args()
 
@@ -52,18 +92,13 @@ def main():
 
     distributed = D.init_distributed()
     torch.cuda.set_device(D.get_local_rank())
-    dim = {"dinov2_vits14": 384, "dinov2_vitb14": 768, "dinov2_vitl14": 1024}[args.arch]
     torch.manual_seed(0)  # identical initial weights on every rank
-    model = iSegProbeModel(
-        backbone_cfg={"type": "dinov2", "params": {"arch": args.arch, "feats_injection_mode": "after_backbone"}},
-        head_cfg={"type": "convhead", "params": dict(in_channels=dim, num_layers=2, num_classes=1)},
-        embed_coords_cfg={"type": "patchEmbed", "params": dict(img_size=(args.size, args.size), patch_size=(14, 14), embed_dim=dim)},
-        upsampler_cfg={"type": args.upsampler, "params": None},
-        use_disks=True, norm_radius=5, with_prev_mask=True).cuda()
+    model = iSegProbeModel(**model_configs(args.model, args.size, args.arch, args.upsampler, args.injection),
+                           use_disks=True, norm_radius=5, with_prev_mask=True).cuda()
     trainer = DataParallelTrainer(model, lr=args.lr)
     rng = np.random.default_rng(100 + D.get_rank())
     if D.get_rank() == 0:
-        print(f"world {D.get_world_size()}  trainable bucket {trainer.bucket.nbytes() / 1e6:.1f} MB  "
+        print(f"model {args.model}  world {D.get_world_size()}  trainable bucket {trainer.bucket.nbytes() / 1e6:.1f} MB  "
               f"per-GPU batch {args.batch} @ {args.size}^2")
     for step in range(args.steps):
         batch = synthetic_batch(args.batch, args.size, rng)
