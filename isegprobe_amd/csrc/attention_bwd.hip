@@ -78,7 +78,10 @@ struct Side {  // one side of the attention (queries or keys): two row-major [L,
 
 // OWN_KEYS: owner side = keys (outputs dK = out1 with m-stream Q, dV = out2 with stream dO);
 // otherwise owner side = queries (output dQ = out1 with stream K).
-template <int HD, bool OWN_KEYS>
+// OW: 16-row owner sub-tiles per wave (the block owns 64*OW rows).  The streamed fragments -- the whole LDS read
+// volume -- are shared by the OW sub-tiles: with OW = 1 the head_dim-128 launches read 256 LDS cycles per 1024 MFMA
+// cycles per wave, i.e. the LDS port is as busy as the MFMA pipe (330 TFLOP/s on LoftUp's dK/dV); OW = 2 halves that.
+template <int HD, bool OWN_KEYS, int OW>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const float* __restrict__ lse,
                                                        const float* __restrict__ delta, long ld_stat,
                                                        bf16_t* __restrict__ out1, bf16_t* __restrict__ out2, long ob,
@@ -95,21 +98,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
     const int b = blockIdx.y / H, h = blockIdx.y % H;
 
     // ---- owner rows: B operands of the score products, element j <-> d = 32kk + 8fq + j
-    const int orow = blockIdx.x * TB + wid * 16 + fr;
-    const int orow_c = orow < own.L ? orow : own.L - 1;
-    const bf16_t* o1 = own.m1 + (size_t)b * own.sb1 + (size_t)orow_c * own.sl1 + (size_t)h * own.sh1 + 8 * fq;
-    const bf16_t* o2 = own.m2 + (size_t)b * own.sb2 + (size_t)orow_c * own.sl2 + (size_t)h * own.sh2 + 8 * fq;
-    bf16x8 own1[KK], own2[KK];
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-        own1[kk] = *reinterpret_cast<const bf16x8*>(o1 + 32 * kk);
-        own2[kk] = *reinterpret_cast<const bf16x8*>(o2 + 32 * kk);
-    }
+    int orow[OW];
+    bf16x8 own1[OW][KK], own2[OW][KK];
+    float lse_o[OW], delta_o[OW];
     const size_t stat_row = (size_t)blockIdx.y * ld_stat;
-    float lse_o = 0.f, delta_o = 0.f;
-    if (!OWN_KEYS) {
-        lse_o = lse[stat_row + orow_c];
-        delta_o = delta[stat_row + orow_c];
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+        orow[ow] = (blockIdx.x * OW + ow) * TB + wid * 16 + fr;
+        const int oc = orow[ow] < own.L ? orow[ow] : own.L - 1;
+        const bf16_t* o1 = own.m1 + (size_t)b * own.sb1 + (size_t)oc * own.sl1 + (size_t)h * own.sh1 + 8 * fq;
+        const bf16_t* o2 = own.m2 + (size_t)b * own.sb2 + (size_t)oc * own.sl2 + (size_t)h * own.sh2 + 8 * fq;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            own1[ow][kk] = *reinterpret_cast<const bf16x8*>(o1 + 32 * kk);
+            own2[ow][kk] = *reinterpret_cast<const bf16x8*>(o2 + 32 * kk);
+        }
+        lse_o[ow] = delta_o[ow] = 0.f;
+        if (!OWN_KEYS) {
+            lse_o[ow] = lse[stat_row + oc];
+            delta_o[ow] = delta[stat_row + oc];
+        }
     }
 
     // ---- DMA: a tile image = PIECES pieces of 1 KiB (1024/ROW rows each); wave w takes pieces w, w+4, ...
@@ -145,9 +153,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
             t_off[dt] = row * G::ROW + (G::tswz(row, 2 * dt + (colb >> 4)) << 4) + (colb & 15);
     }
 
-    f32x4 acc1[DT], acc2[DT];  // out^T tiles: [dt] -> rows d = 16dt + 4fq + r, column o = fr
+    f32x4 acc1[OW][DT], acc2[OW][DT];  // out^T tiles: [dt] -> rows d = 16dt + 4fq + r, column o = fr
 #pragma unroll
-    for (int i = 0; i < DT; ++i) acc1[i] = acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ow = 0; ow < OW; ++ow)
+#pragma unroll
+        for (int i = 0; i < DT; ++i) acc1[ow][i] = acc2[ow][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = (str.L + TB - 1) / TB;
     stage(0, smem);
@@ -155,22 +165,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
     for (int t = 0; t < nt; ++t) {
         const char* buf = smem + (t & 1) * STAGE;
         if (t + 1 < nt) stage(t + 1, smem + ((t + 1) & 1) * STAGE);
-
-        f32x4 x1[4], x2[4];  // [mi]: streamed rows s = 16mi + 4fq + r, owner o = fr
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            x1[mi] = x2[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < 4; ++mi) {  // 16 streamed rows s = 16mi + 4fq + r at a time, owner o = fr
+            f32x4 x1[OW], x2[OW];
+#pragma unroll
+            for (int ow = 0; ow < OW; ++ow) x1[ow] = x2[ow] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(buf + mi * 16 * G::ROW + r_off[kk]);
                 const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(buf + TILE + mi * 16 * G::ROW + r_off[kk]);
-                x1[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, own1[kk], x1[mi], 0, 0, 0);
-                x2[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, own2[kk], x2[mi], 0, 0, 0);
-            }
-        }
-        // P and dS in place (x1 -> P, x2 -> dS)
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+                for (int ow = 0; ow < OW; ++ow) {
+                    x1[ow] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, own1[ow][kk], x1[ow], 0, 0, 0);
+                    x2[ow] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, own2[ow][kk], x2[ow], 0, 0, 0);
+                }
+            }
+            // P and dS in place (x1 -> P, x2 -> dS)
             const int sbase = t * TB + 16 * mi + 4 * fq;
             float l4[4], d4[4];
             if (OWN_KEYS) {  // statistics belong to the streamed (query) rows; buffers are padded to 64
@@ -178,45 +188,48 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
                 const float4 dv = *reinterpret_cast<const float4*>(delta + stat_row + sbase);
                 l4[0] = lv.x, l4[1] = lv.y, l4[2] = lv.z, l4[3] = lv.w;
                 d4[0] = dv.x, d4[1] = dv.y, d4[2] = dv.z, d4[3] = dv.w;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) l4[r] = lse_o, d4[r] = delta_o;
             }
+            s16x4 ds[OW], pp[OW];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = sbase + r < str.L && orow < own.L;
-                const float p = ok ? __builtin_amdgcn_exp2f(x1[mi][r] * c - l4[r]) : 0.f;
-                x1[mi][r] = p;
-                x2[mi][r] = ok ? p * (x2[mi][r] - d4[r]) * scale : 0.f;
+            for (int ow = 0; ow < OW; ++ow) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = sbase + r < str.L && orow[ow] < own.L;
+                    const float lv = OWN_KEYS ? l4[r] : lse_o[ow], dv = OWN_KEYS ? d4[r] : delta_o[ow];
+                    const float p = ok ? __builtin_amdgcn_exp2f(x1[ow][r] * c - lv) : 0.f;
+                    pp[ow][r] = (short)f2bf(p);
+                    ds[ow][r] = (short)f2bf(ok ? p * (x2[ow][r] - dv) * scale : 0.f);
+                }
             }
-        }
-        // out1^T += stream1^T . dS ; out2^T += stream2^T . P   (contraction over the 16 streamed rows of tile mi)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const s16x4 ds = {(short)f2bf(x2[mi][0]), (short)f2bf(x2[mi][1]), (short)f2bf(x2[mi][2]), (short)f2bf(x2[mi][3])};
-            const s16x4 pp = {(short)f2bf(x1[mi][0]), (short)f2bf(x1[mi][1]), (short)f2bf(x1[mi][2]), (short)f2bf(x1[mi][3])};
+            // out1^T += stream1^T . dS ; out2^T += stream2^T . P   (contraction over these 16 streamed rows)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const s16x4 a1 = tr_read(buf + 2 * TILE + mi * 16 * G::ROW + t_off[dt]);
-                acc1[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, ds, acc1[dt], 0, 0, 0);
+#pragma unroll
+                for (int ow = 0; ow < OW; ++ow)
+                    acc1[ow][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, ds[ow], acc1[ow][dt], 0, 0, 0);
                 if (OWN_KEYS) {
                     const s16x4 a2 = tr_read(buf + 3 * TILE + mi * 16 * G::ROW + t_off[dt]);
-                    acc2[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, pp, acc2[dt], 0, 0, 0);
+#pragma unroll
+                    for (int ow = 0; ow < OW; ++ow)
+                        acc2[ow][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, pp[ow], acc2[ow][dt], 0, 0, 0);
                 }
             }
         }
         __syncthreads();
     }
 
-    if (orow < own.L) {
-        const size_t off = (size_t)b * ob + (size_t)orow * ol + (size_t)h * oh + 4 * fq;
+#pragma unroll
+    for (int ow = 0; ow < OW; ++ow) {
+        if (orow[ow] >= own.L) continue;
+        const size_t off = (size_t)b * ob + (size_t)orow[ow] * ol + (size_t)h * oh + 4 * fq;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             *reinterpret_cast<uint2*>(out1 + off + 16 * dt) =
-                make_uint2(pack2bf(acc1[dt][0], acc1[dt][1]), pack2bf(acc1[dt][2], acc1[dt][3]));
+                make_uint2(pack2bf(acc1[ow][dt][0], acc1[ow][dt][1]), pack2bf(acc1[ow][dt][2], acc1[ow][dt][3]));
             if (OWN_KEYS)
                 *reinterpret_cast<uint2*>(out2 + off + 16 * dt) =
-                    make_uint2(pack2bf(acc2[dt][0], acc2[dt][1]), pack2bf(acc2[dt][2], acc2[dt][3]));
+                    make_uint2(pack2bf(acc2[ow][dt][0], acc2[ow][dt][1]), pack2bf(acc2[ow][dt][2], acc2[ow][dt][3]));
         }
     }
 }
@@ -224,18 +237,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
 template <int HD, bool OWN_KEYS>
 int launch_bwd(const Side& own, const Side& str, const float* lse, const float* delta, long ld, void* out1, void* out2,
                long ob, long ol, long oh, int B, int H, float scale, hipStream_t s) {
+    // head_dim 128 runs one block per CU anyway (LDS): give each wave 32 owner rows there when the owner side is long
+    // enough to still fill the chip; head_dim 64 keeps 16 (2 blocks per CU, more blocks for the short ViT sequences)
     constexpr int lds = 2 * (OWN_KEYS ? 4 : 3) * BGeo<HD>::TILE;
-    static bool attr_done = false;
-    auto kern = attn_bwd_kernel<HD, OWN_KEYS>;
-    if (!attr_done) {
+    const bool wide = HD == 128 && (long)((own.L + 2 * TB - 1) / (2 * TB)) * B * H >= 256;
+    auto launch = [&](auto kern, int ow) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return ISP_ERR_LAUNCH;
-        attr_done = true;
+            return (int)ISP_ERR_LAUNCH;
+        dim3 grid((own.L + ow * TB - 1) / (ow * TB), B * H);
+        kern<<<grid, 256, lds, s>>>(own, str, lse, delta, ld, (bf16_t*)out1, (bf16_t*)out2, ob, ol, oh, H, scale,
+                                   scale * 1.4426950408889634f);
+        return isp_launch_status();
+    };
+    if constexpr (HD == 128) {
+        if (wide) return launch(attn_bwd_kernel<HD, OWN_KEYS, 2>, 2);
     }
-    dim3 grid((own.L + TB - 1) / TB, B * H);
-    kern<<<grid, 256, lds, s>>>(own, str, lse, delta, ld, (bf16_t*)out1, (bf16_t*)out2, ob, ol, oh, H, scale,
-                               scale * 1.4426950408889634f);
-    return isp_launch_status();
+    return launch(attn_bwd_kernel<HD, OWN_KEYS, 1>, 1);
 }
 
 }  // namespace

@@ -220,7 +220,8 @@ def test_logits_resize_backward(ops):
     assert rel(ops.resize_bilinear_nchw_f32_bwd(g, 4, 5), x.grad) < 1e-5
 
 
-@pytest.mark.parametrize("B,Lq,Lk,H,hd,real", [(2, 300, 130, 2, 128, 101), (1, 3136, 16, 4, 128, 37), (2, 200, 77, 3, 64, 64)])
+@pytest.mark.parametrize("B,Lq,Lk,H,hd,real", [(2, 300, 130, 2, 128, 101), (1, 3136, 16, 4, 128, 37), (2, 200, 77, 3, 64, 64),
+                                               (8, 1190, 1100, 4, 128, 101)])  # last: 32 owner rows per wave (both launches)
 def test_cross_attention_backward(ops, B, Lq, Lk, H, hd, real):
     """Lq != Lk, head_dim 128 with zero padding beyond `real` (LoftUp: 101 -> 128), dQ optional."""
     torch.manual_seed(Lq)
