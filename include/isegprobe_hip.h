@@ -114,11 +114,11 @@ int isp_sum_partials_f32(const float* partial, float* out, long M, int slots, fl
 int isp_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, long rows, int D, float eps,
                       int in_dtype, int out_dtype, int group_out, int skip, long ld_in, long ld_out, void* stream);
 
-/* ---- softmax(Q K^T * scale) V, head_dim 64 or 128, bf16 in/out, fp32 online softmax; never
+/* ---- softmax(Q K^T * scale) V, head_dim 64, 128 or 256, bf16 in/out, fp32 online softmax; never
  * materialises the score matrix.  Element strides are explicit so the packed qkv tensor of
  * attention.py:56-60 is consumed in place.  Q [B,Lq,H,hd], K/V [B,Lk,H,hd], O [B,Lq,H,hd].
  * Also replaces nn.MultiheadAttention in LoftUp's CrossAttentionLayer (loftup/layers.py:182-198),
- * head_dim 101 zero-padded to 128. */
+ * head_dim 101 zero-padded to 128 (n_dim 384) or 197 zero-padded to 256 (n_dim 768, BASELINE configs[4]). */
 int isp_attention_fwd(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, int head_dim,
                       long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
                       long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
@@ -130,7 +130,7 @@ int isp_attention_fwd_lse(const void* Q, const void* K, const void* V, void* O, 
                           long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
                           float scale, void* stream);
 
-/* ---- Backward of isp_attention_fwd (head_dim 64 or 128): dQ (nullable: skipped), dK, dV (bf16, strides of Q / of K,V) from O, dO (strides
+/* ---- Backward of isp_attention_fwd (head_dim 64, 128 or 256): dQ (nullable: skipped), dK, dV (bf16, strides of Q / of K,V) from O, dO (strides
  * o_stride_*) and lse.  delta is a [B*H, stat_ld] fp32 workspace (rowsum(dO*O)); stat_ld % 64 == 0 is the row
  * stride of BOTH lse and delta.  What autograd does for Attention.forward (dinov2/layers/attention.py:54-71) when the
  * reference trains with feats_injection_mode="before_backbone" (models/sbd/dinov2/patch-embed_*.py:40); the

@@ -143,9 +143,9 @@ class LoftUpUpsampler(BaseUpsampler):
             c = C + lu.lr_pe_dim
             cp, fin, fin_p = _pad64(c), 10 * lu.n_freqs + 3, _pad64(10 * lu.n_freqs + 3)
             hd = c // heads
-            hdp = 64 if hd <= 64 else 128
-            if c % heads or hd > 128:
-                raise NotImplementedError("head dim > 128")
+            hdp = 64 if hd <= 64 else (128 if hd <= 128 else 256)  # n_dim 384 -> 101 -> 128; n_dim 768 -> 197 -> 256
+            if c % heads or hd > 256:
+                raise NotImplementedError("head dim > 256")
             f32 = lambda t: t.detach().float().contiguous()
 
             def padded(w, rows, cols):  # [r, k] -> zero-padded bf16 [rows, cols]

@@ -40,7 +40,7 @@ struct Geo {
     // 128-byte rows: 16 consecutive rows share 2 bank-row positions -> spread with (row>>1)&7;
     // 256-byte rows: every row starts on the same bank -> spread with row&15.
     __device__ static __forceinline__ int kswz(int row, int chunk) {
-        return HD == 64 ? chunk ^ ((row >> 1) & 7) : chunk ^ (row & 15);
+        return HD == 64 ? chunk ^ ((row >> 1) & 7) : chunk ^ (row & 15);  // 256- and 512-byte rows alike
     }
     // transposed reads touch 4 consecutive key rows x 64 contiguous bytes per half-wave
     __device__ static __forceinline__ int vswz(int row, int chunk) {
@@ -257,6 +257,9 @@ static int attention_fwd_impl(const void* Q, const void* K, const void* V, void*
                                     kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
     if (head_dim == 128)
         return launch_attention<128>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                                     kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
+    if (head_dim == 256)
+        return launch_attention<256>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
                                      kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
     return ISP_ERR_UNSUPPORTED;
 }

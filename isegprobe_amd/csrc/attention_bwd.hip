@@ -1,4 +1,4 @@
-// Backward of softmax(Q K^T * scale) V for head_dim 64 and 128 on gfx950 (bf16 MFMA, fp32 accumulate):
+// Backward of softmax(Q K^T * scale) V for head_dim 64, 128 and 256 on gfx950 (bf16 MFMA, fp32 accumulate):
 // dQ, dK, dV from Q, K, V, O, dO and the forward's log-sum-exp; the [Lq, Lk] probability matrix
 // is recomputed tile by tile and never stored.
 //
@@ -33,9 +33,10 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) {
 }
 template <int HD>
 struct BGeo {
-    static constexpr int ROW = HD * 2;            // bytes per row (128 or 256)
+    static constexpr int ROW = HD * 2;            // bytes per row (128, 256 or 512)
     static constexpr int CHUNKS = ROW / 16;       // 16-byte chunks per row
-    static constexpr int TILE = TB * ROW;         // one streamed tile image
+    static constexpr int STR = HD == 256 ? 32 : 64;  // streamed rows per tile (4 images x 2 stages must fit 160 KiB)
+    static constexpr int TILE = STR * ROW;        // one streamed tile image
     static constexpr int ROWS_PER_PIECE = 1024 / ROW;
     static constexpr int PIECES = TILE / 1024;    // 1 KiB DMA pieces per image (8 or 16)
     static constexpr int KK = HD / 32;            // k-steps of the score products
@@ -45,6 +46,7 @@ struct BGeo {
         return HD == 64 ? chunk ^ ((row >> 1) & 7) : chunk ^ (row & 15);
     }
     // tr-read image: a half-wave touches 8 rows x 32 B; spread the 32-B pair index over the rows
+    // (256- and 512-byte rows all start on bank 0: the same XOR serves both)
     __device__ static __forceinline__ int tswz(int row, int chunk) {
         return HD == 64 ? chunk ^ (((row >> 1) & 3) << 1) : chunk ^ ((row & 7) << 1);
     }
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
         for (int i = 0; i < G::PIECES / 4; ++i) {
             const int piece = wid + 4 * i;
             const int row = piece * G::ROWS_PER_PIECE + lane / G::CHUNKS, pch = lane % G::CHUNKS;
-            int g = tile * TB + row;
+            int g = tile * G::STR + row;
             g = g < str.L ? g : str.L - 1;
             const bf16_t* r1 = s1 + (size_t)g * str.sl1;
             const bf16_t* r2 = s2 + (size_t)g * str.sl2;
@@ -159,14 +161,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
 #pragma unroll
         for (int i = 0; i < DT; ++i) acc1[ow][i] = acc2[ow][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (str.L + TB - 1) / TB;
+    const int nt = (str.L + G::STR - 1) / G::STR;
     stage(0, smem);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const char* buf = smem + (t & 1) * STAGE;
         if (t + 1 < nt) stage(t + 1, smem + ((t + 1) & 1) * STAGE);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {  // 16 streamed rows s = 16mi + 4fq + r at a time, owner o = fr
+        for (int mi = 0; mi < G::STR / 16; ++mi) {  // 16 streamed rows s = 16mi + 4fq + r at a time, owner o = fr
             f32x4 x1[OW], x2[OW];
 #pragma unroll
             for (int ow = 0; ow < OW; ++ow) x1[ow] = x2[ow] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
                 }
             }
             // P and dS in place (x1 -> P, x2 -> dS)
-            const int sbase = t * TB + 16 * mi + 4 * fq;
+            const int sbase = t * G::STR + 16 * mi + 4 * fq;
             float l4[4], d4[4];
             if (OWN_KEYS) {  // statistics belong to the streamed (query) rows; buffers are padded to 64
                 const float4 lv = *reinterpret_cast<const float4*>(lse + stat_row + sbase);
@@ -293,6 +295,10 @@ extern "C" int isp_attention_bwd(const void* Q, const void* K, const void* V, co
                                       scale, s);
     if (head_dim == 128)
         return attention_bwd_impl<128>(Q, K, V, O, dO, lse, delta, stat_ld, dQ, dK, dV, B, H, Lq, Lk, q_stride_b, q_stride_l,
+                                       q_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h,
+                                       scale, s);
+    if (head_dim == 256)
+        return attention_bwd_impl<256>(Q, K, V, O, dO, lse, delta, stat_ld, dQ, dK, dV, B, H, Lq, Lk, q_stride_b, q_stride_l,
                                        q_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h,
                                        scale, s);
     return ISP_ERR_UNSUPPORTED;

@@ -373,8 +373,8 @@ def attention_lse(q, k, v, scale):
     hd = q.shape[3]
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _need(t, BF16, n, contiguous=False)
-        if t.stride(3) != 1 or t.shape[3] != hd or hd not in (64, 128):
-            raise IspError(f"{n}: head_dim must be 64 or 128 with unit stride")
+        if t.stride(3) != 1 or t.shape[3] != hd or hd not in (64, 128, 256):
+            raise IspError(f"{n}: head_dim must be 64, 128 or 256 with unit stride")
     if k.stride() != v.stride():
         raise IspError("k and v must share strides")
     B, Lq, H, _ = q.shape
@@ -393,8 +393,8 @@ def attention(q, k, v, scale):
     hd = q.shape[3]
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _need(t, BF16, n, contiguous=False)
-        if t.stride(3) != 1 or t.shape[3] != hd or hd not in (64, 128):
-            raise IspError(f"{n}: head_dim must be 64 or 128 with unit stride")
+        if t.stride(3) != 1 or t.shape[3] != hd or hd not in (64, 128, 256):
+            raise IspError(f"{n}: head_dim must be 64, 128 or 256 with unit stride")
     if k.stride() != v.stride():
         raise IspError("k and v must share strides")
     B, Lq, H, _ = q.shape

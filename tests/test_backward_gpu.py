@@ -221,7 +221,8 @@ def test_logits_resize_backward(ops):
 
 
 @pytest.mark.parametrize("B,Lq,Lk,H,hd,real", [(2, 300, 130, 2, 128, 101), (1, 3136, 16, 4, 128, 37), (2, 200, 77, 3, 64, 64),
-                                               (8, 1190, 1100, 4, 128, 101)])  # last: 32 owner rows per wave (both launches)
+                                               (8, 1190, 1100, 4, 128, 101),   # 32 owner rows per wave (both launches)
+                                               (2, 333, 150, 2, 256, 197)])   # LoftUp(768): head_dim 197 padded to 256
 def test_cross_attention_backward(ops, B, Lq, Lk, H, hd, real):
     """Lq != Lk, head_dim 128 with zero padding beyond `real` (LoftUp: 101 -> 128), dQ optional."""
     torch.manual_seed(Lq)

@@ -72,6 +72,23 @@ def test_jbu_stages_and_stack_vs_oracle():
     assert err.pow(2).mean().sqrt().item() < 5e-3 * max(1.0, ref.pow(2).mean().sqrt().item())
 
 
+def test_attention_hd256():
+    """head_dim 197 zero-padded to 256: LoftUp(n_dim=768)'s cross-attention (BASELINE configs[4])."""
+    from isegprobe_amd import hip_ops as ops
+    torch.manual_seed(2)
+    B, Lq, Lk, H, hd, real = 2, 500, 260, 4, 256, 197
+    def mk(L):
+        t = torch.randn(B, L, H, hd, device="cuda")
+        t[..., real:] = 0
+        return t.to(torch.bfloat16)
+    q, k, v = mk(Lq), mk(Lk), mk(Lk)
+    out = ops.attention(q, k, v, real ** -0.5)
+    p = ((q.float().permute(0, 2, 1, 3) * real ** -0.5) @ k.float().permute(0, 2, 3, 1)).softmax(-1)
+    ref = (p @ v.float().permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+    assert (out.float() - ref).abs().max().item() < 2e-2
+    assert out[..., real:].abs().max().item() == 0
+
+
 def test_attention_hd128():
     from isegprobe_amd import hip_ops as ops
     torch.manual_seed(3)
@@ -133,3 +150,35 @@ def test_lift_vs_golden(golden):
     err = (y - ref).abs()
     print("lift max err", err.max().item(), "rms", err.pow(2).mean().sqrt().item(), "ref rms", ref.pow(2).mean().sqrt().item())
     assert err.max().item() < 3e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_loftup_768_vs_oracle():
+    """LoftUp(n_dim=768), the upsampler of BASELINE configs[4] (DINOv2-B/14): 788 channels (832 padded), 4 heads of
+    197 (padded to 256 for the fused attention), vs the CPU oracle with seeded weights; and its gradient w.r.t. the LR
+    features (head_dim-256 attention backward) vs autograd of the oracle."""
+    from isegprobe_amd.core.model.upsamplers import LoftUpUpsampler
+    from oracle import upsamplers as oups
+    torch.manual_seed(4)
+    up = seeded_(LoftUpUpsampler(None, n_dim=768), 11)
+    w = {"upsampler." + k: v.clone() for k, v in up.upsampler.state_dict().items()}
+    src = torch.randn(1, 768, 3, 4)
+    gd = torch.randn(1, 3, 42, 56)
+    src_ref = src.clone().requires_grad_(True)
+    ref = oups.loftup(src_ref, gd, w, "upsampler.")
+    coef = torch.randn_like(ref)
+    (ref * coef).sum().backward()
+    up = up.cuda().eval()
+    with torch.no_grad():
+        y = _f32(up(src.cuda(), gd.cuda()))
+    err = (y - ref.detach()).abs()
+    print("loftup768 max err", err.max().item(), "rms", err.pow(2).mean().sqrt().item(), "ref rms", ref.pow(2).mean().sqrt().item())
+    assert err.max().item() < 6e-2 * max(1.0, ref.abs().max().item())
+    assert err.pow(2).mean().sqrt().item() < 1e-2 * max(1.0, ref.pow(2).mean().sqrt().item())
+    s = src.cuda().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).requires_grad_(True)  # NHWC storage
+    out = up(s, gd.cuda())
+    (out.float() * coef.cuda()).sum().backward()
+    got, want = s.grad.float().cpu(), src_ref.grad
+    cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
+    rms = (got - want).pow(2).mean().sqrt().item() / want.pow(2).mean().sqrt().item()
+    print(f"loftup768 grad: cos {cos:.6f} rms-rel {rms:.3e}")
+    assert cos > 0.995 and rms < 0.1
