@@ -389,8 +389,6 @@ __global__ __launch_bounds__(256) void layernorm_wgrad_kernel(const TX* __restri
     }
 }
 
-}  // namespace
-
 // ---------------------------------------------------------------------------------------
 // LayerNorm backward w.r.t. the input (weights frozen), one wave per INPUT row:
 //   g^ = gy * gamma,  x^ = (x - mean) * rstd,  dx = rstd * (g^ - mean(g^) - x^ * mean(g^ x^)).
@@ -490,6 +488,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
         }
     }
 }
+
+}  // namespace
 
 extern "C" int isp_tn_gemm_bf16_atomic(const void* P, long ldp, const void* Q, long ldq, float* out, long ldo, long M,
                                        int N, int J, int shift_H, int shift_W, int shift_dy, int shift_dx,
