@@ -224,6 +224,12 @@ def main():
                          "traffic_note": "fabric bytes per launch from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_conv_pmc.json",
                          "launch_ms": conv_ms, "flops_per_launch": ct.flops},
         }
+        try:  # on-box probe of the dense-bf16 ceiling on random operands (profiles/r01_peaks.json; tools/peaks.py)
+            pk = json.load(open(os.path.join(ROOT, "profiles", "r01_peaks.json")))["mfma_bf16_16x16x32_register_loop_tflops"]
+            line["roofline"]["peak_measured_random_operands"] = pk["random"]
+            line["roofline"]["frac_of_measured"] = achieved / pk["random"]
+        except Exception:
+            pass
         if not args.no_stages:
             try:
                 st = stage_times(model, image, points)

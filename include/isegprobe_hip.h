@@ -274,6 +274,12 @@ long isp_next_points_workspace_bytes(int B, int H, int W);
 int isp_next_points(const float* pred, const float* gt, float* points, const unsigned* rand32, int B, int H, int W, int P,
                     int click_indx, float pred_thresh, void* workspace, void* stream);
 
+/* ---- On-box roofline probes (diagnostics; tools/peaks.py): a register-resident v_mfma_f32_16x16x32_bf16 loop
+ * (blocks x 4 waves x iters x 16 MFMAs; operands read once from a 64 Ki-element bf16 seed: zeros vs random bits show the
+ * clock the chip holds) and a float4 copy of `bytes` bytes. */
+int isp_probe_mfma_bf16(const void* seed_bf16_64k, float* sink, int blocks, int iters, void* stream);
+int isp_probe_copy(const void* src, void* dst, long bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
