@@ -37,6 +37,7 @@ struct TileCfg {
     static_assert(NST == 2 || NST == 3, "ring depth");
 };
 using Cfg128 = TileCfg<128, 128, 2, 2, 2>;    // 4 waves, 64 KiB LDS, 2 blocks / CU   (short-K dense layers)
+using Cfg64 = TileCfg<64, 128, 1, 4, 2>;      // 4 waves, 48 KiB LDS: twice the blocks for problems that cannot fill 256 CUs
 // large-K implicit conv: 8 waves, 1 block / CU.  Measured on the seg-head conv (B=8, 448^2, C=N=384):
 // 128x128 1050, 256x128 1050, 128x384 1127, 256x192 1161 TFLOP/s.
 #ifndef ISP_CONV192
@@ -831,6 +832,8 @@ extern "C" int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, in
     // M = 1.6 M-row layers.  With >= 512 row tiles of 256 the 8-wave 256x192 tile (110 FLOP/B) runs them at
     // 460-556 even when N is not a multiple of 192; ViT-sized problems (M = 33 k) lose 10 % on it and stay on 128x128.
     if ((M + 255) / 256 >= 512 && N >= 384) return run(CfgConv192{});
+    // the batch-2 click loop (M = 2050 tokens): 128-row tiles give 153 blocks for 256 CUs; 64-row tiles fill the chip
+    if (((M + 127) / 128) * ((N + 127) / 128) < 256) return run(Cfg64{});
     return run(Cfg128{});
 }
 
