@@ -1,0 +1,85 @@
+"""GPU, two processes on one device (gloo over CUDA tensors; the multi-GPU runs use backend "nccl" = RCCL with the same
+code): the data-parallel train step on the HIP path -- per-rank minibatch shards, ONE flat-bucket gradient all-reduce,
+identical parameters on every rank after the optimiser steps, and rank-averaged gradients equal to the gradients of the
+whole batch in one process."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _batch():
+    torch.manual_seed(3)
+    image = torch.rand(4, 3, 56, 56)
+    gt = torch.zeros(4, 1, 56, 56)
+    gt[:, :, 12:40, 10:44] = 1
+    gt[2:, :, 5:20, 30:50] = 1
+    pts = -np.ones((4, 6, 3), np.float32)
+    for b in range(4):
+        pts[b, 0] = (20 + b, 25, 0)
+    return image, gt, torch.from_numpy(pts)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import build_model, seeded_
+    from isegprobe_amd.core.training.trainer import DataParallelTrainer
+    from isegprobe_amd.core.utils import distributed as D
+    torch.cuda.set_device(0)
+    if world > 1:
+        assert D.init_distributed("gloo")
+    model = seeded_(build_model("bilinear", injection="before_backbone"), 9).cuda()
+    image, gt, pts = _batch()
+    sl = slice(rank * 4 // world, (rank + 1) * 4 // world)
+    batch = {"images": image[sl].cuda(), "instances": gt[sl].cuda(), "points": pts[sl].cuda()}
+    trainer = DataParallelTrainer(model, lr=1e-3)
+    trainer.net.train()
+    trainer.bucket.zero()
+    loss, _ = trainer.batch_forward(batch, num_iters=0)
+    loss.backward()
+    work = trainer.bucket.all_reduce_mean(async_op=True)
+    trainer.bucket.finish(work)
+    grads = trainer.bucket.flat.clone().cpu()
+    for _ in range(2):
+        trainer.step(batch, num_iters=0)
+    params = torch.cat([p.detach().flatten().cpu() for p in trainer.bucket.params])
+    out.put((rank, world, grads.numpy(), params.numpy()))  # numpy: plain pickles, no fd passing after exit
+    if world > 1:
+        D.synchronize()
+        torch.distributed.destroy_process_group()
+
+
+def test_two_rank_train_step_on_one_gpu():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs.append(ctx.Process(target=_worker, args=(0, 1, _free_port(), out)))  # the whole batch in one process
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    two = sorted([r for r in res if r[1] == 2], key=lambda r: r[0])
+    one = [r for r in res if r[1] == 1][0]
+    assert np.array_equal(two[0][2], two[1][2])       # the all-reduce left the same averaged gradients on both ranks
+    assert np.array_equal(two[0][3], two[1][3])       # ... and the replicas stay bit-identical through Adam steps
+    g2, g1 = torch.from_numpy(two[0][2]), torch.from_numpy(one[2])
+    cos = torch.nn.functional.cosine_similarity(g2, g1, dim=0).item()
+    rel = (g2 - g1).norm().item() / g1.norm().item()
+    print(f"rank-averaged vs whole-batch gradients: cos {cos:.6f} rel {rel:.3e}")
+    assert cos > 0.9999 and rel < 2e-2                # fp32 atomics: summation order differs, values agree
