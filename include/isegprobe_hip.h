@@ -134,11 +134,14 @@ int isp_attention_fwd_lse(const void* Q, const void* K, const void* V, void* O, 
  * o_stride_*) and lse.  delta is a [B*H, stat_ld] fp32 workspace (rowsum(dO*O)); stat_ld % 64 == 0 is the row
  * stride of BOTH lse and delta.  What autograd does for Attention.forward (dinov2/layers/attention.py:54-71) when the
  * reference trains with feats_injection_mode="before_backbone" (models/sbd/dinov2/patch-embed_*.py:40); the
- * probability matrix is recomputed per 64x64 tile, never stored. */
+ * probability matrix is recomputed per 64x64 tile, never stored.  kv_split_workspace (nullable): 2*B*Lk*H*head_dim fp32;
+ * when given and the key side alone cannot fill the chip (few keys, many queries: LoftUp's cross-attention at the training
+ * crop) the query range is split over several blocks that add fp32 partials of dK / dV into it. */
 int isp_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                       float* delta, long stat_ld, void* dQ, void* dK, void* dV, int B, int H, int Lq, int Lk, int head_dim,
                       long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
-                      long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
+                      long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale,
+                      float* kv_split_workspace, void* stream);
 
 /* ---- LayerNorm backward w.r.t. the input (frozen affine): gx (fp32, row stride ld_gx) (+)= dLN(x; gamma)(gy),
  * statistics recomputed from x (fp32 or bf16, row stride ld_x, first D columns); gy bf16 (row stride ld_gy); optional

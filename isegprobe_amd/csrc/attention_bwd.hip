@@ -20,6 +20,8 @@
 // v_mfma_f32_16x16x16_bf16, whose A operand (streamed tile transposed) comes from
 // ds_read_b64_tr_b16: P / dS never touch LDS.  Streamed tiles are staged twice by LDS-DMA, once
 // swizzled for the row reads and once for the transposed reads (source-side XOR swizzles).
+#include <algorithm>
+
 #include "isp_common.h"
 
 namespace {
@@ -87,7 +89,10 @@ template <int HD, bool OWN_KEYS, int OW>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const float* __restrict__ lse,
                                                        const float* __restrict__ delta, long ld_stat,
                                                        bf16_t* __restrict__ out1, bf16_t* __restrict__ out2, long ob,
-                                                       long ol, long oh, int H, float scale, float c) {
+                                                       long ol, long oh, int H, float scale, float c,
+                                                       float* __restrict__ part1, float* __restrict__ part2) {
+    // part1 / part2 (nullable): split launch -- gridDim.z blocks share the streamed range of one owner block and add
+    // their partial results into fp32 [B, own.L, H, HD] buffers (converted by attn_convert_kernel afterwards).
     // LDS per stage: [stream1 rows][stream2 rows][stream1 tr]([stream2 tr] when OWN_KEYS)
     using G = BGeo<HD>;
     constexpr int TILE = G::TILE, KK = G::KK, DT = G::DT;
@@ -161,12 +166,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
 #pragma unroll
         for (int i = 0; i < DT; ++i) acc1[ow][i] = acc2[ow][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (str.L + G::STR - 1) / G::STR;
-    stage(0, smem);
+    const int nt_all = (str.L + G::STR - 1) / G::STR;
+    const int per = (nt_all + gridDim.z - 1) / gridDim.z;
+    const int t_begin = blockIdx.z * per, nt = min(nt_all, t_begin + per);
+    if (t_begin >= nt) return;
+    stage(t_begin, smem);
     __syncthreads();
-    for (int t = 0; t < nt; ++t) {
-        const char* buf = smem + (t & 1) * STAGE;
-        if (t + 1 < nt) stage(t + 1, smem + ((t + 1) & 1) * STAGE);
+    for (int t = t_begin; t < nt; ++t) {
+        const char* buf = smem + ((t - t_begin) & 1) * STAGE;
+        if (t + 1 < nt) stage(t + 1, smem + ((t - t_begin + 1) & 1) * STAGE);
 #pragma unroll
         for (int mi = 0; mi < G::STR / 16; ++mi) {  // 16 streamed rows s = 16mi + 4fq + r at a time, owner o = fr
             f32x4 x1[OW], x2[OW];
@@ -221,6 +229,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
         __syncthreads();
     }
 
+    if (part1) {  // split launch: fp32 partial sums
+#pragma unroll
+        for (int ow = 0; ow < OW; ++ow) {
+            if (orow[ow] >= own.L) continue;
+            const size_t off = (((size_t)b * own.L + orow[ow]) * H + h) * HD + 4 * fq;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    atomicAdd(part1 + off + 16 * dt + r, acc1[ow][dt][r]);
+                    if (OWN_KEYS) atomicAdd(part2 + off + 16 * dt + r, acc2[ow][dt][r]);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int ow = 0; ow < OW; ++ow) {
         if (orow[ow] >= own.L) continue;
@@ -236,9 +259,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
     }
 }
 
+// fp32 partials [B, L, H, HD] -> bf16 output with the caller's strides
+__global__ void attn_convert_kernel(const float* __restrict__ part, bf16_t* __restrict__ out, long ob, long ol, long oh,
+                                    int L, int H, int hd, long total4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const long e = i * 4;
+    const int d = (int)(e % hd);
+    long t = e / hd;
+    const int h = (int)(t % H);
+    t /= H;
+    const int l = (int)(t % L);
+    const long b = t / L;
+    const float4 v = *reinterpret_cast<const float4*>(part + e);
+    *reinterpret_cast<uint2*>(out + b * ob + (long)l * ol + (long)h * oh + d) = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w));
+}
+
 template <int HD, bool OWN_KEYS>
 int launch_bwd(const Side& own, const Side& str, const float* lse, const float* delta, long ld, void* out1, void* out2,
-               long ob, long ol, long oh, int B, int H, float scale, hipStream_t s) {
+               long ob, long ol, long oh, int B, int H, float scale, hipStream_t s, float* part = nullptr) {
     // head_dim 128 runs one block per CU anyway (LDS): give each wave 32 owner rows there when the owner side is long
     // enough to still fill the chip; head_dim 64 keeps 16 (2 blocks per CU, more blocks for the short ViT sequences)
     constexpr int lds = 2 * (OWN_KEYS ? 4 : 3) * BGeo<HD>::TILE;
@@ -247,8 +286,28 @@ int launch_bwd(const Side& own, const Side& str, const float* lse, const float* 
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return (int)ISP_ERR_LAUNCH;
         dim3 grid((own.L + ow * TB - 1) / (ow * TB), B * H);
+        // Few owner rows and a long streamed side (LoftUp's dK/dV at the 224^2 training crop: 128 blocks for 256 CUs,
+        // each sweeping 784 query tiles): split the streamed range over gridDim.z blocks that add fp32 partials.
+        const long blocks = (long)grid.x * grid.y;
+        const int nt = (str.L + BGeo<HD>::STR - 1) / BGeo<HD>::STR;
+        int nsplit = 1;
+        if (part && blocks < 256 && nt >= 64) nsplit = (int)std::min<long>((512 + blocks - 1) / blocks, nt / 16);
+        if (nsplit > 1) {
+            const size_t bytes = (size_t)B * own.L * H * HD * 4;
+            float* p1 = part;
+            float* p2 = OWN_KEYS ? part + (size_t)B * own.L * H * HD : nullptr;
+            if (hipMemsetAsync(part, 0, bytes * (OWN_KEYS ? 2 : 1), s) != hipSuccess) return (int)ISP_ERR_LAUNCH;
+            grid.z = nsplit;
+            kern<<<grid, 256, lds, s>>>(own, str, lse, delta, ld, (bf16_t*)out1, (bf16_t*)out2, ob, ol, oh, H, scale,
+                                       scale * 1.4426950408889634f, p1, p2);
+            const long total4 = (long)B * own.L * H * HD / 4;
+            attn_convert_kernel<<<(unsigned)((total4 + 255) / 256), 256, 0, s>>>(p1, (bf16_t*)out1, ob, ol, oh, own.L, H, HD, total4);
+            if (OWN_KEYS)
+                attn_convert_kernel<<<(unsigned)((total4 + 255) / 256), 256, 0, s>>>(p2, (bf16_t*)out2, ob, ol, oh, own.L, H, HD, total4);
+            return isp_launch_status();
+        }
         kern<<<grid, 256, lds, s>>>(own, str, lse, delta, ld, (bf16_t*)out1, (bf16_t*)out2, ob, ol, oh, H, scale,
-                                   scale * 1.4426950408889634f);
+                                   scale * 1.4426950408889634f, nullptr, nullptr);
         return isp_launch_status();
     };
     if constexpr (HD == 128) {
@@ -263,14 +322,14 @@ template <int HD>
 int attention_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                        float* delta, long stat_ld, void* dQ, void* dK, void* dV, int B, int H, int Lq, int Lk, long q_stride_b,
                        long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l, long kv_stride_h,
-                       long o_stride_b, long o_stride_l, long o_stride_h, float scale, hipStream_t s) {
+                       long o_stride_b, long o_stride_l, long o_stride_h, float scale, float* kv_part, hipStream_t s) {
     attn_delta_kernel<HD><<<dim3((Lq + 255) / 256, B * H), 256, 0, s>>>((const bf16_t*)O, (const bf16_t*)dO, delta, H, Lq,
                                                                         o_stride_b, o_stride_l, o_stride_h, stat_ld);
     if (int rc = isp_launch_status()) return rc;
     const Side qs{(const bf16_t*)Q, (const bf16_t*)dO, q_stride_b, q_stride_l, q_stride_h, o_stride_b, o_stride_l, o_stride_h, Lq};
     const Side ks{(const bf16_t*)K, (const bf16_t*)V, kv_stride_b, kv_stride_l, kv_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, Lk};
     // dK (stream1 = Q with dS) and dV (stream2 = dO with P): gradients share the K/V strides
-    if (int rc = launch_bwd<HD, true>(ks, qs, lse, delta, stat_ld, dK, dV, kv_stride_b, kv_stride_l, kv_stride_h, B, H, scale, s))
+    if (int rc = launch_bwd<HD, true>(ks, qs, lse, delta, stat_ld, dK, dV, kv_stride_b, kv_stride_l, kv_stride_h, B, H, scale, s, kv_part))
         return rc;
     if (!dQ) return ISP_OK;  // caller does not need the query gradient (LoftUp's first layer: queries come from the image)
     // dQ (stream1 = K with dS)
@@ -281,7 +340,7 @@ extern "C" int isp_attention_bwd(const void* Q, const void* K, const void* V, co
                                  const float* lse, float* delta, long stat_ld, void* dQ, void* dK, void* dV, int B, int H,
                                  int Lq, int Lk, int head_dim, long q_stride_b, long q_stride_l, long q_stride_h,
                                  long kv_stride_b, long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l,
-                                 long o_stride_h, float scale, void* stream) {
+                                 long o_stride_h, float scale, float* kv_split_workspace, void* stream) {
     ISP_CHECK_ARG(Q && K && V && O && dO && lse && delta && dK && dV);
     ISP_CHECK_ARG(B > 0 && H > 0 && Lq > 0 && Lk > 0 && scale > 0.f && (long)B * H <= 65535);
     ISP_CHECK_ARG(stat_ld % TB == 0 && stat_ld >= Lq);  // statistics rows padded: float4 reads of a partial last tile
@@ -292,14 +351,14 @@ extern "C" int isp_attention_bwd(const void* Q, const void* K, const void* V, co
     if (head_dim == 64)
         return attention_bwd_impl<64>(Q, K, V, O, dO, lse, delta, stat_ld, dQ, dK, dV, B, H, Lq, Lk, q_stride_b, q_stride_l,
                                       q_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h,
-                                      scale, s);
+                                      scale, kv_split_workspace, s);
     if (head_dim == 128)
         return attention_bwd_impl<128>(Q, K, V, O, dO, lse, delta, stat_ld, dQ, dK, dV, B, H, Lq, Lk, q_stride_b, q_stride_l,
                                        q_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h,
-                                       scale, s);
+                                       scale, kv_split_workspace, s);
     if (head_dim == 256)
         return attention_bwd_impl<256>(Q, K, V, O, dO, lse, delta, stat_ld, dQ, dK, dV, B, H, Lq, Lk, q_stride_b, q_stride_l,
                                        q_stride_h, kv_stride_b, kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h,
-                                       scale, s);
+                                       scale, kv_split_workspace, s);
     return ISP_ERR_UNSUPPORTED;
 }

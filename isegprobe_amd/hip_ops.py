@@ -267,7 +267,7 @@ def attention_packed_qkv_bwd(qkv, out, dout, lse, B, L, heads, scale):
     dq, dk, dv = (ctypes.c_void_p(gbase + i * D * 2) for i in range(3))
     check(_lib.lib().isp_attention_bwd(q, k, v, _p(out), _p(dout), _p(lse), _p(delta), lse.shape[1], dq, dk, dv,
                                        B, heads, L, L, 64, L * 3 * D, 3 * D, 64, L * 3 * D, 3 * D, 64, L * D, D, 64,
-                                       float(scale), _stream()), "isp_attention_bwd")
+                                       float(scale), None, _stream()), "isp_attention_bwd")
     return dqkv
 
 
@@ -360,10 +360,13 @@ def attention_bwd(q, k, v, out, dout, lse, scale, want_dq=True):
     if want_dq and dq.stride() != q.stride() or dk.stride() != k.stride():
         raise IspError("attention_bwd expects contiguous q, k, v (gradients share their strides)")
     delta = torch.zeros_like(lse)
+    # few keys, many queries (cross-attention): let the kernel split the query range over blocks (fp32 dK/dV partials)
+    split = torch.empty(2 * B * Lk * H * hd, device=q.device, dtype=torch.float32) if Lq >= 64 * Lk // 4 and Lk <= 4096 else None
     check(_lib.lib().isp_attention_bwd(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), _p(delta), lse.shape[1],
                                        _p(dq) if dq is not None else None, _p(dk), _p(dv), B, H, Lq, Lk, hd,
                                        q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
-                                       out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()),
+                                       out.stride(0), out.stride(1), out.stride(2), float(scale),
+                                       _p(split) if split is not None else None, _stream()),
           "isp_attention_bwd")
     return dq, dk, dv
 

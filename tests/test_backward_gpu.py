@@ -222,7 +222,8 @@ def test_logits_resize_backward(ops):
 
 @pytest.mark.parametrize("B,Lq,Lk,H,hd,real", [(2, 300, 130, 2, 128, 101), (1, 3136, 16, 4, 128, 37), (2, 200, 77, 3, 64, 64),
                                                (8, 1190, 1100, 4, 128, 101),   # 32 owner rows per wave (both launches)
-                                               (2, 333, 150, 2, 256, 197)])   # LoftUp(768): head_dim 197 padded to 256
+                                               (2, 333, 150, 2, 256, 197),    # LoftUp(768): head_dim 197 padded to 256
+                                               (2, 12544, 256, 4, 128, 101)])  # LoftUp at the 224^2 crop: split query range, fp32 dK/dV partials
 def test_cross_attention_backward(ops, B, Lq, Lk, H, hd, real):
     """Lq != Lk, head_dim 128 with zero padding beyond `real` (LoftUp: 101 -> 128), dQ optional."""
     torch.manual_seed(Lq)
@@ -236,7 +237,11 @@ def test_cross_attention_backward(ops, B, Lq, Lk, H, hd, real):
     assert torch.equal(out, ops.attention(q, k, v, scale))
     dq, dk, dv = ops.attention_bwd(q, k, v, out, dout, lse, scale)
     none_dq, dk2, dv2 = ops.attention_bwd(q, k, v, out, dout, lse, scale, want_dq=False)
-    assert none_dq is None and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+    assert none_dq is None
+    if Lq < 16 * Lk:  # (the split-query launch adds fp32 partials with atomics: order-dependent rounding)
+        assert torch.equal(dk, dk2) and torch.equal(dv, dv2)
+    else:
+        assert rel(dk, dk2) < 1e-2 and rel(dv, dv2) < 1e-2
     qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
     p = ((qf.permute(0, 2, 1, 3) * scale) @ kf.permute(0, 2, 3, 1)).softmax(-1)
     (p @ vf.permute(0, 2, 1, 3)).permute(0, 2, 1, 3).backward(dout.float())
