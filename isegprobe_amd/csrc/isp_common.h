@@ -55,7 +55,7 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // than their 6-step K loop.
 __device__ __forceinline__ float fast_erf(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));  // v_rcp_f32 (1 ulp); __frcp_rn is a ~10-instruction IEEE divide
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);

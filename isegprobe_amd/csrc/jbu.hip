@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
     const float g0 = G[(b * 3 + 0) * HW + p], g1 = G[(b * 3 + 1) * HW + p], g2 = G[(b * 3 + 2) * HW + p];
     float hid[KEY];
 #pragma unroll
-    for (int j = 0; j < KEY; ++j) hid[j] = gelu_erf(b0[j] + w0[j * 3 + 0] * g0 + w0[j * 3 + 1] * g1 + w0[j * 3 + 2] * g2);
+    // explicit fmaf: the library is built with -ffp-contract=off (bit-exact click maps), which would otherwise split
+    // every multiply-add of these VALU-bound loops into two instructions
+    for (int j = 0; j < KEY; ++j)
+        hid[j] = gelu_erf(fmaf(w0[j * 3 + 2], g2, fmaf(w0[j * 3 + 1], g1, fmaf(w0[j * 3 + 0], g0, b0[j]))));
     float4* o = reinterpret_cast<float4*>(proj + idx * KEY);
 #pragma unroll
     for (int m4 = 0; m4 < KEY / 4; ++m4) {
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
             const int m = m4 * 4 + q;
             float s = b3[m];
 #pragma unroll
-            for (int j = 0; j < KEY; ++j) s += w3[m * KEY + j] * hid[j];
+            for (int j = 0; j < KEY; ++j) s = fmaf(w3[m * KEY + j], hid[j], s);
             r[q] = s;
         }
         o[m4] = make_float4(r[0], r[1], r[2], r[3]);
@@ -75,9 +78,11 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
 }
 
 // --------------------------------------------------------------------------------------
-// Per-pixel 7x7 kernels.  Block = 16x16 pixels; the 22x22 reflect-padded proj tile is staged
-// in LDS (pixel stride padded to 36 floats against bank conflicts).
-constexpr int TS = 16, HALO = TS + 2 * R, PSTRIDE = 36;
+// Per-pixel 7x7 kernels.  Block = 32x8 pixels; the 38x14 reflect-padded proj tile is staged in LDS with a pixel
+// stride of 36 floats (9 sixteen-byte slots: consecutive pixels of ONE row rotate through all 16 slots).  The block is
+// 32 wide so that each 16-lane group of a ds_read_b128 stays inside one tile row -- a 16x16 block mixed two rows per
+// group and 47 % of its LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+constexpr int TSX = 32, TSY = 8, HALOX = TSX + 2 * R, HALOY = TSY + 2 * R, PSTRIDE = 36;
 
 // Composite-kernel tables (host-built, depend only on the output size):
 //   bys[y][ty][ry]  : weight of window row ry (src row base_y(y)+ry) in hr row reflect(y+ty-3)
@@ -98,23 +103,23 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
                                                            int GH, int GW) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);
-    const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
+    const int b = blockIdx.z, ty0 = blockIdx.y * TSY, tx0 = blockIdx.x * TSX;
     const long HW = (long)GH * GW;
-    // stage proj tile (+halo, reflect) : HALO*HALO pixels x 8 float4
-    for (int i = threadIdx.x; i < HALO * HALO * (KEY / 4); i += 256) {
+    // stage proj tile (+halo, reflect) : HALOY*HALOX pixels x 8 float4
+    for (int i = threadIdx.x; i < HALOY * HALOX * (KEY / 4); i += 256) {
         const int c4 = i % (KEY / 4), pix = i / (KEY / 4);
-        const int py = pix / HALO, px = pix % HALO;
+        const int py = pix / HALOX, px = pix % HALOX;
         const int gy = reflect(min(ty0 + py - R, GH - 1 + R), GH), gx = reflect(min(tx0 + px - R, GW - 1 + R), GW);
         *reinterpret_cast<float4*>(tile + pix * PSTRIDE + c4 * 4) =
             *reinterpret_cast<const float4*>(proj + ((size_t)b * HW + (size_t)gy * GW + gx) * KEY + c4 * 4);
     }
     __syncthreads();
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int lx = threadIdx.x & (TSX - 1), ly = threadIdx.x / TSX;
     const bool in_image = (ty0 + ly) < GH && (tx0 + lx) < GW;
     const int y = min(ty0 + ly, GH - 1), x = min(tx0 + lx, GW - 1);  // out-of-image lanes compute a clamped pixel
 
     float4 ctr[KEY / 4];
-    const float* cp = tile + ((ly + R) * HALO + lx + R) * PSTRIDE;
+    const float* cp = tile + ((ly + R) * HALOX + lx + R) * PSTRIDE;
 #pragma unroll
     for (int c = 0; c < KEY / 4; ++c) ctr[c] = *reinterpret_cast<const float4*>(cp + c * 4);
 
@@ -123,12 +128,12 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
         const int i = t / DIA, j = t % DIA;
-        const float* np = tile + ((ly + i) * HALO + lx + j) * PSTRIDE;
+        const float* np = tile + ((ly + i) * HALOX + lx + j) * PSTRIDE;
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < KEY / 4; ++c) {
             const float4 v = *reinterpret_cast<const float4*>(np + c * 4);
-            s += v.x * ctr[c].x + v.y * ctr[c].y + v.z * ctr[c].z + v.w * ctr[c].w;
+            s = fmaf(v.w, ctr[c].w, fmaf(v.z, ctr[c].z, fmaf(v.y, ctr[c].y, fmaf(v.x, ctr[c].x, s))));
         }
         k[t] = s * temp;
         mx = fmaxf(mx, k[t]);
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
 #pragma unroll
         for (int ry = 0; ry < 8; ++ry)
 #pragma unroll
-            for (int tx = 0; tx < DIA; ++tx) hrow[ry][tx] += by[ry] * k[ty * DIA + tx];
+            for (int tx = 0; tx < DIA; ++tx) hrow[ry][tx] = fmaf(by[ry], k[ty * DIA + tx], hrow[ry][tx]);
     }
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
 #pragma unroll
             for (int tx = 0; tx < DIA; ++tx)
 #pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8) r[s8] += hrow[ry][tx] * bx[tx][s8];
+                for (int s8 = 0; s8 < 8; ++s8) r[s8] = fmaf(hrow[ry][tx], bx[tx][s8], r[s8]);
             *reinterpret_cast<uint4*>(o + ry * 16 + half * 8) =
                 make_uint4(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]), pack2bf(r[4], r[5]), pack2bf(r[6], r[7]));
         }
@@ -412,7 +417,7 @@ extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* k
     ISP_CHECK_ARG(B > 0 && GH >= 4 && GW >= 4 && GH % 2 == 0 && GW % 2 == 0 && B <= 65535 && sigma_spatial != 0.f);
     const float temp = fminf(fmaxf(expf(range_temp), 1e-4f), 1e4f);
     const float inv2s2 = 1.0f / (2.f * sigma_spatial * sigma_spatial);
-    const int lds = HALO * HALO * PSTRIDE * 4;
+    const int lds = HALOY * HALOX * PSTRIDE * 4;  // 76.6 KB (>= the 64 KB the MLP staging reuses): 2 blocks per CU
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)jbu_kernels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
@@ -420,7 +425,7 @@ extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* k
             return ISP_ERR_LAUNCH;
         attr_done = true;
     }
-    dim3 grid((GW + TS - 1) / TS, (GH + TS - 1) / TS, B);
+    dim3 grid((GW + TSX - 1) / TSX, (GH + TSY - 1) / TSY, B);
     jbu_kernels_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
                                                                 fix0_b, (const bf16_t*)fix3_w, fix3_b, bys, bxs, temp,
                                                                 inv2s2, GH, GW);
