@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
 // stride of 36 floats (9 sixteen-byte slots: consecutive pixels of ONE row rotate through all 16 slots).  The block is
 // 32 wide so that each 16-lane group of a ds_read_b128 stays inside one tile row -- a 16x16 block mixed two rows per
 // group and 47 % of its LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr int TSX = 32, TSY = 8, HALOX = TSX + 2 * R, HALOY = TSY + 2 * R, PSTRIDE = 36;
 
 // Composite-kernel tables (host-built, depend only on the output size):
@@ -129,12 +130,14 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
     for (int t = 0; t < TAPS; ++t) {
         const int i = t / DIA, j = t % DIA;
         const float* np = tile + ((ly + i) * HALOX + lx + j) * PSTRIDE;
-        float s = 0.f;
+        f32x2 s2 = {0.f, 0.f};  // two running sums -> v_pk_fma_f32 (2 FMAs per instruction)
 #pragma unroll
         for (int c = 0; c < KEY / 4; ++c) {
             const float4 v = *reinterpret_cast<const float4*>(np + c * 4);
-            s = fmaf(v.w, ctr[c].w, fmaf(v.z, ctr[c].z, fmaf(v.y, ctr[c].y, fmaf(v.x, ctr[c].x, s))));
+            s2 = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{ctr[c].x, ctr[c].y}, s2);
+            s2 = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{ctr[c].z, ctr[c].w}, s2);
         }
+        const float s = s2.x + s2.y;
         k[t] = s * temp;
         mx = fmaxf(mx, k[t]);
     }
