@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][i] * c - m_new);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][i], c, -m_new));  // (explicit fma: -ffp-contract=off)
                 s[kb][i] = p;
                 psum += p;
             }

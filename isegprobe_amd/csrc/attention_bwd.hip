@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = sbase + r < str.L && orow[ow] < own.L;
                     const float lv = OWN_KEYS ? l4[r] : lse_o[ow], dv = OWN_KEYS ? d4[r] : delta_o[ow];
-                    const float p = ok ? __builtin_amdgcn_exp2f(x1[ow][r] * c - lv) : 0.f;
+                    const float p = ok ? __builtin_amdgcn_exp2f(fmaf(x1[ow][r], c, -lv)) : 0.f;
                     pp[ow][r] = (short)f2bf(p);
                     ds[ow][r] = (short)f2bf(ok ? p * (x2[ow][r] - dv) * scale : 0.f);
                 }
