@@ -49,10 +49,8 @@ def main():
     crop = (int(parts[0]), int(parts[1]) if len(parts) > 1 else int(parts[0]))  # inference/utils.py:307-316
     device = torch.device("cuda")
     if args.checkpoint:
-        isegprobe_amd.install_as_core()  # reference checkpoints name core.* classes
-        ckpt = torch.load(args.checkpoint, map_location="cpu", weights_only=False)
-        model = load_model(ckpt["config"])
-        print("load_state_dict:", model.load_state_dict(ckpt["state_dict"], strict=False))
+        from isegprobe_amd.core.inference.utils import load_is_model
+        model = load_is_model(args.checkpoint, device)  # reference-format {"state_dict", "config"} (inference/utils.py:37-83)
     else:
         dim = {"dinov2_vits14": 384, "dinov2_vitb14": 768, "dinov2_vitl14": 1024}[args.arch]
         up_params = {"backbone_type": "dinov2"} if args.upsampler == "jbu_featup" else None

@@ -123,3 +123,28 @@ def save_iou_analysis_data(dataset_name, logs_path, dataset_results, eval_mode="
     with path.open("wb") as f:
         pickle.dump({"dataset_name": dataset_name, "model_name": f"{model_name}_{mode}", "all_ious": all_ious}, f)
     return path
+
+
+def load_single_is_model(state_dict, device, **kwargs):
+    """core/inference/utils.py:60-83: rebuild the model from the checkpoint's config, load the saved (trainable) weights
+    over the freshly constructed ones, freeze, move, eval."""
+    from ..utils.serialization import load_model
+    model = load_model(state_dict["config"], **kwargs)
+    current = model.state_dict()
+    current.update(state_dict["state_dict"])
+    model.load_state_dict(current, strict=False)
+    for p in model.parameters():
+        p.requires_grad = False
+    return model.to(device).eval()
+
+
+def load_is_model(checkpoint, device, **kwargs):
+    """core/inference/utils.py:37-57: a checkpoint path / dict, or a list of them (per-click models)."""
+    import torch
+    from pathlib import Path
+    import isegprobe_amd
+    isegprobe_amd.install_as_core()  # checkpoints name core.* classes and pickle core.utils.model_builder.ModelBuilder
+    sd = torch.load(checkpoint, map_location="cpu", weights_only=False) if isinstance(checkpoint, (str, Path)) else checkpoint
+    if isinstance(sd, list):
+        return load_single_is_model(sd[0], device, **kwargs), [load_single_is_model(x, device, **kwargs) for x in sd]
+    return load_single_is_model(sd, device, **kwargs)

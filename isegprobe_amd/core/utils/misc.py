@@ -1,4 +1,4 @@
-"""Bounding-box helpers used by the zoom-in transform (reference core/utils/misc.py:71-119)."""
+"""Checkpoint writer and bounding-box helpers (reference core/utils/misc.py:37-119)."""
 from typing import Tuple
 
 import numpy as np
@@ -35,3 +35,25 @@ def get_segments_iou(s1: Tuple, s2: Tuple) -> float:
 
 def get_bbox_iou(b1, b2):
     return get_segments_iou(b1[:2], b2[:2]) * get_segments_iou(b1[2:4], b2[2:4])
+
+
+def save_checkpoint(net, checkpoints_path, epoch=None, prefix="", verbose=True, multi_gpu=False):
+    """core/utils/misc.py:37-68: ``{"state_dict": net.get_state_dict_to_save(), "config": net._config}`` as
+    ``[<prefix>_]last_checkpoint.pth`` (epoch None) or ``[<prefix>_]<epoch:03d>.pth``.  The file loads in the reference
+    and the reference's checkpoints load here (class path ``core.model...``, see isegprobe_amd.install_as_core)."""
+    from pathlib import Path
+    import torch
+    checkpoints_path = Path(checkpoints_path)
+    name = "last_checkpoint.pth" if epoch is None else f"{epoch:03d}.pth"
+    if prefix:
+        name = f"{prefix}_{name}"
+    checkpoints_path.mkdir(parents=True, exist_ok=True)
+    net = net.module if multi_gpu else net
+    state_dict = net.get_state_dict_to_save() if hasattr(net, "get_state_dict_to_save") else net.state_dict()
+    config = dict(net._config)
+    # reference-compatible class path (serialization.py:65): the reference resolves "core.model.iseg_probe_model..."
+    config["class"] = config["class"].replace("isegprobe_amd.core.", "core.")
+    torch.save({"state_dict": state_dict, "config": config}, str(checkpoints_path / name))
+    if verbose:
+        print(f"Save checkpoint to {checkpoints_path / name}")
+    return checkpoints_path / name

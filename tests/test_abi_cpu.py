@@ -99,3 +99,23 @@ def test_grabcut_layout_reader(tmp_path):
     assert s.image.shape == (60, 80, 3) and s.image.dtype == np.uint8
     m = s.gt_mask(0)  # objects_ids are positions, as in the reference's DSample (data_sample.py:161-167)
     assert set(np.unique(m)) == {-1, 0, 1} and s.objects_ids == [0]
+
+
+def test_save_checkpoint_and_load_is_model(tmp_path):
+    """misc.save_checkpoint writes the reference's format (class path core.model..., trainable weights only under the
+    model scripts' save_cfg); inference.utils.load_is_model rebuilds, loads, freezes it."""
+    from helpers import build_model, seeded_
+    from isegprobe_amd.core.inference.utils import load_is_model
+    from isegprobe_amd.core.utils.misc import save_checkpoint
+    m = seeded_(build_model("bilinear"), 4)
+    m.save_cfg = {"embed_coords": True, "backbone": False, "upsampler": False, "head": True}
+    path = save_checkpoint(m, tmp_path / "ckpts", verbose=False)
+    assert path.name == "last_checkpoint.pth"
+    assert save_checkpoint(m, tmp_path / "ckpts", epoch=7, prefix="run", verbose=False).name == "run_007.pth"
+    ckpt = torch.load(str(path), map_location="cpu", weights_only=False)
+    assert ckpt["config"]["class"] == "core.model.iseg_probe_model.iSegProbeModel"
+    assert ckpt["state_dict"] and all(k.startswith(("head.", "embed_coords.")) for k in ckpt["state_dict"])
+    m2 = load_is_model(str(path), torch.device("cpu"))
+    assert torch.equal(m2.head.classifier.weight, m.head.classifier.weight)
+    assert torch.equal(m2.embed_coords.proj.bias, m.embed_coords.proj.bias)
+    assert not any(p.requires_grad for p in m2.parameters()) and not m2.training

@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--upsampler", default=None, help="override the script's upsampler")
     ap.add_argument("--injection", default=None, help="override feats_injection_mode (before_backbone | after_backbone)")
     ap.add_argument("--lr", type=float, default=5e-5)
+    ap.add_argument("--save", default=None, help="directory for a reference-format last_checkpoint.pth (rank 0)")
     args = ap.parse_args()
 
     from isegprobe_amd.core.model import iSegProbeModel
@@ -111,6 +112,10 @@ def main():
         if D.get_rank() == 0:
             print(f"step {step:3d}  loss {float(red['loss']):.4f}  {dt * 1e3:7.1f} ms  "
                   f"{D.get_world_size() * args.batch / dt:7.1f} img/s")
+    if args.save and D.get_rank() == 0:
+        from isegprobe_amd.core.utils.misc import save_checkpoint
+        model.save_cfg = {"embed_coords": True, "backbone": False, "upsampler": False, "head": True}  # as the model scripts do
+        save_checkpoint(model, args.save)
     D.synchronize()
 
 
