@@ -850,6 +850,7 @@ static bool ep_forces_tile_engine() {
 // number of partial-sum slots isp_conv3x3_nhwc_bf16 writes with ISP_EP_RELU_DOT_PARTIAL_F32
 extern "C" int isp_conv3x3_partial_slots(int N) {
     if (N % 192 == 0) return ((N + CfgConv192::BN - 1) / CfgConv192::BN) * CfgConv192::WN;
+    if (N % 128 == 0 && !ep_forces_tile_engine()) return N / 128 * 2;  // patch kernel, 128-channel blocks
     if (N > 64) return ((N + CfgConv128::BN - 1) / CfgConv128::BN) * CfgConv128::WN;
     return ((N + Cfg128::BN - 1) / Cfg128::BN) * Cfg128::WN;
 }
@@ -874,11 +875,12 @@ extern "C" int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int 
         al.tiles_y = (H + CFG::BM / 16 - 1) / (CFG::BM / 16);
         return dispatch_epilogue<CFG, Conv3x3A<CFG::PA>, CONV_KINDS>(al, Wt, M, N, 9 * C, ep, (hipStream_t)stream);
     };
-    // LDS-resident-patch kernel when 192-channel blocks tile N exactly.  (A 256-channel variant, TN = 8, for
-    // N = 1024 needs ~280 VGPRs and spills; those shapes stay on the tile engine.)
-    if (!ep_forces_tile_engine() && N % 192 == 0) {
+    // LDS-resident-patch kernel when 192- or 128-channel blocks tile N exactly (C = N = 384 / 768 heads: 192;
+    // N = 1024, ViT-L heads: 128.  A 256-channel variant, TN = 8, needs ~280 VGPRs and spills.)
+    if (!ep_forces_tile_engine() && (N % 192 == 0 || N % 128 == 0)) {
         if (!ep) return ISP_ERR_INVALID;
-        const int rc = dispatch_conv_patch<6>(in, Wt, B, H, W, C, N, ep, (hipStream_t)stream);
+        const int rc = N % 192 == 0 ? dispatch_conv_patch<6>(in, Wt, B, H, W, C, N, ep, (hipStream_t)stream)
+                                    : dispatch_conv_patch<4>(in, Wt, B, H, W, C, N, ep, (hipStream_t)stream);
         if (rc != ISP_ERR_UNSUPPORTED) return rc;
     }
     if (N % 192 == 0) return run(CfgConv192{});
