@@ -847,10 +847,13 @@ static bool ep_forces_tile_engine() {
     return v == 1;
 }
 
+// 128-channel blocks of the patch kernel: exact tilings, or a ragged last block that wastes <= 15 % (LoftUp's 448)
+static bool patch128_ok(int N) { return N >= 128 && ((N + 127) / 128 * 128 - N) * 100 <= 15 * N; }
+
 // number of partial-sum slots isp_conv3x3_nhwc_bf16 writes with ISP_EP_RELU_DOT_PARTIAL_F32
 extern "C" int isp_conv3x3_partial_slots(int N) {
     if (N % 192 == 0) return ((N + CfgConv192::BN - 1) / CfgConv192::BN) * CfgConv192::WN;
-    if (N % 128 == 0 && !ep_forces_tile_engine()) return N / 128 * 2;  // patch kernel, 128-channel blocks
+    if (patch128_ok(N) && !ep_forces_tile_engine()) return (N + 127) / 128 * 2;  // patch kernel, 128-channel blocks
     if (N > 64) return ((N + CfgConv128::BN - 1) / CfgConv128::BN) * CfgConv128::WN;
     return ((N + Cfg128::BN - 1) / Cfg128::BN) * Cfg128::WN;
 }
@@ -877,7 +880,7 @@ extern "C" int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int 
     };
     // LDS-resident-patch kernel when 192- or 128-channel blocks tile N exactly (C = N = 384 / 768 heads: 192;
     // N = 1024, ViT-L heads: 128.  A 256-channel variant, TN = 8, needs ~280 VGPRs and spills.)
-    if (!ep_forces_tile_engine() && (N % 192 == 0 || N % 128 == 0)) {
+    if (!ep_forces_tile_engine() && (N % 192 == 0 || patch128_ok(N))) {
         if (!ep) return ISP_ERR_INVALID;
         const int rc = N % 192 == 0 ? dispatch_conv_patch<6>(in, Wt, B, H, W, C, N, ep, (hipStream_t)stream)
                                     : dispatch_conv_patch<4>(in, Wt, B, H, W, C, N, ep, (hipStream_t)stream);
