@@ -282,14 +282,16 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
 // read from the [pixel][channel] LDS tile with ds_read_b64_tr_b16.  D[ch][px] lands with 4
 // consecutive channels per lane (8-byte stores).
 //   LDS: source tile 11 rows x 24 cols x 64 ch bf16 (33 KiB, 16-B chunks XOR-swizzled so the
-//        transposed reads are conflict-free) + kernel tile [8 strips][8 ry][16 px][16 slots]
-//        bf16 (32 KiB)  -> 2 blocks per CU.
-//   The band fragments (8 per strip) live in registers across the channel loop.
+//        transposed reads are conflict-free); the kernel tile [8 strips][8 ry][16 px][16 slots]
+//        bf16 (32 KiB) is staged through the SAME bytes first: the band fragments (8 per strip)
+//        live in registers across the channel loop.  3 blocks per CU (measured 3.86 vs 4.09 ms at
+//        2; 4 blocks would need <= 128 VGPRs and spills).  A wave's two strips (rows 2k, 2k+1)
+//        share base_y, so one transposed source fragment feeds both.
 constexpr int ATH = 8, ATW = 16, ACC = 64;
 constexpr int SROWS = 11, SCOLS = 24, SPIX = SROWS * SCOLS;                   // 264 source pixels
 constexpr int SRC_TILE_BYTES = ((SPIX + 7) / 8) * 8 * ACC * 2;                // padded to whole 1 KiB pieces
 constexpr int KC_TILE_BYTES = ATH * 8 * ATW * 32;
-constexpr int APPLY_LDS = SRC_TILE_BYTES + KC_TILE_BYTES;
+constexpr int APPLY_LDS = SRC_TILE_BYTES > KC_TILE_BYTES ? SRC_TILE_BYTES : KC_TILE_BYTES;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -297,12 +299,12 @@ __device__ __forceinline__ int src_swz(int pix, int chunk) {  // 16-B chunk swiz
     return chunk ^ ((((pix >> 1) & 1) << 2) | (((pix >> 3) & 1) << 1));
 }
 
-__global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ kc,
+__global__ __launch_bounds__(256, 3) void jbu_apply_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ kc,
                                                            bf16_t* __restrict__ out, int h, int w, int C, int tiles_x,
                                                            int tiles_y, int nwg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_src = smem;
-    char* s_kc = smem + SRC_TILE_BYTES;
+    char* s_kc = smem;  // same bytes: the kernel tile is dead once the band fragments are in registers
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int GH = 2 * h, GW = 2 * w;
@@ -357,36 +359,39 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restr
             glds16(src + src_img + ((size_t)sy * w + sx) * C + c0 + chunk * 8, s_src + piece * 1024);
         }
         __syncthreads();  // (emits vmcnt(0): the DMA has landed)
+        // the wave's two strips (output rows 2k, 2k+1) share base_y, hence the transposed source fragments
+        const int r0 = (((min(y0 + wid * 2, GH - 1) - 4) >> 1) - 1) - tile_y0;  // first window row inside the tile
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int si = 0; si < 2; ++si)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[si][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ry = 0; ry < 8; ++ry) {
+            const int rowpix = (r0 + ry) * SCOLS + gk;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int pa = rowpix + gq, pb = rowpix + 4 + gq;
+                const int ch = cb * 2 + (gp >> 1);
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (ISP_LDS s16x4_t*)(s_src + pa * 128 + src_swz(pa, ch) * 16 + (gp & 1) * 8));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (ISP_LDS s16x4_t*)(s_src + pb * 128 + src_swz(pb, ch) * 16 + (gp & 1) * 8));
+                const bf16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, band[0][ry], acc[0][cb], 0, 0, 0);
+                acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, band[1][ry], acc[1][cb], 0, 0, 0);
+            }
+        }
+        // D[ch = 4*(lane>>4)+j][px = lane&15]
 #pragma unroll
         for (int si = 0; si < 2; ++si) {
             const int strip = wid * 2 + si;
-            const int gy = min(y0 + strip, GH - 1);
-            const int r0 = (((gy - 4) >> 1) - 1) - tile_y0;  // first window row inside the tile
-            f32x4 acc[4];
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ry = 0; ry < 8; ++ry) {
-                const int rowpix = (r0 + ry) * SCOLS + gk;
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    const int pa = rowpix + gq, pb = rowpix + 4 + gq;
-                    const int ch = cb * 2 + (gp >> 1);
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (ISP_LDS s16x4_t*)(s_src + pa * 128 + src_swz(pa, ch) * 16 + (gp & 1) * 8));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (ISP_LDS s16x4_t*)(s_src + pb * 128 + src_swz(pb, ch) * 16 + (gp & 1) * 8));
-                    const bf16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, band[si][ry], acc[cb], 0, 0, 0);
-                }
-            }
-            // D[ch = 4*(lane>>4)+j][px = lane&15]
             if (y0 + strip < GH && x0 + px < GW) {
                 bf16_t* op = out + (((size_t)b * GH + y0 + strip) * GW + x0 + px) * C + c0 + 4 * g;
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
                     *reinterpret_cast<uint2*>(op + cb * 16) =
-                        make_uint2(pack2bf(acc[cb][0], acc[cb][1]), pack2bf(acc[cb][2], acc[cb][3]));
+                        make_uint2(pack2bf(acc[si][cb][0], acc[si][cb][1]), pack2bf(acc[si][cb][2], acc[si][cb][3]));
             }
         }
     }
