@@ -66,6 +66,8 @@ struct DenseA {
         return m < M ? m : -1;
     }
     template <int BM>
+    __device__ __forceinline__ bool tile_full(long tm) const { return (tm + 1) * BM <= M; }
+    template <int BM>
     long num_tiles() const { return (M + BM - 1) / BM; }
     __device__ __forceinline__ const void* ptr(int i) const { return cur[i]; }
     __device__ __forceinline__ long advance() {  // returns the step of the weight-column cursor (elements)
@@ -128,6 +130,12 @@ struct Conv3x3A {
         return (y < H && x < W) ? ((long)b * H + y) * W + x : -1;
     }
     template <int BM>
+    __device__ __forceinline__ bool tile_full(long tm) const {  // last row of the tile inside the image <=> all rows
+        int b, y, x;
+        locate<BM>(tm, BM - 1, b, y, x);
+        return y < H && x < W;
+    }
+    template <int BM>
     long num_tiles() const { return (long)(M / ((long)H * W)) * tiles_x * tiles_y; }
     __device__ __forceinline__ const void* ptr(int i) const { return cur[i]; }
     __device__ __forceinline__ long advance() {
@@ -144,25 +152,44 @@ struct Conv3x3A {
 };
 
 // ------------------------------------------------------------------------------ epilogues
-// Epilogue contract: operator()(m, n, v[4]) for output row m < M, columns n..n+3 < N.
+// Epilogue contract (driven by run_epilogue below), for output row m < M and columns n..n+3 < N:
+//   Cols cols(n)            per-column constants (bias, LayerScale, classifier weights), loaded ONCE per wave column
+//                           group before the row loop -- not once per 4x4 accumulator fragment, where every store
+//                           would sit behind its own L2 round trip;
+//   Pre  pre(m, n)          optional per-element operand (residual stream, saved pre-activation), loaded for a whole
+//                           fragment row before any of that row's stores (a store to the same array would otherwise
+//                           serialise the following load behind it);
+//   unsigned row_begin(m)   optional per-row context;
+//   operator()(m, n, v[4], cols [, pre] [, ctx])   /   float term(n, v[4], cols) for row-reducing epilogues.
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_QGELU = 3 };  // QGELU: x*sigmoid(1.702x), CLIP's QuickGELU
+
+struct ColsBias {
+    float4 b;
+};
+__device__ __forceinline__ ColsBias load_bias(const float* bias, int n) {  // bias may be null
+    return ColsBias{bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0)};
+}
 
 template <int ACT>
 struct EpBiasActBf16 {  // out[m][n] = bf16(act(v + bias[n]))
     bf16_t* out;
     const float* bias;  // may be null
     long ldo;
-    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
-        float r[4];
-        float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
-        r[0] = v[0] + b.x, r[1] = v[1] + b.y, r[2] = v[2] + b.z, r[3] = v[3] + b.w;
+    using Cols = ColsBias;
+    __device__ __forceinline__ Cols cols(int n) const { return load_bias(bias, n); }
+    // the four bf16 outputs of columns n..n+3 (kernels that stage their output tile through LDS store them themselves)
+    __device__ __forceinline__ uint2 pack(long, int, const float* v, const Cols& c) const {
+        float r[4] = {v[0] + c.b.x, v[1] + c.b.y, v[2] + c.b.z, v[3] + c.b.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (ACT == ACT_RELU) r[j] = fmaxf(r[j], 0.f);
             if (ACT == ACT_GELU) r[j] = gelu_erf(r[j]);
             if (ACT == ACT_QGELU) r[j] = r[j] / (1.0f + __expf(-1.702f * r[j]));
         }
-        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = make_uint2(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]));
+        return make_uint2(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]));
+    }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c) const {
+        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = pack(m, n, v, c);
     }
 };
 
@@ -181,25 +208,33 @@ __device__ __forceinline__ float act_grad(int act, float x) {
 template <int ACT>
 struct EpBiasGeluSaveBf16 {  // out = act(v + bias), pre = v + bias (kept for the backward); act = GELU or QuickGELU
     bf16_t* out;
-    bf16_t* pre;
+    bf16_t* pre_out;
     const float* bias;
     long ldo;
-    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
-        float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
-        const float r[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
-        *reinterpret_cast<uint2*>(pre + (size_t)m * ldo + n) = make_uint2(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]));
+    using Cols = ColsBias;
+    __device__ __forceinline__ Cols cols(int n) const { return load_bias(bias, n); }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c) const {
+        const float r[4] = {v[0] + c.b.x, v[1] + c.b.y, v[2] + c.b.z, v[3] + c.b.w};
+        *reinterpret_cast<uint2*>(pre_out + (size_t)m * ldo + n) = make_uint2(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]));
         *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) =
             make_uint2(pack2bf(act_fwd(ACT, r[0]), act_fwd(ACT, r[1])), pack2bf(act_fwd(ACT, r[2]), act_fwd(ACT, r[3])));
     }
 };
 
+struct ColsNone {};
+
 template <int ACT>
 struct EpMulDGeluBf16 {  // out = v * act'(pre)
     bf16_t* out;
-    const bf16_t* pre;
+    const bf16_t* pre_in;
     long ldo;
-    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
-        const uint2 raw = *reinterpret_cast<const uint2*>(pre + (size_t)m * ldo + n);
+    using Cols = ColsNone;
+    using Pre = uint2;
+    __device__ __forceinline__ Cols cols(int) const { return {}; }
+    __device__ __forceinline__ Pre pre(long m, int n) const {
+        return *reinterpret_cast<const uint2*>(pre_in + (size_t)m * ldo + n);
+    }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols&, const Pre& raw) const {
         const float x[4] = {bf2f((bf16_t)(raw.x & 0xffff)), bf2f((bf16_t)(raw.x >> 16)), bf2f((bf16_t)(raw.y & 0xffff)),
                             bf2f((bf16_t)(raw.y >> 16))};
         float r[4];
@@ -214,9 +249,10 @@ struct EpBiasActF32 {  // out[m][n] = act(v + bias[n]) in fp32
     float* out;
     const float* bias;
     long ldo;
-    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
-        float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
-        float r[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w};
+    using Cols = ColsBias;
+    __device__ __forceinline__ Cols cols(int n) const { return load_bias(bias, n); }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c) const {
+        float r[4] = {v[0] + c.b.x, v[1] + c.b.y, v[2] + c.b.z, v[3] + c.b.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (ACT == ACT_RELU) r[j] = fmaxf(r[j], 0.f);
@@ -231,16 +267,22 @@ struct EpResidual {  // x[m][n] += gamma[n] * (v + bias[n])   (LayerScale + resi
     const float* bias;
     const float* gamma;  // may be null (no LayerScale)
     long ldx;
-    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
-        float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
-        float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + n) : make_float4(1, 1, 1, 1);
-        float4* px = reinterpret_cast<float4*>(x + (size_t)m * ldx + n);
-        float4 o = *px;
-        o.x += g.x * (v[0] + b.x);
-        o.y += g.y * (v[1] + b.y);
-        o.z += g.z * (v[2] + b.z);
-        o.w += g.w * (v[3] + b.w);
-        *px = o;
+    struct Cols {
+        float4 b, g;
+    };
+    using Pre = float4;
+    __device__ __forceinline__ Cols cols(int n) const {
+        return Cols{bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0),
+                    gamma ? *reinterpret_cast<const float4*>(gamma + n) : make_float4(1, 1, 1, 1)};
+    }
+    __device__ __forceinline__ Pre pre(long m, int n) const { return *reinterpret_cast<const float4*>(x + (size_t)m * ldx + n); }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c, const Pre& old) const {
+        float4 o = old;
+        o.x += c.g.x * (v[0] + c.b.x);
+        o.y += c.g.y * (v[1] + c.b.y);
+        o.z += c.g.z * (v[2] + c.b.z);
+        o.w += c.g.w * (v[3] + c.b.w);
+        *reinterpret_cast<float4*>(x + (size_t)m * ldx + n) = o;
     }
 };
 
@@ -250,13 +292,15 @@ struct EpAxpyResBf16 {  // out = res + alpha * (v + bias), bf16 in/out (FeatUp J
     const float* bias;
     float alpha;
     long ldo;
-    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
-        float4 b = bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0);
-        const uint2 u = *reinterpret_cast<const uint2*>(res + (size_t)m * ldo + n);
-        const float r0 = __uint_as_float(u.x << 16) + alpha * (v[0] + b.x);
-        const float r1 = __uint_as_float(u.x & 0xffff0000u) + alpha * (v[1] + b.y);
-        const float r2 = __uint_as_float(u.y << 16) + alpha * (v[2] + b.z);
-        const float r3 = __uint_as_float(u.y & 0xffff0000u) + alpha * (v[3] + b.w);
+    using Cols = ColsBias;
+    using Pre = uint2;
+    __device__ __forceinline__ Cols cols(int n) const { return load_bias(bias, n); }
+    __device__ __forceinline__ Pre pre(long m, int n) const { return *reinterpret_cast<const uint2*>(res + (size_t)m * ldo + n); }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c, const Pre& u) const {
+        const float r0 = __uint_as_float(u.x << 16) + alpha * (v[0] + c.b.x);
+        const float r1 = __uint_as_float(u.x & 0xffff0000u) + alpha * (v[1] + c.b.y);
+        const float r2 = __uint_as_float(u.y << 16) + alpha * (v[2] + c.b.z);
+        const float r3 = __uint_as_float(u.y & 0xffff0000u) + alpha * (v[3] + c.b.w);
         *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = make_uint2(pack2bf(r0, r1), pack2bf(r2, r3));
     }
 };
@@ -271,6 +315,8 @@ struct EpBiasTapsReluBf16 {
     const float* taps;  // [9][ldo]
     int H, W;
     long ldo;
+    using Cols = ColsBias;
+    __device__ __forceinline__ Cols cols(int n) const { return load_bias(bias, n); }
     // row context: 9-bit mask of the taps that fall outside the image for output pixel m
     __device__ __forceinline__ unsigned row_begin(long m) const {
         const unsigned rem = (unsigned)m % ((unsigned)H * (unsigned)W);
@@ -282,22 +328,22 @@ struct EpBiasTapsReluBf16 {
         if (x == W - 1) mask |= 0x124u;
         return mask;
     }
-    __device__ __forceinline__ void operator()(long m, int n, const float* v, unsigned outside) const {
-        float4 b = *reinterpret_cast<const float4*>(bias + n);
+    __device__ __forceinline__ uint2 pack(long, int n, const float* v, const Cols& c, unsigned outside) const {
+        float4 b = c.b;
         if (outside) {
 #pragma unroll 1
             for (int t = 0; t < 9; ++t) {
                 if ((outside >> t) & 1u) {
-                {
                     const float4 tv = *reinterpret_cast<const float4*>(taps + (size_t)t * ldo + n);
                     b.x -= tv.x, b.y -= tv.y, b.z -= tv.z, b.w -= tv.w;
                 }
-                }
             }
         }
-        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) =
-            make_uint2(pack2bf(fmaxf(v[0] + b.x, 0.f), fmaxf(v[1] + b.y, 0.f)),
-                       pack2bf(fmaxf(v[2] + b.z, 0.f), fmaxf(v[3] + b.w, 0.f)));
+        return make_uint2(pack2bf(fmaxf(v[0] + b.x, 0.f), fmaxf(v[1] + b.y, 0.f)),
+                          pack2bf(fmaxf(v[2] + b.z, 0.f), fmaxf(v[3] + b.w, 0.f)));
+    }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c, unsigned outside) const {
+        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = pack(m, n, v, c, outside);
     }
 };
 
@@ -310,11 +356,15 @@ struct EpReluDotPartial {
     const float* bias;   // [N]
     const float* wcls;   // [N]
     long M;
-    __device__ __forceinline__ float term(int n, const float* v) const {
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        const float4 w = *reinterpret_cast<const float4*>(wcls + n);
-        return fmaxf(v[0] + b.x, 0.f) * w.x + fmaxf(v[1] + b.y, 0.f) * w.y + fmaxf(v[2] + b.z, 0.f) * w.z +
-               fmaxf(v[3] + b.w, 0.f) * w.w;
+    struct Cols {
+        float4 b, w;
+    };
+    __device__ __forceinline__ Cols cols(int n) const {
+        return Cols{*reinterpret_cast<const float4*>(bias + n), *reinterpret_cast<const float4*>(wcls + n)};
+    }
+    __device__ __forceinline__ float term(int, const float* v, const Cols& c) const {
+        return fmaxf(v[0] + c.b.x, 0.f) * c.w.x + fmaxf(v[1] + c.b.y, 0.f) * c.w.y + fmaxf(v[2] + c.b.z, 0.f) * c.w.z +
+               fmaxf(v[3] + c.b.w, 0.f) * c.w.w;
     }
 };
 
@@ -324,13 +374,18 @@ struct EpTokens {  // patch-embed: token row b*(T+1)+1+t gets v + bias[n] + pos[
     const float* pos;   // [T+1][N] interpolated pos-embed (row 0 = cls), may be null
     int T;
     long ldx;
-    __device__ __forceinline__ void operator()(long m, int n, const float* v) const {
+    using Cols = ColsBias;
+    using Pre = float4;
+    __device__ __forceinline__ Cols cols(int n) const { return load_bias(bias, n); }
+    __device__ __forceinline__ Pre pre(long m, int n) const {
+        const int t = (int)(m % T);
+        return pos ? *reinterpret_cast<const float4*>(pos + (size_t)(1 + t) * ldx + n) : make_float4(0, 0, 0, 0);
+    }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c, const Pre& pp) const {
         const long b = m / T;
         const int t = (int)(m - b * T);
-        float4 bb = *reinterpret_cast<const float4*>(bias + n);
-        float4 pp = pos ? *reinterpret_cast<const float4*>(pos + (size_t)(1 + t) * ldx + n) : make_float4(0, 0, 0, 0);
         *reinterpret_cast<float4*>(x + (size_t)(b * (T + 1) + 1 + t) * ldx + n) =
-            make_float4(v[0] + bb.x + pp.x, v[1] + bb.y + pp.y, v[2] + bb.z + pp.z, v[3] + bb.w + pp.w);
+            make_float4(v[0] + c.b.x + pp.x, v[1] + c.b.y + pp.y, v[2] + c.b.z + pp.z, v[3] + c.b.w + pp.w);
     }
 };
 
@@ -341,9 +396,20 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // fr) and the 4 consecutive columns n_base + 16*ni + 4*fq + j.  `row_of(local_row)` maps a tile row
 // to the global output row (or -1).  EP::kRowReduce epilogues reduce over the wave's columns instead
 // of storing them (conv + classifier fusion): slot = which (n-tile, n-wave) partial this wave owns.
-template <int TM, int TN, class EP, class RowFn>
+// FULL = the wave-uniform fast path for tiles that lie entirely inside the matrix: no per-lane row / column
+// checks, hence no divergent branches -- behind those the compiler has to place s_waitcnt vmcnt(0) at every join,
+// which makes each store wait for the previous store's acknowledgement (measured: 11 us of a 66 us conv tile).
+template <int TM, int TN, bool FULL = false, class EP, class RowFn>
 __device__ __forceinline__ void run_epilogue(const EP& ep, f32x4 (&acc)[TM][TN], RowFn row_of, int row_base, int fr,
                                              int fq, int n_base, int N, int slot) {
+    // per-column constants of the wave's TN column groups (columns past N read the last valid group: never used)
+    typename EP::Cols cc[TN];
+    int ncol[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        ncol[ni] = n_base + ni * 16 + fq * 4;
+        cc[ni] = ep.cols(FULL || ncol[ni] < N ? ncol[ni] : N - 4);
+    }
     if constexpr (requires { EP::kRowReduce; }) {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
@@ -351,28 +417,41 @@ __device__ __forceinline__ void run_epilogue(const EP& ep, f32x4 (&acc)[TM][TN],
             float sum = 0.f;
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
-                const int n = n_base + ni * 16 + fq * 4;
                 const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-                if (n < N) sum += ep.term(n, v);
+                if (FULL || ncol[ni] < N) sum += ep.term(ncol[ni], v, cc[ni]);
             }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
-            if (fq == 0 && m >= 0) ep.partial[(size_t)slot * ep.M + m] = sum;
+            if (fq == 0 && (FULL || m >= 0)) ep.partial[(size_t)slot * ep.M + m] = sum;
         }
     } else {
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
             const long m = row_of(row_base + mi * 16 + fr);
-            if (m < 0) continue;
-            [[maybe_unused]] unsigned ctx = 0;
-            if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
+            if constexpr (requires { ep.pre(m, 0); }) {
+                // all of the row's operand loads first (rows / columns outside the matrix read element (0, N-4))
+                typename EP::Pre pp[TN];
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int n = n_base + ni * 16 + fq * 4;
-                if (n >= N) continue;
-                const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-                if constexpr (requires { ep.row_begin(m); }) ep(m, n, v, ctx);
-                else ep(m, n, v);
+                for (int ni = 0; ni < TN; ++ni)
+                    pp[ni] = ep.pre(FULL || m >= 0 ? m : 0, FULL || ncol[ni] < N ? ncol[ni] : N - 4);
+                if (!FULL && m < 0) continue;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    if (!FULL && ncol[ni] >= N) continue;
+                    const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                    ep(m, ncol[ni], v, cc[ni], pp[ni]);
+                }
+            } else {
+                if (!FULL && m < 0) continue;
+                [[maybe_unused]] unsigned ctx = 0;
+                if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    if (!FULL && ncol[ni] >= N) continue;
+                    const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                    if constexpr (requires { ep.row_begin(m); }) ep(m, ncol[ni], v, cc[ni], ctx);
+                    else ep(m, ncol[ni], v, cc[ni]);
+                }
             }
         }
     }
@@ -499,8 +578,12 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
         if (t + 1 < nk) step(t + 1, smem + CFG::STAGE, smem);
     }
 
-    run_epilogue<TM, TN>(ep, acc, [&](int r) { return al.template out_row<BM>(tm, r); }, wm * (TM * 16), fr, fq,
-                         n0 + wn * (TN * 16), N, tn * CFG::WN + wn);
+    auto row_of = [&](int r) { return al.template out_row<BM>(tm, r); };
+    // interior tile (wave-uniform): every row of the tile maps to an output row and every column is < N
+    if (n0 + BN <= N && al.template tile_full<BM>(tm))
+        run_epilogue<TM, TN, true>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * CFG::WN + wn);
+    else
+        run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * CFG::WN + wn);
 }
 
 template <class CFG, class AL, class EP>
@@ -692,7 +775,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const bf16_t* __r
 #ifdef ISP_ABLATE_NO_EPILOGUE
     if (acc[0][0][0] == 12345.678f)
 #endif
-    run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
+    {
+        if (y0 + PT <= H && x0 + PT <= W && n0 + PBN <= N) {  // interior tile: no per-lane checks
+            run_epilogue<TM, TN, true>(
+                ep, acc, [&](int r) -> long { return ((long)b * H + y0 + (r >> 4)) * W + x0 + (r & 15); }, wm * (TM * 16),
+                fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
+        } else {
+            run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
+        }
+    }
 }
 
 template <int TN, class EP>
@@ -713,12 +804,302 @@ int launch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int C
     return isp_launch_status();
 }
 
+// One-wave-per-SIMD variant of the patch conv for 192-channel blocks: 4 waves, each 128 pixels x 96 channels
+// (TM = 8, TN = 6: 14 fragment reads feed 48 MFMAs instead of 10 feeding 24, so the LDS port is ~60 % busy instead
+// of ~100 %), up to 512 registers per wave: both K-halves' fragments are double-buffered and the loop is
+// software-pipelined across the barrier -- the barrier of step s+1 sits inside the MFMA stream of step s (after the
+// first 12 of its last 48 MFMAs), the fragments of step s+1 are read behind the remaining 36.  Weight ring of 3
+// stages fetched two steps ahead (the DMA a barrier waits for was issued 1.5 steps earlier), counted vmcnt waits.
+// Staging by buffer_load ... lds: 32-bit per-lane offsets against SGPR resources, out-of-image lanes use an
+// out-of-range offset (the load returns zeros), so no 64-bit pointers or selects live in VGPRs.  The patch's 16-byte
+// chunks are XOR-swizzled by the pixel's COLUMN in the patch ((px >> 1) & 7): a fragment read's address is then
+// lane constant(dx, k-half) + immediate((t + dy + 1) * row pitch) -- no per-read address arithmetic.
+//   LDS = 2 x 42 KiB patch + 3 x 24 KiB weights = 156 KiB.
+template <class EP>
+__global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel(const bf16_t* __restrict__ in,
+                                                                const bf16_t* __restrict__ Wt, int H, int W, int C,
+                                                                int N, int tiles_x, int tiles_y, int tiles_n, int nwg,
+                                                                EP ep) {
+    constexpr int TM = 8, TN = 6, NWV = 4, PPW = (P_PIECES + NWV - 1) / NWV;  // 11 patch pieces per wave
+    constexpr int PBN = 2 * TN * 16, PWB = PBN * BK * 2, WPW = PBN / 8 / NWV;  // 6 weight pieces per wave
+    constexpr int PPS = 2;                                                     // patch pieces per wave per K-step
+    constexpr int ROWB = PW_ * 128;                                            // bytes per patch row
+#ifndef ISP_C4_PRE
+#define ISP_C4_PRE 2
+#endif
+#ifndef ISP_C4_SP
+#define ISP_C4_SP 1
+#endif
+    constexpr int C4_PRE = ISP_C4_PRE, C4_SP = ISP_C4_SP;  // second-half MFMA rows before the barrier; MFMAs per fragment read
+    static_assert(PPS * 6 >= PPW, "next patch must be complete before tap 6");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int tn = wg % tiles_n;
+    const int tmi = wg / tiles_n;
+    const int per_img = tiles_x * tiles_y;
+    const int b = tmi / per_img, tt = tmi - b * per_img;
+    const int y0 = (tt / tiles_x) * PT, x0 = (tt % tiles_x) * PT, n0 = tn * PBN;
+    const long K = 9L * C;
+    const int cblocks = C / BK;
+
+    // --- DMA slots.  Wave w owns patch pieces w, w+4, ... (a wave whose last slot falls off the patch re-issues
+    // its previous piece, so that every wave issues the same number of DMA instructions per step: the vmcnt
+    // waits below count instructions); lane -> (pixel = 8*piece + lane/8, physical chunk lane%8).
+    const __amdgpu_buffer_rsrc_t r_img =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(in + (size_t)b * H * W * C), 0, H * W * C * 2, 0x00020000);
+    const int wrows = N - n0 < PBN ? N - n0 : PBN;
+    const __amdgpu_buffer_rsrc_t r_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(Wt + (size_t)n0 * K), 0, (int)(wrows * K * 2), 0x00020000);
+    unsigned poff[PPW];
+    int ppiece[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wid + NWV * i < P_PIECES ? wid + NWV * i : wid + NWV * (i - 1);
+        const int pix = piece * 8 + (lane >> 3);
+        const int py = pix / PW_, px = pix - py * PW_;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = pix < PPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        poff[i] = ok ? (unsigned)((iy * W + ix) * C + swz(px, lane & 7) * 8) * 2u : 0x80000000u;
+        ppiece[i] = piece;
+    }
+    auto issue_patch = [&](int i, int cb, char* buf) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_img, (ISP_LDS void*)(buf + ppiece[i] * 1024), 16, poff[i],
+                                                 cb * (BK * 2), 0, 0);
+    };
+    unsigned woff[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int row = (wid + NWV * i) * 8 + (lane >> 3);
+        woff[i] = (unsigned)((row < wrows ? row : wrows - 1) * K + swz(row, lane & 7) * 8) * 2u;
+    }
+    auto issue_w = [&](int col, char* buf) {
+#pragma unroll
+        for (int i = 0; i < WPW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (ISP_LDS void*)(buf + (wid + NWV * i) * 1024), 16, woff[i],
+                                                     col * 2, 0, 0);
+    };
+
+    // --- fragment geometry
+    const int wm = wid >> 1, wn = wid & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    int aoff[3][2];  // [dx + 1][k-half]: byte offset of patch pixel (row 8*wm, col fr + 1 + dx), swizzled chunk
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) aoff[d][ks] = (8 * wm * PW_ + fr + d) * 128 + swz(fr + d, ks * 4 + fq) * 16;
+    const int w_off0 = (wn * (TN * 16) + fr) * 128 + swz(fr, fq) * 16;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    char* const s_w = smem + 2 * P_BYTES;
+    auto read_a = [&](bf16x8 (&fa)[TM], const char* patch, int tap, int ks) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const char* base = patch + aoff[dx + 1][ks];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const bf16x8*>(base + (t + dy + 1) * ROWB);
+    };
+    auto read_w = [&](bf16x8 (&fw)[TN], const char* wb, int ks) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) fw[t] = *reinterpret_cast<const bf16x8*>(wb + ((w_off0 ^ (ks * 64)) + t * 2048));
+    };
+    auto mma = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fw)[TN], int m_lo, int m_hi) {
+#pragma unroll
+        for (int mi = m_lo; mi < m_hi; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+    };
+
+    // --- prologue: patch of channel block 0, weight tiles of steps 0 and 1
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_patch(i, 0, smem);
+    issue_w(0, s_w);
+    issue_w(C, s_w + PWB);  // step 1 = (cb 0, tap 1)
+    bf16x8 fa0[TM], fa1[TM], fw0[TN], fw1[TN];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_w(fw0, s_w, 0);
+    read_a(fa0, smem, 0, 0);
+
+    // One K-step (tap TAP of channel block cb); ring slot of the step = TAP % 3 (9 % 3 == 0).
+    auto step = [&]<int TAP, bool MORE, bool HASW>(int cb, const char* patch, char* patch_next) {
+        constexpr int NP = !MORE ? 0 : (PPS * TAP + PPS <= PPW ? PPS : (PPS * TAP < PPW ? PPW - PPS * TAP : 0));
+        // The instruction order is pinned (sched_barrier / sched_group_barrier): with one wave per SIMD nothing
+        // else covers a fragment read that is issued right before its first use.
+        // region 1: DMA for two steps ahead + second-half fragment reads, one per MFMA, inside the 48 first-half MFMAs
+        constexpr int NDMA = NP + (HASW ? WPW : 0);
+#ifdef ISP_ABLATE_NO_DMA  // timing experiment only
+        constexpr int NDMA_ISSUED = 0;
+#else
+        constexpr int NDMA_ISSUED = NDMA;
+#pragma unroll
+        for (int i = PPS * TAP; i < PPS * TAP + NP; ++i) issue_patch(i, cb + 1, patch_next);
+        if constexpr (HASW)
+            issue_w(TAP < 7 ? (TAP + 2) * C + cb * BK : (TAP - 7) * C + (cb + 1) * BK, s_w + ((TAP + 2) % 3) * PWB);
+#endif
+        read_w(fw1, s_w + (TAP % 3) * PWB, 1);
+        read_a(fa1, patch, TAP, 1);
+        mma(fa0, fw0, 0, TM);
+#pragma unroll
+        for (int i = 0; i < NDMA_ISSUED; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // 1 VMEM (LDS-DMA)
+        }
+#pragma unroll
+        for (int i = 0; i < TM + TN; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, C4_SP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - NDMA_ISSUED - C4_SP * (TM + TN), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // region 2: the first 12 second-half MFMAs, then the barrier of step s+1: everything older than this step's
+        // DMA has landed (weight tile of step s+1, earlier patch pieces) and every wave is done with tile s-1
+        mma(fa1, fw1, 0, C4_PRE);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA_ISSUED) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // region 3: first-half fragments of step s+1 behind the remaining 36 MFMAs
+        // (after the very last step these read stale, in-bounds LDS: unused)
+        read_w(fw0, s_w + ((TAP + 1) % 3) * PWB, 0);
+        read_a(fa0, TAP < 8 ? patch : patch_next, TAP < 8 ? TAP + 1 : 0, 0);
+        mma(fa1, fw1, C4_PRE, TM);
+#pragma unroll
+        for (int i = 0; i < TM + TN; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, C4_SP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, (TM - C4_PRE) * TN - C4_SP * (TM + TN), 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto block9 = [&]<bool MORE>(int cb) {
+        const char* patch = smem + (cb & 1) * P_BYTES;
+        char* patch_next = smem + ((cb + 1) & 1) * P_BYTES;
+        step.template operator()<0, MORE, true>(cb, patch, patch_next);
+        step.template operator()<1, MORE, true>(cb, patch, patch_next);
+        step.template operator()<2, MORE, true>(cb, patch, patch_next);
+        step.template operator()<3, MORE, true>(cb, patch, patch_next);
+        step.template operator()<4, MORE, true>(cb, patch, patch_next);
+        step.template operator()<5, MORE, true>(cb, patch, patch_next);
+        step.template operator()<6, MORE, true>(cb, patch, patch_next);
+        step.template operator()<7, MORE, MORE>(cb, patch, patch_next);  // steps s+2 of taps 7, 8 are in block cb+1
+        step.template operator()<8, MORE, MORE>(cb, patch, patch_next);
+    };
+    for (int cb = 0; cb + 1 < cblocks; ++cb) block9.template operator()<true>(cb);
+    block9.template operator()<false>(cblocks - 1);
+
+    auto row_of = [&](int r) -> long {
+        const int y = y0 + (r >> 4), x = x0 + (r & 15);
+        return (y < H && x < W) ? ((long)b * H + y) * W + x : -1;
+    };
+#ifdef ISP_ABLATE_NO_EPILOGUE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+    if (y0 + PT <= H && x0 + PT <= W && n0 + PBN <= N) {  // interior tile: no per-lane checks
+        auto row_in = [&](int r) -> long { return ((long)b * H + y0 + (r >> 4)) * W + x0 + (r & 15); };
+#ifdef ISP_C4_NO_STAGE  // A/B experiment: direct 8-byte stores
+        if constexpr (false) {
+#else
+        if constexpr (requires { ep.out; ep.ldo; typename EP::Cols; } && !requires { EP::kRowReduce; } &&
+                      !requires { typename EP::Pre; }) {
+#endif
+            // bf16 output tile staged through the (now idle) LDS so that the global stores are 16 bytes per lane with
+            // neighbouring lanes contiguous: the accumulator layout gives a lane 4 channels of ONE pixel, i.e. 64
+            // separate 8-byte segments per store instruction (measured: half of the epilogue's 9 % of the launch).
+            // Wave-private staging [128 px][96 ch] bf16 at a 208-byte pitch (<= 2-way write conflicts); the other
+            // waves are past every LDS read whose value is used.
+            constexpr int SP = TN * 32 + 16;
+            char* const stg = smem + wid * (TM * 16 * SP);
+            const int n_base = n0 + wn * (TN * 16);
+            typename EP::Cols cc[TN];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) cc[ni] = ep.cols(n_base + ni * 16 + fq * 4);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const long m = row_in(wm * (TM * 16) + mi * 16 + fr);
+                [[maybe_unused]] unsigned ctx = 0;
+                if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                    uint2 o;
+                    if constexpr (requires { ep.row_begin(m); }) o = ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni], ctx);
+                    else o = ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni]);
+                    *reinterpret_cast<uint2*>(stg + (mi * 16 + fr) * SP + ni * 32 + fq * 8) = o;
+                }
+            }
+            // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier)
+            constexpr int CPP = TN * 2;  // 16-byte chunks per pixel
+#pragma unroll
+            for (int j = 0; j < TM * 16 * CPP / 64; ++j) {
+                const int id = j * 64 + lane, px = id / CPP, c = id - px * CPP;
+                const uint4 q = *reinterpret_cast<const uint4*>(stg + px * SP + c * 16);
+                *reinterpret_cast<uint4*>(ep.out + (size_t)row_in(wm * (TM * 16) + px) * ep.ldo + n_base + c * 8) = q;
+            }
+        } else {
+            run_epilogue<TM, TN, true>(ep, acc, row_in, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
+        }
+    } else {
+        run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
+    }
+}
+
+template <class EP>
+int launch_conv_patch4(const void* in, const void* Wt, int B, int H, int W, int C, int N, EP ep, hipStream_t s) {
+    constexpr int PBN = 192, P_LDS = 2 * P_BYTES + 3 * PBN * BK * 2;
+    const int tiles_x = (W + PT - 1) / PT, tiles_y = (H + PT - 1) / PT, tiles_n = (N + PBN - 1) / PBN;
+    const long nwg = (long)B * tiles_x * tiles_y * tiles_n;
+    // buffer resources address bytes with 32-bit offsets; 0x80000000 must stay out of range
+    if (nwg > 0x7fffffffL || (long)H * W * C * 2 >= 0x7fffffffL || (long)PBN * 9 * C * 2 >= 0x7fffffffL) return ISP_ERR_UNSUPPORTED;
+    static bool attr_done = false;
+    auto kern = conv3x3_patch4_kernel<EP>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess)
+            return ISP_ERR_LAUNCH;
+        attr_done = true;
+    }
+    kern<<<(unsigned)nwg, 256, P_LDS, s>>>((const bf16_t*)in, (const bf16_t*)Wt, H, W, C, N, tiles_x, tiles_y, tiles_n,
+                                          (int)nwg, ep);
+    return isp_launch_status();
+}
+
+static int conv_patch_waves() {  // A/B switch: ISEGPROBE_CONV_ENGINE=8 keeps 192-channel blocks on the 8-wave patch kernel
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ISEGPROBE_CONV_ENGINE");
+        v = (e && e[0] == '8') ? 8 : 4;
+    }
+    return v;
+}
+
 // dispatch of the epilogue kinds the patch conv supports
 template <int TN>
 int dispatch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int C, int N, const isp_epilogue* e,
                         hipStream_t s) {
     const long M = (long)B * H * W;
     const long ldo = e->ldo > 0 ? e->ldo : N;
+    if constexpr (TN == 6) {
+        // (the 4-wave kernel stores its bf16 tile as 16-byte chunks)
+        if (conv_patch_waves() == 4 && ldo % 8 == 0 && (reinterpret_cast<size_t>(e->out) & 15) == 0) {
+            switch (e->kind) {
+                case ISP_EP_BIAS_RELU_BF16:
+                    return launch_conv_patch4(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_RELU>{(bf16_t*)e->out, e->bias, ldo}, s);
+                case ISP_EP_BIAS_TAPS_RELU_BF16:
+                    if (!e->bias || !e->pos || e->img_h <= 0 || e->img_w <= 0 || ldo != N) return ISP_ERR_INVALID;
+                    return launch_conv_patch4(in, Wt, B, H, W, C, N,
+                                              EpBiasTapsReluBf16{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
+                case ISP_EP_RELU_DOT_PARTIAL_F32:
+                    if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
+                    return launch_conv_patch4(in, Wt, B, H, W, C, N, EpReluDotPartial{(float*)e->out, e->bias, e->gamma, M}, s);
+                default: break;
+            }
+        }
+    }
     switch (e->kind) {
         case ISP_EP_BIAS_BF16:
             return launch_conv_patch<TN>(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_NONE>{(bf16_t*)e->out, e->bias, ldo}, s);
