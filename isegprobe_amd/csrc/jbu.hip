@@ -291,7 +291,9 @@ constexpr int ATH = 8, ATW = 16, ACC = 64;
 constexpr int SROWS = 11, SCOLS = 24, SPIX = SROWS * SCOLS;                   // 264 source pixels
 constexpr int SRC_TILE_BYTES = ((SPIX + 7) / 8) * 8 * ACC * 2;                // padded to whole 1 KiB pieces
 constexpr int KC_TILE_BYTES = ATH * 8 * ATW * 32;
-constexpr int APPLY_LDS = SRC_TILE_BYTES > KC_TILE_BYTES ? SRC_TILE_BYTES : KC_TILE_BYTES;
+constexpr int STG_PITCH = ACC * 2 + 16;                                        // output staging: bytes per pixel
+constexpr int APPLY_TILE = SRC_TILE_BYTES > KC_TILE_BYTES ? SRC_TILE_BYTES : KC_TILE_BYTES;
+constexpr int APPLY_LDS = APPLY_TILE + 4 * 2 * ATW * STG_PITCH;                // + 18 KiB: still 3 blocks per CU
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -305,6 +307,7 @@ __global__ __launch_bounds__(256, 3) void jbu_apply_kernel(const bf16_t* __restr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_src = smem;
     char* s_kc = smem;  // same bytes: the kernel tile is dead once the band fragments are in registers
+    char* s_stage = smem + APPLY_TILE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int GH = 2 * h, GW = 2 * w;
@@ -382,17 +385,24 @@ __global__ __launch_bounds__(256, 3) void jbu_apply_kernel(const bf16_t* __restr
                 acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, band[1][ry], acc[1][cb], 0, 0, 0);
             }
         }
-        // D[ch = 4*(lane>>4)+j][px = lane&15]
+        // D[ch = 4*(lane>>4)+j][px = lane&15]: a lane holds 4 channels of ONE pixel, i.e. a direct store is 64 separate
+        // 8-byte segments per instruction.  The wave's 2 x 16 pixels x 64 channels go through a wave-private LDS
+        // staging tile (144-byte pixel pitch) and leave as 16 bytes per lane, 8 lanes per 128-byte pixel segment.
+        char* const stg = s_stage + wid * (2 * ATW * STG_PITCH);
 #pragma unroll
-        for (int si = 0; si < 2; ++si) {
+        for (int si = 0; si < 2; ++si)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                *reinterpret_cast<uint2*>(stg + (si * ATW + px) * STG_PITCH + cb * 32 + g * 8) =
+                    make_uint2(pack2bf(acc[si][cb][0], acc[si][cb][1]), pack2bf(acc[si][cb][2], acc[si][cb][3]));
+        // (written and read by the same wave: ordered by the compiler's lgkmcnt wait)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int id = j * 64 + lane, si = id >> 7, spx = (id >> 3) & 15, ck = id & 7;
+            const uint4 q = *reinterpret_cast<const uint4*>(stg + (si * ATW + spx) * STG_PITCH + ck * 16);
             const int strip = wid * 2 + si;
-            if (y0 + strip < GH && x0 + px < GW) {
-                bf16_t* op = out + (((size_t)b * GH + y0 + strip) * GW + x0 + px) * C + c0 + 4 * g;
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-                    *reinterpret_cast<uint2*>(op + cb * 16) =
-                        make_uint2(pack2bf(acc[si][cb][0], acc[si][cb][1]), pack2bf(acc[si][cb][2], acc[si][cb][3]));
-            }
+            if (y0 + strip < GH && x0 + spx < GW)
+                *reinterpret_cast<uint4*>(out + (((size_t)b * GH + y0 + strip) * GW + x0 + spx) * C + c0 + ck * 8) = q;
         }
     }
 }
