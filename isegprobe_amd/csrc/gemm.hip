@@ -457,6 +457,58 @@ __device__ __forceinline__ void run_epilogue(const EP& ep, f32x4 (&acc)[TM][TN],
     }
 }
 
+// bf16-output epilogues that can hand back their packed values (pack(), no per-element operand, no row reduction)
+// may leave through LDS: the accumulator layout gives a lane 4 columns of ONE row, so a direct store instruction is
+// 64 separate 8-byte segments (measured: the epilogue was ~40 % of a K = 384..512 GEMM and half of the conv's 9 %).
+// The wave's TM*16 x TN*16 tile is written to a wave-private LDS tile (pitch TN*32 + 16 bytes: <= 2-way conflicts)
+// and read back as 16 bytes per lane with neighbouring lanes contiguous along the row.
+template <class EP>
+constexpr bool kStagedStore = requires(const EP& e) { e.out; e.ldo; typename EP::Cols; } &&
+                              !requires { EP::kRowReduce; } && !requires { typename EP::Pre; } &&
+                              (requires(const EP& e, const float* v, const typename EP::Cols& c) { e.pack(0L, 0, v, c); } ||
+                               requires(const EP& e, const float* v, const typename EP::Cols& c) { e.pack(0L, 0, v, c, 0u); });
+template <int TM, int TN>
+constexpr int kStageBytes = TM * 16 * (TN * 32 + 16);  // per wave
+
+template <class EP>
+__device__ __forceinline__ bool staged_store_ok(const EP& ep) {  // 16-byte chunks need 8-element alignment
+    if constexpr (kStagedStore<EP>) return ep.ldo % 8 == 0 && (reinterpret_cast<size_t>(ep.out) & 15) == 0;
+    else return false;
+}
+
+// row_in(r): global output row of tile row r (the tile is interior: every row and column exists); stg: this wave's
+// kStageBytes<TM, TN> of LDS that no other wave touches any more.
+template <int TM, int TN, class EP, class RowFn>
+__device__ __forceinline__ void staged_epilogue(const EP& ep, f32x4 (&acc)[TM][TN], RowFn row_in, int row_base, int fr,
+                                                int fq, int lane, int n_base, char* stg) {
+    constexpr int SP = TN * 32 + 16, CPR = TN * 2;  // row pitch; 16-byte chunks per row
+    static_assert((TM * 16 * CPR) % 64 == 0);
+    typename EP::Cols cc[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) cc[ni] = ep.cols(n_base + ni * 16 + fq * 4);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        [[maybe_unused]] const long m = row_in(row_base + mi * 16 + fr);
+        [[maybe_unused]] unsigned ctx = 0;
+        if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+            uint2 o;
+            if constexpr (requires { ep.row_begin(m); }) o = ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni], ctx);
+            else o = ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni]);
+            *reinterpret_cast<uint2*>(stg + (mi * 16 + fr) * SP + ni * 32 + fq * 8) = o;
+        }
+    }
+    // (written and read by the same wave: the compiler's lgkmcnt wait orders them)
+#pragma unroll
+    for (int j = 0; j < TM * 16 * CPR / 64; ++j) {
+        const int id = j * 64 + lane, row = id / CPR, c = id - row * CPR;
+        const uint4 q = *reinterpret_cast<const uint4*>(stg + row * SP + c * 16);
+        *reinterpret_cast<uint4*>(ep.out + (size_t)row_in(row_base + row) * ep.ldo + n_base + c * 8) = q;
+    }
+}
+
 template <class CFG, class AL, class EP>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL al, const bf16_t* __restrict__ Wt, long M,
                                                                           int N, int K, int tiles_n, int nwg, EP ep) {
@@ -579,11 +631,23 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
     }
 
     auto row_of = [&](int r) { return al.template out_row<BM>(tm, r); };
+#ifdef ISP_ABLATE_GEMM_NO_EPILOGUE  // timing experiment only
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     // interior tile (wave-uniform): every row of the tile maps to an output row and every column is < N
-    if (n0 + BN <= N && al.template tile_full<BM>(tm))
+    if (n0 + BN <= N && al.template tile_full<BM>(tm)) {
+        if constexpr (kStagedStore<EP> && NW * kStageBytes<TM, TN> <= CFG::LDS) {
+            if (staged_store_ok(ep)) {
+                __builtin_amdgcn_s_barrier();  // every wave is done reading the operand ring
+                staged_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, lane, n0 + wn * (TN * 16),
+                                        smem + wid * kStageBytes<TM, TN>);
+                return;
+            }
+        }
         run_epilogue<TM, TN, true>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * CFG::WN + wn);
-    else
+    } else {
         run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * CFG::WN + wn);
+    }
 }
 
 template <class CFG, class AL, class EP>
@@ -777,9 +841,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(const bf16_t* __r
 #endif
     {
         if (y0 + PT <= H && x0 + PT <= W && n0 + PBN <= N) {  // interior tile: no per-lane checks
-            run_epilogue<TM, TN, true>(
-                ep, acc, [&](int r) -> long { return ((long)b * H + y0 + (r >> 4)) * W + x0 + (r & 15); }, wm * (TM * 16),
-                fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
+            auto row_in = [&](int r) -> long { return ((long)b * H + y0 + (r >> 4)) * W + x0 + (r & 15); };
+            if constexpr (kStagedStore<EP>) {
+                if (staged_store_ok(ep)) {
+                    __builtin_amdgcn_s_barrier();  // every wave is done with the patch and the weight ring
+                    staged_epilogue<TM, TN>(ep, acc, row_in, wm * (TM * 16), fr, fq, lane, n0 + wn * (TN * 16),
+                                            smem + wid * kStageBytes<TM, TN>);
+                    return;
+                }
+            }
+            run_epilogue<TM, TN, true>(ep, acc, row_in, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
         } else {
             run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
         }
@@ -1002,45 +1073,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel(const bf16_t* __
 #endif
     if (y0 + PT <= H && x0 + PT <= W && n0 + PBN <= N) {  // interior tile: no per-lane checks
         auto row_in = [&](int r) -> long { return ((long)b * H + y0 + (r >> 4)) * W + x0 + (r & 15); };
-#ifdef ISP_C4_NO_STAGE  // A/B experiment: direct 8-byte stores
-        if constexpr (false) {
-#else
-        if constexpr (requires { ep.out; ep.ldo; typename EP::Cols; } && !requires { EP::kRowReduce; } &&
-                      !requires { typename EP::Pre; }) {
-#endif
-            // bf16 output tile staged through the (now idle) LDS so that the global stores are 16 bytes per lane with
-            // neighbouring lanes contiguous: the accumulator layout gives a lane 4 channels of ONE pixel, i.e. 64
-            // separate 8-byte segments per store instruction (measured: half of the epilogue's 9 % of the launch).
-            // Wave-private staging [128 px][96 ch] bf16 at a 208-byte pitch (<= 2-way write conflicts); the other
-            // waves are past every LDS read whose value is used.
-            constexpr int SP = TN * 32 + 16;
-            char* const stg = smem + wid * (TM * 16 * SP);
-            const int n_base = n0 + wn * (TN * 16);
-            typename EP::Cols cc[TN];
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) cc[ni] = ep.cols(n_base + ni * 16 + fq * 4);
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const long m = row_in(wm * (TM * 16) + mi * 16 + fr);
-                [[maybe_unused]] unsigned ctx = 0;
-                if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) {
-                    const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-                    uint2 o;
-                    if constexpr (requires { ep.row_begin(m); }) o = ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni], ctx);
-                    else o = ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni]);
-                    *reinterpret_cast<uint2*>(stg + (mi * 16 + fr) * SP + ni * 32 + fq * 8) = o;
-                }
-            }
-            // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier)
-            constexpr int CPP = TN * 2;  // 16-byte chunks per pixel
-#pragma unroll
-            for (int j = 0; j < TM * 16 * CPP / 64; ++j) {
-                const int id = j * 64 + lane, px = id / CPP, c = id - px * CPP;
-                const uint4 q = *reinterpret_cast<const uint4*>(stg + px * SP + c * 16);
-                *reinterpret_cast<uint4*>(ep.out + (size_t)row_in(wm * (TM * 16) + px) * ep.ldo + n_base + c * 8) = q;
-            }
+        // the other waves are past every LDS read whose value is used: no barrier before the wave-private staging
+        if constexpr (kStagedStore<EP>) {
+            staged_epilogue<TM, TN>(ep, acc, row_in, wm * (TM * 16), fr, fq, lane, n0 + wn * (TN * 16),
+                                    smem + wid * kStageBytes<TM, TN>);
         } else {
             run_epilogue<TM, TN, true>(ep, acc, row_in, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
         }
