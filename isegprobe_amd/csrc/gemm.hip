@@ -886,13 +886,12 @@ int launch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int C
 // chunks are XOR-swizzled by the pixel's COLUMN in the patch ((px >> 1) & 7): a fragment read's address is then
 // lane constant(dx, k-half) + immediate((t + dy + 1) * row pitch) -- no per-read address arithmetic.
 //   LDS = 2 x 42 KiB patch + 3 x 24 KiB weights = 156 KiB.
-template <class EP>
-__global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel(const bf16_t* __restrict__ in,
-                                                                const bf16_t* __restrict__ Wt, int H, int W, int C,
-                                                                int N, int tiles_x, int tiles_y, int tiles_n, int nwg,
-                                                                EP ep) {
-    constexpr int TM = 8, TN = 6, NWV = 4, PPW = (P_PIECES + NWV - 1) / NWV;  // 11 patch pieces per wave
-    constexpr int PBN = 2 * TN * 16, PWB = PBN * BK * 2, WPW = PBN / 8 / NWV;  // 6 weight pieces per wave
+template <class EP, int TN>
+__device__ __forceinline__ void conv3x3_patch4_body(const bf16_t* __restrict__ in, const bf16_t* __restrict__ Wt, int H,
+                                                    int W, int C, int N, int tiles_x, int tiles_y, int tiles_n, int nwg,
+                                                    const EP& ep) {
+    constexpr int TM = 8, NWV = 4, PPW = (P_PIECES + NWV - 1) / NWV;          // 11 patch pieces per wave
+    constexpr int PBN = 2 * TN * 16, PWB = PBN * BK * 2, WPW = PBN / 8 / NWV;  // 6 (TN = 6) or 4 weight pieces per wave
     constexpr int PPS = 2;                                                     // patch pieces per wave per K-step
     constexpr int ROWB = PW_ * 128;                                            // bytes per patch row
 #ifndef ISP_C4_PRE
@@ -1085,15 +1084,35 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel(const bf16_t* __
     }
 }
 
+// (thin kernels: with the body above written directly as a __global__ template that depends on TN, hipcc 7.2
+// silently leaves the kernel's host-side handle undefined)
 template <class EP>
+__global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel_192(const bf16_t* __restrict__ in,
+                                                                    const bf16_t* __restrict__ Wt, int H, int W, int C,
+                                                                    int N, int tiles_x, int tiles_y, int tiles_n,
+                                                                    int nwg, EP ep) {
+    conv3x3_patch4_body<EP, 6>(in, Wt, H, W, C, N, tiles_x, tiles_y, tiles_n, nwg, ep);
+}
+template <class EP>
+__global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel_128(const bf16_t* __restrict__ in,
+                                                                    const bf16_t* __restrict__ Wt, int H, int W, int C,
+                                                                    int N, int tiles_x, int tiles_y, int tiles_n,
+                                                                    int nwg, EP ep) {
+    conv3x3_patch4_body<EP, 4>(in, Wt, H, W, C, N, tiles_x, tiles_y, tiles_n, nwg, ep);
+}
+
+template <int TN, class EP>
 int launch_conv_patch4(const void* in, const void* Wt, int B, int H, int W, int C, int N, EP ep, hipStream_t s) {
-    constexpr int PBN = 192, P_LDS = 2 * P_BYTES + 3 * PBN * BK * 2;
+    constexpr int PBN = 2 * TN * 16, P_LDS = 2 * P_BYTES + 3 * PBN * BK * 2;
     const int tiles_x = (W + PT - 1) / PT, tiles_y = (H + PT - 1) / PT, tiles_n = (N + PBN - 1) / PBN;
     const long nwg = (long)B * tiles_x * tiles_y * tiles_n;
     // buffer resources address bytes with 32-bit offsets; 0x80000000 must stay out of range
     if (nwg > 0x7fffffffL || (long)H * W * C * 2 >= 0x7fffffffL || (long)PBN * 9 * C * 2 >= 0x7fffffffL) return ISP_ERR_UNSUPPORTED;
     static bool attr_done = false;
-    auto kern = conv3x3_patch4_kernel<EP>;
+    static_assert(TN == 6 || TN == 4);
+    void (*kern)(const bf16_t*, const bf16_t*, int, int, int, int, int, int, int, int, EP);
+    if constexpr (TN == 6) kern = conv3x3_patch4_kernel_192<EP>;
+    else kern = conv3x3_patch4_kernel_128<EP>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess)
             return ISP_ERR_LAUNCH;
@@ -1119,19 +1138,21 @@ int dispatch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int
                         hipStream_t s) {
     const long M = (long)B * H * W;
     const long ldo = e->ldo > 0 ? e->ldo : N;
-    if constexpr (TN == 6) {
-        // (the 4-wave kernel stores its bf16 tile as 16-byte chunks)
+    {
+        // one-wave-per-SIMD kernel (it stores its bf16 tile as 16-byte chunks)
         if (conv_patch_waves() == 4 && ldo % 8 == 0 && (reinterpret_cast<size_t>(e->out) & 15) == 0) {
             switch (e->kind) {
+                case ISP_EP_BIAS_BF16:
+                    return launch_conv_patch4<TN>(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_NONE>{(bf16_t*)e->out, e->bias, ldo}, s);
                 case ISP_EP_BIAS_RELU_BF16:
-                    return launch_conv_patch4(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_RELU>{(bf16_t*)e->out, e->bias, ldo}, s);
+                    return launch_conv_patch4<TN>(in, Wt, B, H, W, C, N, EpBiasActBf16<ACT_RELU>{(bf16_t*)e->out, e->bias, ldo}, s);
                 case ISP_EP_BIAS_TAPS_RELU_BF16:
                     if (!e->bias || !e->pos || e->img_h <= 0 || e->img_w <= 0 || ldo != N) return ISP_ERR_INVALID;
-                    return launch_conv_patch4(in, Wt, B, H, W, C, N,
+                    return launch_conv_patch4<TN>(in, Wt, B, H, W, C, N,
                                               EpBiasTapsReluBf16{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
                 case ISP_EP_RELU_DOT_PARTIAL_F32:
                     if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
-                    return launch_conv_patch4(in, Wt, B, H, W, C, N, EpReluDotPartial{(float*)e->out, e->bias, e->gamma, M}, s);
+                    return launch_conv_patch4<TN>(in, Wt, B, H, W, C, N, EpReluDotPartial{(float*)e->out, e->bias, e->gamma, M}, s);
                 default: break;
             }
         }
