@@ -61,7 +61,7 @@ def build(upsampler, size):
 class ConvTimer:
     """HIP events around every 3x3-conv launch of the timed steps (same stream as the launch).  The
     seg head issues them through three wrappers (plain, folded-affine first layer, classifier-fused
-    last layer); all three run conv3x3_patch_kernel<...> with the same algorithmic FLOPs."""
+    last layer); all three run conv3x3_patch4_kernel_192<...> with the same algorithmic FLOPs."""
 
     NAMES = ("conv3x3", "conv3x3_folded_affine", "conv3x3_relu_classifier")
 
@@ -218,7 +218,7 @@ def main():
                                    f"{args.size}x{args.size}, batch {args.batch}/GPU, forward-only, "
                                    "seeded random-init weights", "per_gpu_batch": args.batch,
                        "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"replicas x{world}"},
-            "roofline": {"kernel": "conv3x3_patch_kernel<bias+ReLU> (seg-head 3x3 conv, implicit GEMM, LDS-resident input patch)",
+            "roofline": {"kernel": "conv3x3_patch4_kernel_192 (seg-head 3x3 conv, implicit GEMM, LDS-resident input patch, one wave per SIMD)",
                          "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_note": "fabric bytes per launch from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_conv_pmc.json",

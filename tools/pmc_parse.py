@@ -2,7 +2,7 @@
 """Summarise the per-counter rocprofv3 CSVs that tools/conv_pmc.sh wrote into profiles/<out>.json."""
 import csv, glob, json, os, sys
 out = sys.argv[1]
-kernel_sub = sys.argv[2] if len(sys.argv) > 2 else "conv3x3_patch_kernel"
+kernel_sub = sys.argv[2] if len(sys.argv) > 2 else "conv3x3_patch"
 res = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_l2"):
     files = sorted(glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
