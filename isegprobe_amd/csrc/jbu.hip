@@ -116,7 +116,6 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
     }
     __syncthreads();
     const int lx = threadIdx.x & (TSX - 1), ly = threadIdx.x / TSX;
-    const bool in_image = (ty0 + ly) < GH && (tx0 + lx) < GW;
     const int y = min(ty0 + ly, GH - 1), x = min(tx0 + lx, GW - 1);  // out-of-image lanes compute a clamped pixel
 
     float4 ctr[KEY / 4];
@@ -233,8 +232,12 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
     // k is dead afterwards), then the two halves of the 16 circular column slots
     const float* byp = bys + (size_t)y * (DIA * 8);
     const float* bxp = bxs + (size_t)x * (DIA * 16);
-    if (!in_image) return;
-    bf16_t* o = kout + ((size_t)b * HW + p) * 128;
+    // The 256-byte record of a pixel is staged in LDS and leaves as 16 bytes per lane with 16 lanes per record: a
+    // thread storing its own record directly issues 64 separate 16-byte segments per instruction (partial lines).
+    // Wave-private staging [64 px][16 chunks], chunk slot XORed with the pixel index (conflict-free both ways).
+    __syncthreads();  // every wave has read its MLP result rows: the LDS below is free
+    char* const stg = smem + (threadIdx.x >> 6) * (64 * 256);
+    const int sl = threadIdx.x & 63;
     float hrow[8][DIA];
 #pragma unroll
     for (int ry = 0; ry < 8; ++ry)
@@ -267,9 +270,19 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
             for (int tx = 0; tx < DIA; ++tx)
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8) r[s8] = fmaf(hrow[ry][tx], bx[tx][s8], r[s8]);
-            *reinterpret_cast<uint4*>(o + ry * 16 + half * 8) =
+            *reinterpret_cast<uint4*>(stg + sl * 256 + (((ry * 2 + half) ^ (sl & 15)) << 4)) =
                 make_uint4(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]), pack2bf(r[4], r[5]), pack2bf(r[6], r[7]));
         }
+    }
+    // (written and read by the same wave: ordered by the compiler's lgkmcnt wait)  The wave's 64 pixels are two
+    // runs of 32 consecutive pixels (tile rows ly = 2w, 2w+1).
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int id = j * 64 + sl, spx = id >> 4, ck = id & 15;
+        const uint4 q = *reinterpret_cast<const uint4*>(stg + spx * 256 + ((ck ^ (spx & 15)) << 4));
+        const int gy = ty0 + (threadIdx.x >> 6) * 2 + (spx >> 5), gx = tx0 + (spx & 31);
+        if (gy < GH && gx < GW)
+            *reinterpret_cast<uint4*>(kout + ((size_t)b * HW + (size_t)gy * GW + gx) * 128 + ck * 8) = q;
     }
 }
 
