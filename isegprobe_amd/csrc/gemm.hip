@@ -1265,10 +1265,11 @@ extern "C" int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, in
         al.M = M;
         return dispatch_epilogue<CFG, DenseA<CFG::PA>, 0x3e7fu>(al, Wt, M, N, K, ep, (hipStream_t)stream);
     };
-    // Operand tiles are staged L2 -> LDS and that path tops out near 7 TB/s chip-wide, so the 128x128 tile
-    // (64 FLOP per staged byte) caps these short-K GEMMs near 450 TFLOP/s: measured 417-454 on LoftUp's
-    // M = 1.6 M-row layers.  With >= 512 row tiles of 256 the 8-wave 256x192 tile (110 FLOP/B) runs them at
-    // 460-556 even when N is not a multiple of 192; ViT-sized problems (M = 33 k) lose 10 % on it and stay on 128x128.
+    // Short-K GEMMs (6-8 K-steps) are bound by per-tile latencies (first-stage DMA, epilogue chain), not by MFMA or
+    // staging bandwidth: without their epilogue they run at 800-980 TFLOP/s, with it at 520-650 (M = 1.6 M rows,
+    // 256x192 tile) / 680-790 (ViT-sized, 128x128, 2 blocks per CU).  Measured alternatives on the M = 1.6 M shapes:
+    // 256x128 with a 3-stage ring 523-619 (ring 2: 451-535), 128x128 ring 3 (1 block / CU) 448-505, 128x64 and
+    // 64x128 ring 3 (2 blocks / CU) 405-522; ViT-sized problems lose 10 % on the 8-wave tiles and stay on 128x128.
     if ((M + 255) / 256 >= 512 && N >= 384) return run(CfgConv192{});
     // the batch-2 click loop (M = 2050 tokens): 128-row tiles give 153 blocks for 256 CUs; 64-row tiles fill the chip
     if (((M + 127) / 128) * ((N + 127) / 128) < 256) return run(Cfg64{});
