@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
                                                             long M, int slots, float bias) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= M) return;
-    if (i + 3 < M) {
+    if ((M & 3) == 0) {  // slot rows are 16-byte aligned only when M is a multiple of 4
         float4 acc = make_float4(bias, bias, bias, bias);
         for (int s = 0; s < slots; ++s) {
             const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)s * M + i);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
         }
         *reinterpret_cast<float4*>(out + i) = acc;
     } else {
-        for (long j = i; j < M; ++j) {
+        for (long j = i; j < M && j < i + 4; ++j) {
             float a = bias;
             for (int s = 0; s < slots; ++s) a += partial[(size_t)s * M + j];
             out[j] = a;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 }
 
 extern "C" int isp_sum_partials_f32(const float* partial, float* out, long M, int slots, float bias, void* stream) {
-    ISP_CHECK_ARG(partial && out && M > 0 && slots > 0 && M % 4 == 0);
-    sum_partials_kernel<<<(unsigned)((M / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(partial, out, M, slots, bias);
+    ISP_CHECK_ARG(partial && out && M > 0 && slots > 0);
+    sum_partials_kernel<<<(unsigned)(((M + 3) / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(partial, out, M, slots, bias);
     return isp_launch_status();
 }

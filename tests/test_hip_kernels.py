@@ -126,7 +126,11 @@ def test_gemm_residual_and_tokens(ops):
 
 
 @pytest.mark.parametrize("B,H,W,C,N", [(1, 8, 8, 64, 64), (2, 20, 24, 64, 64), (1, 37, 45, 128, 192),
-                                       (2, 56, 56, 384, 384)])
+                                       (2, 56, 56, 384, 384),
+                                       # one-wave-per-SIMD patch kernel: a single channel block, 128-channel blocks with a
+                                       # ragged last block (448), exact 128-channel tiling, interior + border tiles
+                                       (2, 33, 47, 64, 192), (1, 40, 40, 448, 448), (1, 16, 16, 128, 128),
+                                       (1, 48, 32, 192, 1024), (1, 21, 19, 64, 320)])
 def test_conv3x3(ops, B, H, W, C, N):
     torch.manual_seed(C + H)
     x = bf(torch.randn(B, C, H, W, device="cuda"))
@@ -135,6 +139,45 @@ def test_conv3x3(ops, B, H, W, C, N):
     ref = F.relu(F.conv2d(x.float(), w.float(), bias, padding=1))
     y = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), bias, "relu")
     assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-2
+
+
+@pytest.mark.parametrize("H,W,C,N", [(48, 48, 128, 384), (37, 29, 64, 192), (32, 32, 128, 128)])
+def test_conv3x3_fused_epilogues(ops, H, W, C, N):
+    """Folded-affine first conv (border-exact tap table) and classifier-fused last conv on interior + border tiles."""
+    torch.manual_seed(H + N)
+    B = 2
+    x = bf(torch.randn(B, C, H, W, device="cuda"))
+    w = bf(torch.randn(N, C, 3, 3, device="cuda") / math.sqrt(9 * C))
+    wt = w.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous()
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    bias = torch.randn(N, device="cuda")
+    # taps[t][n]: constant contributed through tap t wherever that tap lies inside the image
+    taps = torch.randn(9, N, device="cuda") * 0.3
+    y = ops.conv3x3_folded_affine(xn, wt, bias + taps.sum(0), taps)
+    inside = F.conv2d(torch.ones(1, 1, H, W, device="cuda"), torch.eye(9, device="cuda").view(9, 1, 3, 3), padding=1)  # [1,9,H,W]
+    const = torch.einsum("tn,thw->nhw", taps, inside[0])
+    ref = F.relu(F.conv2d(x.float(), w.float(), bias, padding=1) + const)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-2
+    wcls = torch.randn(N, device="cuda") / math.sqrt(N)
+    z = ops.conv3x3_relu_classifier(xn, wt, bias, wcls, 0.25)
+    refz = (F.relu(F.conv2d(x.float(), w.float(), bias, padding=1)) * wcls.view(1, N, 1, 1)).sum(1) + 0.25
+    assert (z - refz).abs().max().item() < 2e-2 * refz.abs().max().item() + 1e-2
+
+
+def test_gemm_bf16_store_paths(ops):
+    """bf16 outputs leave through LDS as 16-byte chunks when the leading dimension allows it; a leading dimension
+    that is only a multiple of 4 and partial edge tiles take the direct path.  Same values either way."""
+    from isegprobe_amd import _lib
+    torch.manual_seed(5)
+    for M, N, K, ldo in ((512, 384, 128, 384), (515, 384, 128, 388), (300, 200, 64, 200), (256, 128, 64, 132)):
+        A, W = bf(torch.randn(M, K, device="cuda")), bf(torch.randn(N, K, device="cuda") / math.sqrt(K))
+        bias = torch.randn(N, device="cuda")
+        out = torch.full((M, ldo), 7.0, device="cuda", dtype=BF)
+        ops.gemm(A, W, ops._epilogue(_lib.EP_BIAS_RELU_BF16, out, ldo, bias))
+        ref = F.relu(A.float() @ W.float().t() + bias)
+        assert rel_err(out[:, :N], ref) < 1e-2
+        if ldo > N:
+            assert torch.equal(out[:, N:], torch.full((M, ldo - N), 7.0, device="cuda", dtype=BF))  # padding untouched
 
 
 @pytest.mark.parametrize("B,L,heads", [(1, 64, 1), (2, 257, 2), (2, 1025, 6), (1, 130, 3)])
