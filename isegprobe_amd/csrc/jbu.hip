@@ -288,25 +288,25 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
 
 // --------------------------------------------------------------------------------------
 // Apply the composite kernels: out[b,y,x,:] = sum_{ry,rx} kc[b,y,x][ry][rx] * src[b, clamp(base_y+ry),
-// clamp(base_x+rx), :].  Block = 8 rows x 16 cols of output pixels, all channels (looped in
-// chunks of 64).  Per 16-pixel strip and window row ry the 16 per-pixel kernels form a banded
-// [32 src cols x 16 px] matrix (k = src column inside the tile, 24 used) that is the B operand
-// of v_mfma_f32_16x16x32_bf16; the A operand is the transposed source row ([16 ch x 32 cols])
-// read from the [pixel][channel] LDS tile with ds_read_b64_tr_b16.  D[ch][px] lands with 4
-// consecutive channels per lane (8-byte stores).
-//   LDS: source tile 11 rows x 24 cols x 64 ch bf16 (33 KiB, 16-B chunks XOR-swizzled so the
-//        transposed reads are conflict-free); the kernel tile [8 strips][8 ry][16 px][16 slots]
-//        bf16 (32 KiB) is staged through the SAME bytes first: the band fragments (8 per strip)
-//        live in registers across the channel loop.  3 blocks per CU (measured 3.86 vs 4.09 ms at
-//        2; 4 blocks would need <= 128 VGPRs and spills).  A wave's two strips (rows 2k, 2k+1)
-//        share base_y, so one transposed source fragment feeds both.
-constexpr int ATH = 8, ATW = 16, ACC = 64;
+// clamp(base_x+rx), :].  Block = 8 rows x 32 cols of output pixels (4 waves x 2 rows x 2 column strips of 16),
+// all channels (looped in chunks of 64).  A 16-pixel strip's windows [base_x(x), base_x(x)+8) lie inside the 16
+// source columns o' .. o'+15, o' = x0/2 - 4, and the record's 16 circular slots (src col & 15, zero outside the
+// window -- the format's precondition) are exactly those 16 columns: per window row ry the strip's kernels ARE
+// the [16 src cols x 16 px] B operand of v_mfma_f32_16x16x16_bf16, one aligned 8-byte load per lane straight
+// from the kernel tensor, no masking.  The A operand is the transposed source row ([16 ch x 16 cols]), one
+// ds_read_b64_tr_b16 from the [pixel][channel] LDS tile.  D[ch][px] lands with 4 consecutive channels per lane.
+// The two column strips share one 11 x 24-pixel source tile -- the same tile the earlier 8 x 16-pixel block (K = 32
+// MFMAs, 24 of 32 columns used) loaded for half the outputs: source traffic through L2 13 -> 6.6 GB per 512^2 launch
+// (the kernel sits on L2 bandwidth: 22 GB moved for a 10 GB HBM floor).
+//   LDS: source tile 11 rows x 24 cols x 64 ch bf16 (33 KiB, 16-B chunks XOR-swizzled for the transposed reads)
+//        + wave-private output staging 4 x 64 px x 144 B (36 KiB): the wave's pixels leave as 16 bytes per lane,
+//        8 lanes per 128-byte pixel segment, instead of 64 separate 8-byte segments per store.
+//   The band fragments (2 rows x 2 strips x 8 window rows x 2 VGPRs) live in registers across the channel loop.
+constexpr int ATH = 8, ATW = 32, ACC = 64;
 constexpr int SROWS = 11, SCOLS = 24, SPIX = SROWS * SCOLS;                   // 264 source pixels
 constexpr int SRC_TILE_BYTES = ((SPIX + 7) / 8) * 8 * ACC * 2;                // padded to whole 1 KiB pieces
-constexpr int KC_TILE_BYTES = ATH * 8 * ATW * 32;
 constexpr int STG_PITCH = ACC * 2 + 16;                                        // output staging: bytes per pixel
-constexpr int APPLY_TILE = SRC_TILE_BYTES > KC_TILE_BYTES ? SRC_TILE_BYTES : KC_TILE_BYTES;
-constexpr int APPLY_LDS = APPLY_TILE + 4 * 2 * ATW * STG_PITCH;                // + 18 KiB: still 3 blocks per CU
+constexpr int APPLY_LDS = SRC_TILE_BYTES + 4 * 64 * STG_PITCH;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -314,13 +314,11 @@ __device__ __forceinline__ int src_swz(int pix, int chunk) {  // 16-B chunk swiz
     return chunk ^ ((((pix >> 1) & 1) << 2) | (((pix >> 3) & 1) << 1));
 }
 
-__global__ __launch_bounds__(256, 3) void jbu_apply_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ kc,
+__global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ kc,
                                                            bf16_t* __restrict__ out, int h, int w, int C, int tiles_x,
                                                            int tiles_y, int nwg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_src = smem;
-    char* s_kc = smem;  // same bytes: the kernel tile is dead once the band fragments are in registers
-    char* s_stage = smem + APPLY_TILE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int GH = 2 * h, GW = 2 * w;
@@ -329,40 +327,29 @@ __global__ __launch_bounds__(256, 3) void jbu_apply_kernel(const bf16_t* __restr
     wg /= tiles_x;
     const int ty = wg % tiles_y, b = wg / tiles_y;
     const int y0 = ty * ATH, x0 = tx * ATW;
-    const int tile_y0 = ((y0 - 4) >> 1) - 1;                 // base_y(y0)
-    const int tile_x0 = (((x0 - 4) >> 1) - 1) & ~7;          // base_x(x0) rounded down to a multiple of 8
+    const int tile_y0 = ((y0 - 4) >> 1) - 1;  // base_y(y0)
+    const int tile_x0 = (x0 >> 1) - 4;        // o' of the first strip = base_x(x0) - 1 (a multiple of 4)
 
-    // ---- stage the kernel tile: global [pixel][8 ry][16 slots] -> LDS [strip][ry][px][16 slots]
-    for (int i = tid; i < ATH * ATW * 16; i += 256) {   // one 16-byte half-row per item
-        const int half = i & 1, ry = (i >> 1) & 7, px = (i >> 4) & 15, strip = i >> 8;
-        const int gy = min(y0 + strip, GH - 1), gx = min(x0 + px, GW - 1);
-        const uint4 v = *reinterpret_cast<const uint4*>(kc + (((size_t)b * GH + gy) * GW + gx) * 128 + ry * 16 + half * 8);
-        *reinterpret_cast<uint4*>(s_kc + ((strip * 8 + ry) * ATW + px) * 32 + half * 16) = v;
-    }
-    __syncthreads();
-    // ---- band fragments: lane (px = lane&15, g = lane>>4) holds, per ry, the 8 slots of src cols
-    // tile_x0 + 8g .. +7; zero unless that chunk overlaps the pixel's window [base_x, base_x+8)
+    // ---- band fragments: lane (px = lane&15, g = lane>>4) holds, per (row si, strip cs, window row ry), the 4 slots
+    // of src cols o'(cs) + 4g .. +3, i.e. the 8-byte chunk ((o' >> 2) + g) & 3 of the record's 32-byte row ry
     const int px = lane & 15, g = lane >> 4;
-    bf16x8 band[2][8];
+    bf16x4 band[2][2][8];
 #pragma unroll
-    for (int si = 0; si < 2; ++si) {
-        const int strip = wid * 2 + si;
-        const int gx = min(x0 + px, GW - 1);
-        const int bx = ((gx - 4) >> 1) - 1;
-        const int X = tile_x0 + 8 * g;
-        const bool live = g < 3 && X > bx - 8 && X < bx + 8;
-        const int half = (X >> 3) & 1;
+    for (int si = 0; si < 2; ++si)
 #pragma unroll
-        for (int ry = 0; ry < 8; ++ry) {
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(s_kc + ((strip * 8 + ry) * ATW + px) * 32 + half * 16);
-            if (!live) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            band[si][ry] = v;
+        for (int cs = 0; cs < 2; ++cs) {
+            const int gy = min(y0 + wid * 2 + si, GH - 1), gx = min(x0 + cs * 16 + px, GW - 1);
+            const int chunk = ((tile_x0 >> 2) + 2 * cs + g) & 3;
+            const bf16_t* kp = kc + (((size_t)b * GH + gy) * GW + gx) * 128 + chunk * 4;
+#pragma unroll
+            for (int ry = 0; ry < 8; ++ry) band[si][cs][ry] = *reinterpret_cast<const bf16x4*>(kp + ry * 16);
         }
-    }
-    // ---- per-lane transposed-read geometry: 16-lane group reads 4 src cols x 16 channels
+    // ---- per-lane transposed-read geometry: a 16-lane group reads 4 src cols x 16 channels
     const int gi = lane & 15, gq = gi >> 2, gp = gi & 3;
-    const int gk = (g < 3 ? g : 2) * 8;  // group 3 multiplies a zero band: any finite data will do
     const size_t src_img = (size_t)b * h * w * C;
+    // the wave's two rows (2k, 2k+1) share base_y, hence the transposed source fragments
+    const int r0 = (((min(y0 + wid * 2, GH - 1) - 4) >> 1) - 1) - tile_y0;  // first window row inside the tile
+    char* const stg = smem + SRC_TILE_BYTES + wid * (64 * STG_PITCH);
 
     for (int c0 = 0; c0 < C; c0 += ACC) {
         __syncthreads();  // previous chunk's reads done before the tile is overwritten
@@ -375,47 +362,44 @@ __global__ __launch_bounds__(256, 3) void jbu_apply_kernel(const bf16_t* __restr
             glds16(src + src_img + ((size_t)sy * w + sx) * C + c0 + chunk * 8, s_src + piece * 1024);
         }
         __syncthreads();  // (emits vmcnt(0): the DMA has landed)
-        // the wave's two strips (output rows 2k, 2k+1) share base_y, hence the transposed source fragments
-        const int r0 = (((min(y0 + wid * 2, GH - 1) - 4) >> 1) - 1) - tile_y0;  // first window row inside the tile
-        f32x4 acc[2][4];
+        f32x4 acc[2][2][4];
 #pragma unroll
         for (int si = 0; si < 2; ++si)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[si][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[si][cs][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ry = 0; ry < 8; ++ry) {
-            const int rowpix = (r0 + ry) * SCOLS + gk;
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                const int pa = rowpix + gq, pb = rowpix + 4 + gq;
-                const int ch = cb * 2 + (gp >> 1);
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (ISP_LDS s16x4_t*)(s_src + pa * 128 + src_swz(pa, ch) * 16 + (gp & 1) * 8));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (ISP_LDS s16x4_t*)(s_src + pb * 128 + src_swz(pb, ch) * 16 + (gp & 1) * 8));
-                const bf16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, band[0][ry], acc[0][cb], 0, 0, 0);
-                acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, band[1][ry], acc[1][cb], 0, 0, 0);
+            for (int cs = 0; cs < 2; ++cs) {
+                const int pa = (r0 + ry) * SCOLS + cs * 8 + 4 * g + gq;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const int ch = cb * 2 + (gp >> 1);
+                    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (ISP_LDS s16x4_t*)(s_src + pa * 128 + src_swz(pa, ch) * 16 + (gp & 1) * 8));
+                    acc[0][cs][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, band[0][cs][ry], acc[0][cs][cb], 0, 0, 0);
+                    acc[1][cs][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, band[1][cs][ry], acc[1][cs][cb], 0, 0, 0);
+                }
             }
         }
-        // D[ch = 4*(lane>>4)+j][px = lane&15]: a lane holds 4 channels of ONE pixel, i.e. a direct store is 64 separate
-        // 8-byte segments per instruction.  The wave's 2 x 16 pixels x 64 channels go through a wave-private LDS
-        // staging tile (144-byte pixel pitch) and leave as 16 bytes per lane, 8 lanes per 128-byte pixel segment.
-        char* const stg = s_stage + wid * (2 * ATW * STG_PITCH);
+        // D[ch = 4*(lane>>4)+j][px = lane&15] -> wave-private staging [si][cs][px] x 64 ch
 #pragma unroll
         for (int si = 0; si < 2; ++si)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-                *reinterpret_cast<uint2*>(stg + (si * ATW + px) * STG_PITCH + cb * 32 + g * 8) =
-                    make_uint2(pack2bf(acc[si][cb][0], acc[si][cb][1]), pack2bf(acc[si][cb][2], acc[si][cb][3]));
+            for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    *reinterpret_cast<uint2*>(stg + ((si * 2 + cs) * 16 + px) * STG_PITCH + cb * 32 + g * 8) = make_uint2(
+                        pack2bf(acc[si][cs][cb][0], acc[si][cs][cb][1]), pack2bf(acc[si][cs][cb][2], acc[si][cs][cb][3]));
         // (written and read by the same wave: ordered by the compiler's lgkmcnt wait)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int id = j * 64 + lane, si = id >> 7, spx = (id >> 3) & 15, ck = id & 7;
-            const uint4 q = *reinterpret_cast<const uint4*>(stg + (si * ATW + spx) * STG_PITCH + ck * 16);
-            const int strip = wid * 2 + si;
-            if (y0 + strip < GH && x0 + spx < GW)
-                *reinterpret_cast<uint4*>(out + (((size_t)b * GH + y0 + strip) * GW + x0 + spx) * C + c0 + ck * 8) = q;
+        for (int j = 0; j < 8; ++j) {
+            const int id = j * 64 + lane, sp = id >> 3, ck = id & 7;  // sp = (si*2 + cs)*16 + px: 32 pixels of row si
+            const uint4 q = *reinterpret_cast<const uint4*>(stg + sp * STG_PITCH + ck * 16);
+            const int oy = y0 + wid * 2 + (sp >> 5), ox = x0 + (sp & 31);
+            if (oy < GH && ox < GW) *reinterpret_cast<uint4*>(out + (((size_t)b * GH + oy) * GW + ox) * C + c0 + ck * 8) = q;
         }
     }
 }
