@@ -114,6 +114,13 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
         *reinterpret_cast<float4*>(tile + pix * PSTRIDE + c4 * 4) =
             *reinterpret_cast<const float4*>(proj + ((size_t)b * HW + (size_t)gy * GW + gx) * KEY + c4 * 4);
     }
+    // spatial Gaussian of the 49 taps (pixel-independent): computed once per block, read back as LDS broadcasts
+    float* const s_gauss = reinterpret_cast<float*>(smem + HALOY * HALOX * PSTRIDE * 4);
+    if (threadIdx.x < TAPS) {
+        const int t = threadIdx.x;
+        const float dy = -1.f + (float)(t / DIA) * (2.f / (DIA - 1)), dx = -1.f + (float)(t % DIA) * (2.f / (DIA - 1));
+        s_gauss[t] = __expf(-(dx * dx + dy * dy) * inv2s2);
+    }
     __syncthreads();
     const int lx = threadIdx.x & (TSX - 1), ly = threadIdx.x / TSX;
     const int y = min(ty0 + ly, GH - 1), x = min(tx0 + lx, GW - 1);  // out-of-image lanes compute a clamped pixel
@@ -151,8 +158,7 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
     float sum2 = 0.f;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
-        const float dy = -1.f + (float)(t / DIA) * (2.f / (DIA - 1)), dx = -1.f + (float)(t % DIA) * (2.f / (DIA - 1));
-        k[t] = k[t] * inv * __expf(-(dx * dx + dy * dy) * inv2s2);
+        k[t] = k[t] * inv * s_gauss[t];
         sum2 += k[t];
     }
     const float inv2 = 1.f / fmaxf(sum2, 1e-7f);
@@ -238,40 +244,47 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
     __syncthreads();  // every wave has read its MLP result rows: the LDS below is free
     char* const stg = smem + (threadIdx.x >> 6) * (64 * 256);
     const int sl = threadIdx.x & 63;
-    float hrow[8][DIA];
+    // packed fp32 FMAs (v_pk_fma_f32): window rows in pairs for the row pass, circular slots in pairs for the column
+    // pass; every output element sees the same fmaf sequence as the scalar form
+    f32x2 hrow[4][DIA];
 #pragma unroll
-    for (int ry = 0; ry < 8; ++ry)
+    for (int r2 = 0; r2 < 4; ++r2)
 #pragma unroll
-        for (int tx = 0; tx < DIA; ++tx) hrow[ry][tx] = 0.f;
+        for (int tx = 0; tx < DIA; ++tx) hrow[r2][tx] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int ty = 0; ty < DIA; ++ty) {
         const float4 c0 = *reinterpret_cast<const float4*>(byp + ty * 8);
         const float4 c1 = *reinterpret_cast<const float4*>(byp + ty * 8 + 4);
-        const float by[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const f32x2 by[4] = {f32x2{c0.x, c0.y}, f32x2{c0.z, c0.w}, f32x2{c1.x, c1.y}, f32x2{c1.z, c1.w}};
 #pragma unroll
-        for (int ry = 0; ry < 8; ++ry)
+        for (int r2 = 0; r2 < 4; ++r2)
 #pragma unroll
-            for (int tx = 0; tx < DIA; ++tx) hrow[ry][tx] = fmaf(by[ry], k[ty * DIA + tx], hrow[ry][tx]);
+            for (int tx = 0; tx < DIA; ++tx) {
+                const float kv = k[ty * DIA + tx];
+                hrow[r2][tx] = __builtin_elementwise_fma(by[r2], f32x2{kv, kv}, hrow[r2][tx]);
+            }
     }
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-        float bx[DIA][8];
+        f32x2 bx[DIA][4];
 #pragma unroll
         for (int tx = 0; tx < DIA; ++tx) {
             const float4 b0 = *reinterpret_cast<const float4*>(bxp + tx * 16 + half * 8);
             const float4 b1 = *reinterpret_cast<const float4*>(bxp + tx * 16 + half * 8 + 4);
-            bx[tx][0] = b0.x, bx[tx][1] = b0.y, bx[tx][2] = b0.z, bx[tx][3] = b0.w;
-            bx[tx][4] = b1.x, bx[tx][5] = b1.y, bx[tx][6] = b1.z, bx[tx][7] = b1.w;
+            bx[tx][0] = f32x2{b0.x, b0.y}, bx[tx][1] = f32x2{b0.z, b0.w};
+            bx[tx][2] = f32x2{b1.x, b1.y}, bx[tx][3] = f32x2{b1.z, b1.w};
         }
 #pragma unroll
         for (int ry = 0; ry < 8; ++ry) {
-            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x2 r[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
-            for (int tx = 0; tx < DIA; ++tx)
+            for (int tx = 0; tx < DIA; ++tx) {
+                const float hv = hrow[ry >> 1][tx][ry & 1];
 #pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8) r[s8] = fmaf(hrow[ry][tx], bx[tx][s8], r[s8]);
+                for (int s4 = 0; s4 < 4; ++s4) r[s4] = __builtin_elementwise_fma(f32x2{hv, hv}, bx[tx][s4], r[s4]);
+            }
             *reinterpret_cast<uint4*>(stg + sl * 256 + (((ry * 2 + half) ^ (sl & 15)) << 4)) =
-                make_uint4(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]), pack2bf(r[4], r[5]), pack2bf(r[6], r[7]));
+                make_uint4(pack2bf(r[0].x, r[0].y), pack2bf(r[1].x, r[1].y), pack2bf(r[2].x, r[2].y), pack2bf(r[3].x, r[3].y));
         }
     }
     // (written and read by the same wave: ordered by the compiler's lgkmcnt wait)  The wave's 64 pixels are two
@@ -432,7 +445,7 @@ extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* k
     ISP_CHECK_ARG(B > 0 && GH >= 4 && GW >= 4 && GH % 2 == 0 && GW % 2 == 0 && B <= 65535 && sigma_spatial != 0.f);
     const float temp = fminf(fmaxf(expf(range_temp), 1e-4f), 1e4f);
     const float inv2s2 = 1.0f / (2.f * sigma_spatial * sigma_spatial);
-    const int lds = HALOY * HALOX * PSTRIDE * 4;  // 76.6 KB (>= the 64 KB the MLP staging reuses): 2 blocks per CU
+    const int lds = HALOY * HALOX * PSTRIDE * 4 + 256;  // 76.8 KB (>= the 64 KB the MLP staging reuses): 2 blocks per CU
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)jbu_kernels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
