@@ -281,6 +281,8 @@ int isp_next_points(const float* pred, const float* gt, float* points, const uns
  * (blocks x 4 waves x iters x 16 MFMAs; operands read once from a 64 Ki-element bf16 seed: zeros vs random bits show the
  * clock the chip holds) and a float4 copy of `bytes` bytes. */
 int isp_probe_mfma_bf16(const void* seed_bf16_64k, float* sink, int blocks, int iters, void* stream);
+/* same loop on v_mfma_f32_32x32x16_bf16: blocks x 4 waves x iters x 8 MFMAs of 32x32x16 */
+int isp_probe_mfma_bf16_32x32(const void* seed_bf16_64k, float* sink, int blocks, int iters, void* stream);
 int isp_probe_copy(const void* src, void* dst, long bytes, void* stream);
 
 #ifdef __cplusplus

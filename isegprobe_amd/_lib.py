@@ -59,6 +59,7 @@ SIGNATURES = {
     "isp_next_points_workspace_bytes": [_i, _i, _i],
     "isp_next_points": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "isp_probe_mfma_bf16": [_vp, _vp, _i, _i, _vp],
+    "isp_probe_mfma_bf16_32x32": [_vp, _vp, _i, _i, _vp],
     "isp_probe_copy": [_vp, _vp, _l, _vp],
     "isp_robot_click_workspace_bytes": [_i, _i],
     "isp_robot_click": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],

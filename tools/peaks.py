@@ -24,6 +24,17 @@ for name, seed in (("zeros", torch.zeros(65536, device="cuda").to(torch.bfloat16
     ms = s.elapsed_time(e) / 3
     fl = blocks * 4 * iters * 16 * 2.0 * 16 * 16 * 32
     print(f"MFMA bf16 16x16x32, {name:6s} operands: {fl / ms / 1e9:7.0f} TFLOP/s  ({ms:.1f} ms)")
+    for _ in range(2):
+        L.isp_probe_mfma_bf16_32x32(seed.data_ptr(), sink.data_ptr(), blocks, iters, st())
+    torch.cuda.synchronize()
+    s, e = ev(), ev()
+    s.record()
+    for _ in range(3):
+        L.isp_probe_mfma_bf16_32x32(seed.data_ptr(), sink.data_ptr(), blocks, iters, st())
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 3
+    fl = blocks * 4 * iters * 8 * 2.0 * 32 * 32 * 16
+    print(f"MFMA bf16 32x32x16, {name:6s} operands: {fl / ms / 1e9:7.0f} TFLOP/s  ({ms:.1f} ms)")
 n = 4 << 30
 a = torch.empty(n, dtype=torch.uint8, device="cuda").random_(0, 255)
 b = torch.empty_like(a)
