@@ -198,6 +198,15 @@ int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, con
                     float sigma_spatial, int B, int GH, int GW, void* stream);
 int isp_jbu_apply(const void* src_nhwc_bf16, const void* kc_bf16, void* out_nhwc_bf16, int B, int h, int w, int C,
                   void* stream);
+/* Last JBU stage fused with the model's bilinear (align_corners) resize to the image size
+ * (core/model/iseg_probe_model.py:120-129; FeatUp's x16 map is 16/14 of the image): isp_jbu_blend turns the stage's
+ * records [B,GH,GW,8,16] into records of the OUTPUT grid [B,OH,OW,9,16] (OH*8 == GH*7, OW*8 == GW*7), each the bilinear
+ * blend of its 2x2 stage records (9 window rows: the lower stage row's window may start one source row later);
+ * isp_jbu_apply_resized applies them to the stage's source [B,h,w,C] (GH = 2h) and writes [B,OH,OW,C] directly. */
+int isp_jbu_blend(const void* kc_bf16, void* kc9_bf16, int B, int GH, int GW, int OH, int OW, void* stream);
+int isp_jbu_apply_resized(const void* src_nhwc_bf16, const void* kc9_bf16, void* out_nhwc_bf16, int B, int h, int w, int OH,
+                          int OW, int C, void* stream);
+
 /* Adjoint of isp_jbu_apply w.r.t. the source: gsrc [B,h,w,C] = A(kc)^T gout [B,2h,2w,C] (kc depends on the guidance only).
  * What autograd does for FeatUp's JBU stage when the probe trains through it (models/sbd/dinov2/patch-embed_jbu.py). */
 int isp_jbu_apply_bwd(const void* gout_nhwc_bf16, const void* kc_bf16, void* gsrc_nhwc_bf16, int B, int h, int w, int C,

@@ -88,7 +88,8 @@ class iSegProbeModel(iSegBaseModel):
                     and isinstance(self.head, ConvSegHead) and self.head.num_layers >= 1):
                 # JBUStack ends with z = x + 0.1*conv1x1(x); that affine map commutes with the bilinear
                 # resize and folds into the head's first conv: the 2.5 TFLOP 1x1 GEMM disappears
-                hr = self.upsampler.upsampler.forward_stages(backbone_features, image)
+                # (the resize to the image size is fused into the last JBU stage when 512 -> 448-like sizes allow it)
+                hr = self.upsampler.upsampler.forward_stages(backbone_features, image, out_size=image.shape[2:])
                 if image.size()[2:] != hr.size()[2:]:
                     hr = nchw_view(ops.resize_nhwc(to_nhwc_bf16(hr), image.shape[2], image.shape[3], "bilinear"))
                 Wf, bf, alpha = self.upsampler.upsampler.fixup_affine()

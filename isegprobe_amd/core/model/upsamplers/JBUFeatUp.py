@@ -59,17 +59,34 @@ class JBULearnedRange(nn.Module):
         """Composite (bicubic-x2 o 7x7) kernels of this stage: a function of the guidance only, so the click loop
         reuses them while the image / zoom-in ROI is unchanged (_guidance_cache)."""
         P = self.packed()
+        return self._gcache.get(guidance, id(P), (GH, GW), lambda: self._build_kernels(P, guidance, GH, GW))
 
-        def build():
-            small = ops.adaptive_avg_pool(guidance, GH, GW)
-            proj = ops.jbu_range_proj(small, P["w0"], P["b0"], P["w3"], P["b3"])
-            return ops.jbu_kernels(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"])
-        return self._gcache.get(guidance, id(P), (GH, GW), build)
+    @staticmethod
+    def _build_kernels(P, guidance, GH, GW):
+        small = ops.adaptive_avg_pool(guidance, GH, GW)
+        proj = ops.jbu_range_proj(small, P["w0"], P["b0"], P["w3"], P["b3"])
+        return ops.jbu_kernels(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"])
 
     def run(self, source_nhwc, guidance):
         # composite kernels on the low-res grid, applied by MFMA: no x2 map in HBM
         kc = self.kernels(guidance, source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2)
         return ops.jbu_apply(source_nhwc, kc)
+
+    @staticmethod
+    def resize_fusable(GH, GW, OH, OW):
+        """The stage's x2 map (GH x GW) resized to OH x OW can be produced in one pass when 8 stage rows / columns map
+        onto exactly 7 output ones (FeatUp's x16 map vs. a patch-14 image: 512 -> 448)."""
+        return GH % 8 == 0 and GW % 8 == 0 and OH * 8 == GH * 7 and OW * 8 == GW * 7
+
+    def run_resized(self, source_nhwc, guidance, OH, OW):
+        """resize_bilinear(run(source), OH, OW) as one operator: the stage's kernel records are blended onto the output
+        grid (guidance-only, cached with them) and applied to the source directly (isp_jbu_apply_resized)."""
+        GH, GW = source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2
+        P = self.packed()
+        # (only the blended records are kept across clicks; the stage's own records are transient)
+        kc9 = self._gcache.get(guidance, id(P), (GH, GW, OH, OW),
+                               lambda: ops.jbu_blend(self._build_kernels(P, guidance, GH, GW), OH, OW))
+        return ops.jbu_apply_resized(source_nhwc, kc9)
 
 
 class JBUStack(nn.Module):
@@ -82,14 +99,19 @@ class JBUStack(nn.Module):
         self.fixup_proj = nn.Sequential(nn.Dropout2d(0.2), nn.Conv2d(feat_dim, feat_dim, kernel_size=1))
         self._packed = PackedCache()
 
-    def forward_stages(self, source, guidance):
+    def forward_stages(self, source, guidance, out_size=None):
         """The four x2 stages WITHOUT the final fix-up  x + 0.1*conv1x1(x).  The fix-up is a per-pixel
-        affine map; iSegProbeModel folds it (through the linear resize) into the seg head's first conv."""
+        affine map; iSegProbeModel folds it (through the linear resize) into the seg head's first conv.
+        With ``out_size`` the model's bilinear resize to the image size (iseg_probe_model.py:120-129) is fused into the
+        last stage when the sizes allow it (otherwise the caller resizes as before)."""
         x = to_nhwc_bf16(source)
         guidance = guidance.float().contiguous()
-        for up in (self.up1, self.up2, self.up3, self.up4):
+        for up in (self.up1, self.up2, self.up3):
             x = up.run(x, guidance)
-        return nchw_view(x)
+        GH, GW = x.shape[1] * 2, x.shape[2] * 2
+        if out_size is not None and JBULearnedRange.resize_fusable(GH, GW, int(out_size[0]), int(out_size[1])):
+            return nchw_view(self.up4.run_resized(x, guidance, int(out_size[0]), int(out_size[1])))
+        return nchw_view(self.up4.run(x, guidance))
 
     def fixup_affine(self):
         """(W [C,C], b [C], alpha): z = x + alpha * (W x + b)."""

@@ -323,9 +323,11 @@ constexpr int APPLY_LDS = SRC_TILE_BYTES + 4 * 64 * STG_PITCH;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
-__device__ __forceinline__ int src_swz(int pix, int chunk) {  // 16-B chunk swizzle of the source tile
-    return chunk ^ ((((pix >> 1) & 1) << 2) | (((pix >> 3) & 1) << 1));
-}
+// 16-B chunk swizzle of the source tile by the pixel's COLUMN in the tile: a transposed read touches 16 consecutive
+// columns x 32 B, which (column parity = bank half, (col >> 1) & 3 = which 32-byte quarter) spread over all banks twice
+// -- the minimum for 512 bytes -- and a fragment address becomes lane constant + row * pitch (an immediate).
+__device__ __forceinline__ int src_swz(int col, int chunk) { return chunk ^ (((col >> 1) & 3) << 1); }
+constexpr int SROWB = 24 * 128;  // bytes per source-tile row
 
 __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ kc,
                                                            bf16_t* __restrict__ out, int h, int w, int C, int tiles_x,
@@ -357,8 +359,17 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restr
 #pragma unroll
             for (int ry = 0; ry < 8; ++ry) band[si][cs][ry] = *reinterpret_cast<const bf16x4*>(kp + ry * 16);
         }
-    // ---- per-lane transposed-read geometry: a 16-lane group reads 4 src cols x 16 channels
+    // ---- per-lane transposed-read geometry: a 16-lane group reads 4 src cols x 16 channels; fb = byte offset of the
+    // lane's fragment piece inside a tile row, per (strip, 16-channel block)
     const int gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+    int fb[2][4];
+#pragma unroll
+    for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int col = cs * 8 + 4 * g + gq;
+            fb[cs][cb] = col * 128 + src_swz(col, cb * 2 + (gp >> 1)) * 16 + (gp & 1) * 8;
+        }
     const size_t src_img = (size_t)b * h * w * C;
     // the wave's two rows (2k, 2k+1) share base_y, hence the transposed source fragments
     const int r0 = (((min(y0 + wid * 2, GH - 1) - 4) >> 1) - 1) - tile_y0;  // first window row inside the tile
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restr
             const int pix = piece * 8 + (lane >> 3);
             const int pr = pix / SCOLS, pc = pix - pr * SCOLS;
             const int sy = min(max(tile_y0 + pr, 0), h - 1), sx = min(max(tile_x0 + pc, 0), w - 1);
-            const int chunk = src_swz(pix, lane & 7);
+            const int chunk = src_swz(pc, lane & 7);
             glds16(src + src_img + ((size_t)sy * w + sx) * C + c0 + chunk * 8, s_src + piece * 1024);
         }
         __syncthreads();  // (emits vmcnt(0): the DMA has landed)
@@ -382,16 +393,15 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restr
             for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) acc[si][cs][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* const rbase = s_src + r0 * SROWB;
 #pragma unroll
         for (int ry = 0; ry < 8; ++ry) {
 #pragma unroll
             for (int cs = 0; cs < 2; ++cs) {
-                const int pa = (r0 + ry) * SCOLS + cs * 8 + 4 * g + gq;
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
-                    const int ch = cb * 2 + (gp >> 1);
                     const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (ISP_LDS s16x4_t*)(s_src + pa * 128 + src_swz(pa, ch) * 16 + (gp & 1) * 8));
+                        (ISP_LDS s16x4_t*)(rbase + fb[cs][cb] + ry * SROWB));
                     acc[0][cs][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, band[0][cs][ry], acc[0][cs][cb], 0, 0, 0);
                     acc[1][cs][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, band[1][cs][ry], acc[1][cs][cb], 0, 0, 0);
                 }
@@ -413,6 +423,166 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restr
             const uint4 q = *reinterpret_cast<const uint4*>(stg + sp * STG_PITCH + ck * 16);
             const int oy = y0 + wid * 2 + (sp >> 5), ox = x0 + (sp & 31);
             if (oy < GH && ox < GW) *reinterpret_cast<uint4*>(out + (((size_t)b * GH + oy) * GW + ox) * C + c0 + ck * 8) = q;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// The last JBU stage followed by the model's bilinear resize to the image size (iseg_probe_model.py:120-129), as ONE
+// linear operator on the low-res source.  FeatUp's x16 output is 16/14 of the image size (512 vs 448): an output
+// pixel blends the 2x2 stage pixels (y0|y1, x0|x1) with the bilinear weights, so its composite kernel is the same
+// blend of their records -- the circular column slots are absolute source columns, so columns just add; the rows
+// of y1 sit one window row lower when base_y(y1) = base_y(y0) + 1, which makes the blended window 9 rows.
+// Because 8 stage rows map onto exactly 7 output rows (src = dst * (8m-1)/(7m-1) never leaves the 8-row group, nor
+// the 16-column group of a 14-pixel strip), the apply below runs on the very same source tiles as jbu_apply_kernel
+// and writes the resized map directly: the stage's 512^2 map (6.4 GB at batch 32) and the 2.3 ms resize pass disappear.
+
+// blended records [B, OH, OW, 9, 16] bf16 from stage records [B, GH, GW, 8, 16]; a thread owns 8 slots of one row
+__global__ __launch_bounds__(256) void jbu_blend_kernel(const bf16_t* __restrict__ kc, bf16_t* __restrict__ kout, int GH, int GW,
+                                                        int OH, int OW, float sy, float sx, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int half = (int)(idx & 1), r = (int)((idx >> 1) % 9);
+    long pix = idx / 18;
+    const int X = (int)(pix % OW);
+    pix /= OW;
+    const int Y = (int)(pix % OH);
+    const int b = (int)(pix / OH);
+    const float fy = sy * (float)Y, fx = sx * (float)X;  // the resize kernel's arithmetic (bilinear_nhwc_kernel)
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, GH - 1), x1 = min(x0 + 1, GW - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const int by0 = ((y0 - 4) >> 1) - 1;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int yy = dy ? y1 : y0;
+        const float wy = dy ? ly : 1.f - ly;
+        const int ry = r - ((((yy - 4) >> 1) - 1) - by0);
+        if (ry < 0 || ry > 7) continue;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int xx = dx ? x1 : x0;
+            const float wgt = wy * (dx ? lx : 1.f - lx);
+            const uint4 v = *reinterpret_cast<const uint4*>(kc + (((size_t)b * GH + yy) * GW + xx) * 128 + ry * 16 + half * 8);
+            const unsigned* q = &v.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] = fmaf(wgt, __uint_as_float(q[e] << 16), acc[2 * e]);
+                acc[2 * e + 1] = fmaf(wgt, __uint_as_float(q[e] & 0xffff0000u), acc[2 * e + 1]);
+            }
+        }
+    }
+    *reinterpret_cast<uint4*>(kout + (((size_t)b * OH + Y) * OW + X) * 144 + r * 16 + half * 8) =
+        make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+}
+
+// Block = 7 rows x 28 cols of OUTPUT pixels (the 8 x 32 stage tile of jbu_apply_kernel), 4 waves x 2 rows x 2 strips
+// of 14 pixels (MFMA columns 14, 15 idle), 9 window rows.  Same source tile, same operand forms as above.
+constexpr int RTH = 7, RTW = 28, RSTRIP = 14;
+// 12 staged source rows: window row 8 of the tile's last output rows lies one row past the 11 the stage needs (it only
+// ever meets zero weights, but must hold finite values)
+constexpr int RSROWS = 12, RSPIX = RSROWS * SCOLS, RSRC_BYTES = ((RSPIX + 7) / 8) * 8 * ACC * 2;
+constexpr int RAPPLY_LDS = RSRC_BYTES + 4 * 64 * STG_PITCH;
+
+__global__ __launch_bounds__(256, 2) void jbu_apply_resized_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ kc9,
+                                                                   bf16_t* __restrict__ out, int h, int w, int OH, int OW,
+                                                                   int C, float sy, int tiles_x, int tiles_y, int nwg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_src = smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wg = xcd_remap(blockIdx.x, nwg);
+    const int tx = wg % tiles_x;
+    wg /= tiles_x;
+    const int ty = wg % tiles_y, b = wg / tiles_y;
+    const int tile_y0 = ((ty * 8 - 4) >> 1) - 1;  // base_y of the stage tile's first row
+    const int tile_x0 = tx * 16 - 4;              // o' of the first strip
+
+    const int px = lane & 15, g = lane >> 4;
+    bf16x4 band[2][2][9];
+    int r0[2];
+#pragma unroll
+    for (int si = 0; si < 2; ++si) {
+        const int orow = wid * 2 + si, oy = min(ty * RTH + orow, OH - 1);
+        const int sy0 = (int)(sy * (float)oy);  // stage row y0 of this output row (jbu_blend_kernel's arithmetic)
+        r0[si] = ((((sy0 - 4) >> 1) - 1)) - tile_y0;
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs) {
+            const int ox = min(tx * RTW + cs * RSTRIP + px, OW - 1);
+            const bool live = orow < RTH && px < RSTRIP;
+            const int chunk = ((tile_x0 >> 2) + 2 * cs + g) & 3;
+            const bf16_t* kp = kc9 + (((size_t)b * OH + oy) * OW + ox) * 144 + chunk * 4;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                bf16x4 v = *reinterpret_cast<const bf16x4*>(kp + r * 16);
+                if (!live) v = bf16x4{0, 0, 0, 0};
+                band[si][cs][r] = v;
+            }
+        }
+    }
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+    int fb[2][4];
+#pragma unroll
+    for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int col = cs * 8 + 4 * g + gq;
+            fb[cs][cb] = col * 128 + src_swz(col, cb * 2 + (gp >> 1)) * 16 + (gp & 1) * 8;
+        }
+    const size_t src_img = (size_t)b * h * w * C;
+    char* const stg = smem + RSRC_BYTES + wid * (64 * STG_PITCH);
+
+    for (int c0 = 0; c0 < C; c0 += ACC) {
+        __syncthreads();
+        for (int piece = wid; piece < (RSPIX + 7) / 8; piece += 4) {
+            const int pix = piece * 8 + (lane >> 3);
+            const int pr = pix / SCOLS, pc = pix - pr * SCOLS;
+            const int syy = min(max(tile_y0 + pr, 0), h - 1), sxx = min(max(tile_x0 + pc, 0), w - 1);
+            const int chunk = src_swz(pc, lane & 7);
+            glds16(src + src_img + ((size_t)syy * w + sxx) * C + c0 + chunk * 8, s_src + piece * 1024);
+        }
+        __syncthreads();
+        f32x4 acc[2][2][4];
+#pragma unroll
+        for (int si = 0; si < 2; ++si)
+#pragma unroll
+            for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[si][cs][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                const char* const rbase = s_src + r0[si] * SROWB;
+#pragma unroll
+                for (int cs = 0; cs < 2; ++cs) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (ISP_LDS s16x4_t*)(rbase + fb[cs][cb] + r * SROWB));
+                        acc[si][cs][cb] =
+                            __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, band[si][cs][r], acc[si][cs][cb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int si = 0; si < 2; ++si)
+#pragma unroll
+            for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    *reinterpret_cast<uint2*>(stg + ((si * 2 + cs) * 16 + px) * STG_PITCH + cb * 32 + g * 8) = make_uint2(
+                        pack2bf(acc[si][cs][cb][0], acc[si][cs][cb][1]), pack2bf(acc[si][cs][cb][2], acc[si][cs][cb][3]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int id = j * 64 + lane, sp = id >> 3, ck = id & 7;  // sp = (si*2 + cs)*16 + px
+            const uint4 q = *reinterpret_cast<const uint4*>(stg + sp * STG_PITCH + ck * 16);
+            const int orow = wid * 2 + (sp >> 5), spx = sp & 15;
+            const int oy = ty * RTH + orow, ox = tx * RTW + ((sp >> 4) & 1) * RSTRIP + spx;
+            if (orow < RTH && spx < RSTRIP && oy < OH && ox < OW)
+                *reinterpret_cast<uint4*>(out + (((size_t)b * OH + oy) * OW + ox) * C + c0 + ck * 8) = q;
         }
     }
 }
@@ -457,6 +627,38 @@ extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* k
     jbu_kernels_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
                                                                 fix0_b, (const bf16_t*)fix3_w, fix3_b, bys, bxs, temp,
                                                                 inv2s2, GH, GW);
+    return isp_launch_status();
+}
+
+extern "C" int isp_jbu_blend(const void* kc_bf16, void* kc9_bf16, int B, int GH, int GW, int OH, int OW, void* stream) {
+    ISP_CHECK_ARG(kc_bf16 && kc9_bf16 && B > 0 && GH >= 8 && GW >= 8 && OH > 1 && OW > 1);
+    // 8 stage rows / 16 stage columns per 7 / 14 output pixels: the blended window must stay inside the stage tile
+    ISP_CHECK_ARG(GH % 8 == 0 && GW % 8 == 0 && (long)OH * 8 == (long)GH * 7 && (long)OW * 8 == (long)GW * 7);
+    const long total = (long)B * OH * OW * 18;
+    const float sy = (float)(GH - 1) / (float)(OH - 1), sx = (float)(GW - 1) / (float)(OW - 1);
+    jbu_blend_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>((const bf16_t*)kc_bf16, (bf16_t*)kc9_bf16,
+                                                                                      GH, GW, OH, OW, sy, sx, total);
+    return isp_launch_status();
+}
+
+extern "C" int isp_jbu_apply_resized(const void* src_nhwc_bf16, const void* kc9_bf16, void* out_nhwc_bf16, int B, int h, int w,
+                                     int OH, int OW, int C, void* stream) {
+    ISP_CHECK_ARG(src_nhwc_bf16 && kc9_bf16 && out_nhwc_bf16 && B > 0 && h >= 4 && w >= 4 && C > 0 && C % ACC == 0);
+    ISP_CHECK_ARG((2 * h) % 8 == 0 && (2 * w) % 8 == 0 && (long)OH * 8 == (long)(2 * h) * 7 && (long)OW * 8 == (long)(2 * w) * 7);
+    const int tiles_x = (OW + RTW - 1) / RTW, tiles_y = (OH + RTH - 1) / RTH;
+    const long nwg = (long)tiles_x * tiles_y * B;
+    ISP_CHECK_ARG(nwg <= 0x7fffffffL);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)jbu_apply_resized_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RAPPLY_LDS) !=
+            hipSuccess)
+            return ISP_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const float sy = (float)(2 * h - 1) / (float)(OH - 1);
+    jbu_apply_resized_kernel<<<(unsigned)nwg, 256, RAPPLY_LDS, (hipStream_t)stream>>>(
+        (const bf16_t*)src_nhwc_bf16, (const bf16_t*)kc9_bf16, (bf16_t*)out_nhwc_bf16, h, w, OH, OW, C, sy, tiles_x, tiles_y,
+        (int)nwg);
     return isp_launch_status();
 }
 

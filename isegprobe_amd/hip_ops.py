@@ -554,6 +554,26 @@ def jbu_apply(src, kc):
     return out
 
 
+def jbu_blend(kc, OH, OW):
+    """Stage records [B,GH,GW,8,16] -> records of the bilinearly resized grid [B,OH,OW,9,16] (OH*8 == GH*7)."""
+    _need(kc, BF16, "kc")
+    B, GH, GW = kc.shape[:3]
+    out = torch.empty(B, OH, OW, 9, 16, device=kc.device, dtype=BF16)
+    check(_lib.lib().isp_jbu_blend(_p(kc), _p(out), B, GH, GW, OH, OW, _stream()), "isp_jbu_blend")
+    return out
+
+
+def jbu_apply_resized(src, kc9):
+    """src [B,h,w,C] bf16 NHWC, kc9 [B,OH,OW,9,16] bf16 (jbu_blend) -> [B,OH,OW,C] bf16 = resize(jbu_apply(src, kc))."""
+    _need(src, BF16, "src")
+    _need(kc9, BF16, "kc9")
+    B, h, w, C = src.shape
+    OH, OW = kc9.shape[1:3]
+    out = torch.empty(B, OH, OW, C, device=src.device, dtype=BF16)
+    check(_lib.lib().isp_jbu_apply_resized(_p(src), _p(kc9), _p(out), B, h, w, OH, OW, C, _stream()), "isp_jbu_apply_resized")
+    return out
+
+
 def jbu_apply_bwd(gout, kc):
     """Adjoint of jbu_apply w.r.t. src: gout [B,2h,2w,C] bf16, kc [B,2h,2w,8,16] bf16 -> [B,h,w,C] bf16."""
     _need(gout, BF16, "gout")

@@ -72,6 +72,47 @@ def test_jbu_stages_and_stack_vs_oracle():
     assert err.pow(2).mean().sqrt().item() < 5e-3 * max(1.0, ref.pow(2).mean().sqrt().item())
 
 
+@pytest.mark.parametrize("h,w", [(4, 8), (8, 4), (16, 16)])
+def test_jbu_last_stage_fused_with_resize(h, w):
+    """JBUStack.forward_stages(out_size=image size): the last x2 stage and the model's bilinear resize as ONE operator
+    (isp_jbu_blend + isp_jbu_apply_resized) against stage -> isp_resize (both bf16 paths) and against the fp32 oracle
+    stack followed by F.interpolate; sizes whose ratio is not 8:7 fall back to the separate resize."""
+    import torch.nn.functional as F
+    from isegprobe_amd import hip_ops as ops
+    from isegprobe_amd.core.model.upsamplers import JBUFeatUpUpsampler
+    from isegprobe_amd.core.model.upsamplers.JBUFeatUp import JBULearnedRange
+    from isegprobe_amd.core.model._tensor import nchw_view, to_nhwc_bf16
+    from oracle import upsamplers as oups
+    torch.manual_seed(h * 31 + w)
+    C = 64
+    up = JBUFeatUpUpsampler("dinov2", feat_dim=C)
+    seeded_(up, 5)
+    w_sd = {k: v.clone() for k, v in up.state_dict().items()}
+    H, W = 14 * h, 14 * w                      # patch-14 image of an h x w token grid; FeatUp's map is 16h x 16w
+    src, gd = torch.randn(2, C, h, w), torch.randn(2, 3, H, W)
+    stack = up.cuda().upsampler
+    assert JBULearnedRange.resize_fusable(16 * h, 16 * w, H, W) and not JBULearnedRange.resize_fusable(16 * h, 16 * w, H - 1, W)
+    fused = _f32(stack.forward_stages(src.cuda(), gd.cuda(), out_size=(H, W)))
+    assert tuple(fused.shape) == (2, C, H, W)
+    plain = stack.forward_stages(src.cuda(), gd.cuda())
+    assert tuple(plain.shape) == (2, C, 16 * h, 16 * w)
+    two_pass = _f32(nchw_view(ops.resize_nhwc(to_nhwc_bf16(plain), H, W, "bilinear")))
+    rms = two_pass.pow(2).mean().sqrt().item()
+    d = (fused - two_pass).abs()
+    assert d.max().item() < 4e-2 * max(1.0, two_pass.abs().max().item()) and d.pow(2).mean().sqrt().item() < 4e-3 * max(1.0, rms)
+    # fp32 oracle: the stack without its final fix-up is not exposed, so compare through the (linear) fix-up
+    ref = F.interpolate(oups.jbu_stack(src, gd, w_sd, "upsampler."), (H, W), mode="bilinear", align_corners=True)
+    conv = stack.fixup_proj[1]
+    fx = fused.cuda()
+    full = (fx + 0.1 * F.conv2d(fx, conv.weight.float(), conv.bias.float())).cpu()
+    err = (full - ref).abs()
+    assert err.max().item() < 3e-2 * max(1.0, ref.abs().max().item())
+    assert err.pow(2).mean().sqrt().item() < 5e-3 * max(1.0, ref.pow(2).mean().sqrt().item())
+    # a size that is not 7/8 of the map: forward_stages leaves the resize to the caller
+    other = stack.forward_stages(src.cuda(), gd.cuda(), out_size=(H - 2, W))
+    assert tuple(other.shape) == (2, C, 16 * h, 16 * w)
+
+
 def test_attention_hd256():
     """head_dim 197 zero-padded to 256: LoftUp(n_dim=768)'s cross-attention (BASELINE configs[4])."""
     from isegprobe_amd import hip_ops as ops
