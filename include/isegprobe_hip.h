@@ -204,6 +204,10 @@ int isp_jbu_apply(const void* src_nhwc_bf16, const void* kc_bf16, void* out_nhwc
  * blend of its 2x2 stage records (9 window rows: the lower stage row's window may start one source row later);
  * isp_jbu_apply_resized applies them to the stage's source [B,h,w,C] (GH = 2h) and writes [B,OH,OW,C] directly. */
 int isp_jbu_blend(const void* kc_bf16, void* kc9_bf16, int B, int GH, int GW, int OH, int OW, void* stream);
+/* isp_jbu_kernels followed by isp_jbu_blend in one launch: the stage's own records are never stored */
+int isp_jbu_kernels_resized(const float* proj, const float* guidance, void* kc9_bf16, const void* fix0_w, const float* fix0_b,
+                            const void* fix3_w, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
+                            float sigma_spatial, int B, int GH, int GW, int OH, int OW, void* stream);
 int isp_jbu_apply_resized(const void* src_nhwc_bf16, const void* kc9_bf16, void* out_nhwc_bf16, int B, int h, int w, int OH,
                           int OW, int C, void* stream);
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     "isp_jbu_apply": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "isp_jbu_apply_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "isp_jbu_blend": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "isp_jbu_kernels_resized": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _vp],
     "isp_jbu_apply_resized": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_fuse_flip_sigmoid": [_vp, _vp, _l, _i, _i, _i, _vp],
     "isp_minmax_nchw_f32": [_vp, _vp, _vp, _i, _i, _l, _vp],

@@ -83,9 +83,11 @@ class JBULearnedRange(nn.Module):
         grid (guidance-only, cached with them) and applied to the source directly (isp_jbu_apply_resized)."""
         GH, GW = source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2
         P = self.packed()
-        # (only the blended records are kept across clicks; the stage's own records are transient)
-        kc9 = self._gcache.get(guidance, id(P), (GH, GW, OH, OW),
-                               lambda: ops.jbu_blend(self._build_kernels(P, guidance, GH, GW), OH, OW))
+        def build():  # the stage's own records are never stored: the kernel blends them on the way out
+            small = ops.adaptive_avg_pool(guidance, GH, GW)
+            proj = ops.jbu_range_proj(small, P["w0"], P["b0"], P["w3"], P["b3"])
+            return ops.jbu_kernels_resized(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"], OH, OW)
+        kc9 = self._gcache.get(guidance, id(P), (GH, GW, OH, OW), build)
         return ops.jbu_apply_resized(source_nhwc, kc9)
 
 

@@ -96,12 +96,16 @@ constexpr int TSX = 32, TSY = 8, HALOX = TSX + 2 * R, HALOY = TSY + 2 * R, PSTRI
 // 64w..64w+63 end to end, so only wave-local LDS ordering is involved after the one barrier.
 __device__ __forceinline__ int mlp_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// BLEND: the block's 32 x 8 records are not stored; the 28 x 7 records of the bilinearly resized grid that depend on
+// them (and on them only, see jbu_blend_kernel below) are blended from the staged records and stored instead
+// ([B, OH, OW, 9, 16]): the stage's own 256-byte records (2.1 GB at 512^2 x 32) never reach HBM.
+template <bool BLEND>
 __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restrict__ proj, const float* __restrict__ G,
                                                            bf16_t* __restrict__ kout, const bf16_t* __restrict__ f0w,
                                                            const float* __restrict__ f0b, const bf16_t* __restrict__ f3w,
                                                            const float* __restrict__ f3b, const float* __restrict__ bys,
                                                            const float* __restrict__ bxs, float temp, float inv2s2,
-                                                           int GH, int GW) {
+                                                           int GH, int GW, int OH, int OW, float rsy, float rsx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* tile = reinterpret_cast<float*>(smem);
     const int b = blockIdx.z, ty0 = blockIdx.y * TSY, tx0 = blockIdx.x * TSX;
@@ -287,15 +291,58 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
                 make_uint4(pack2bf(r[0].x, r[0].y), pack2bf(r[1].x, r[1].y), pack2bf(r[2].x, r[2].y), pack2bf(r[3].x, r[3].y));
         }
     }
-    // (written and read by the same wave: ordered by the compiler's lgkmcnt wait)  The wave's 64 pixels are two
-    // runs of 32 consecutive pixels (tile rows ly = 2w, 2w+1).
+    if constexpr (!BLEND) {
+        // (written and read by the same wave: ordered by the compiler's lgkmcnt wait)  The wave's 64 pixels are two
+        // runs of 32 consecutive pixels (tile rows ly = 2w, 2w+1).
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int id = j * 64 + sl, spx = id >> 4, ck = id & 15;
-        const uint4 q = *reinterpret_cast<const uint4*>(stg + spx * 256 + ((ck ^ (spx & 15)) << 4));
-        const int gy = ty0 + (threadIdx.x >> 6) * 2 + (spx >> 5), gx = tx0 + (spx & 31);
-        if (gy < GH && gx < GW)
-            *reinterpret_cast<uint4*>(kout + ((size_t)b * HW + (size_t)gy * GW + gx) * 128 + ck * 8) = q;
+        for (int j = 0; j < 16; ++j) {
+            const int id = j * 64 + sl, spx = id >> 4, ck = id & 15;
+            const uint4 q = *reinterpret_cast<const uint4*>(stg + spx * 256 + ((ck ^ (spx & 15)) << 4));
+            const int gy = ty0 + (threadIdx.x >> 6) * 2 + (spx >> 5), gx = tx0 + (spx & 31);
+            if (gy < GH && gx < GW)
+                *reinterpret_cast<uint4*>(kout + ((size_t)b * HW + (size_t)gy * GW + gx) * 128 + ck * 8) = q;
+        }
+    } else {
+        __syncthreads();  // all 256 records staged
+        // record of tile pixel (ly, lx), chunk c (= window row * 2 + half): wave ly/2, slot (ly & 1) * 32 + lx
+        auto rec = [&](int rly, int rlx, int c) {
+            const int s2 = (rly & 1) * 32 + rlx;
+            return *reinterpret_cast<const uint4*>(smem + (rly >> 1) * (64 * 256) + s2 * 256 + ((c ^ (s2 & 15)) << 4));
+        };
+        const int oy0 = blockIdx.y * 7, ox0 = blockIdx.x * 28;
+        for (int i = threadIdx.x; i < 7 * 28 * 18; i += 256) {  // item = 8 slots of one window row of one output pixel
+            const int half = i & 1, r = (i >> 1) % 9, op = i / 18;
+            const int Y = oy0 + op / 28, X = ox0 + op % 28;
+            if (Y >= OH || X >= OW) continue;
+            const float fy = rsy * (float)Y, fx = rsx * (float)X;  // bilinear_nhwc_kernel's arithmetic
+            const int y0 = (int)fy, x0 = (int)fx;
+            // (y0 + 1, x0 + 1 leave the tile only where they also leave the image: 8 rows <-> 7 rows)
+            const int y1 = min(min(y0 + 1, GH - 1), ty0 + TSY - 1), x1 = min(min(x0 + 1, GW - 1), tx0 + TSX - 1);
+            const float wy1 = fy - (float)y0, wx1 = fx - (float)x0;
+            const int by0 = ((y0 - 4) >> 1) - 1;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int yy = dy ? y1 : y0;
+                const float wy = dy ? wy1 : 1.f - wy1;
+                const int ry = r - ((((yy - 4) >> 1) - 1) - by0);
+                if (ry < 0 || ry > 7) continue;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int xx = dx ? x1 : x0;
+                    const float wgt = wy * (dx ? wx1 : 1.f - wx1);
+                    const uint4 v = rec(yy - ty0, xx - tx0, ry * 2 + half);
+                    const unsigned* q = &v.x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 * e] = fmaf(wgt, __uint_as_float(q[e] << 16), acc[2 * e]);
+                        acc[2 * e + 1] = fmaf(wgt, __uint_as_float(q[e] & 0xffff0000u), acc[2 * e + 1]);
+                    }
+                }
+            }
+            *reinterpret_cast<uint4*>(kout + (((size_t)b * OH + Y) * OW + X) * 144 + r * 16 + half * 8) =
+                make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+        }
     }
 }
 
@@ -607,10 +654,9 @@ extern "C" int isp_jbu_range_proj(const float* guidance, float* proj, const floa
     return isp_launch_status();
 }
 
-extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const void* fix0_w,
-                               const float* fix0_b, const void* fix3_w, const float* fix3_b, const float* bys,
-                               const float* bxs, float range_temp, float sigma_spatial, int B, int GH, int GW,
-                               void* stream) {
+static int launch_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const void* fix0_w, const float* fix0_b,
+                              const void* fix3_w, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
+                              float sigma_spatial, int B, int GH, int GW, int OH, int OW, void* stream) {
     ISP_CHECK_ARG(proj && guidance && kc_bf16 && fix0_w && fix0_b && fix3_w && fix3_b && bys && bxs);
     ISP_CHECK_ARG(B > 0 && GH >= 4 && GW >= 4 && GH % 2 == 0 && GW % 2 == 0 && B <= 65535 && sigma_spatial != 0.f);
     const float temp = fminf(fmaxf(expf(range_temp), 1e-4f), 1e4f);
@@ -618,16 +664,43 @@ extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* k
     const int lds = HALOY * HALOX * PSTRIDE * 4 + 256;  // 76.8 KB (>= the 64 KB the MLP staging reuses): 2 blocks per CU
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)jbu_kernels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess)
+        if (hipFuncSetAttribute((const void*)jbu_kernels_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void*)jbu_kernels_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+                hipSuccess)
             return ISP_ERR_LAUNCH;
         attr_done = true;
     }
     dim3 grid((GW + TSX - 1) / TSX, (GH + TSY - 1) / TSY, B);
-    jbu_kernels_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
-                                                                fix0_b, (const bf16_t*)fix3_w, fix3_b, bys, bxs, temp,
-                                                                inv2s2, GH, GW);
+    if (OH > 0) {
+        const float rsy = (float)(GH - 1) / (float)(OH - 1), rsx = (float)(GW - 1) / (float)(OW - 1);
+        jbu_kernels_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
+                                                                          fix0_b, (const bf16_t*)fix3_w, fix3_b, bys, bxs, temp,
+                                                                          inv2s2, GH, GW, OH, OW, rsy, rsx);
+    } else {
+        jbu_kernels_kernel<false><<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
+                                                                           fix0_b, (const bf16_t*)fix3_w, fix3_b, bys, bxs, temp,
+                                                                           inv2s2, GH, GW, 0, 0, 0.f, 0.f);
+    }
     return isp_launch_status();
+}
+
+extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const void* fix0_w,
+                               const float* fix0_b, const void* fix3_w, const float* fix3_b, const float* bys,
+                               const float* bxs, float range_temp, float sigma_spatial, int B, int GH, int GW,
+                               void* stream) {
+    return launch_jbu_kernels(proj, guidance, kc_bf16, fix0_w, fix0_b, fix3_w, fix3_b, bys, bxs, range_temp, sigma_spatial, B,
+                              GH, GW, 0, 0, stream);
+}
+
+extern "C" int isp_jbu_kernels_resized(const float* proj, const float* guidance, void* kc9_bf16, const void* fix0_w,
+                                       const float* fix0_b, const void* fix3_w, const float* fix3_b, const float* bys,
+                                       const float* bxs, float range_temp, float sigma_spatial, int B, int GH, int GW, int OH,
+                                       int OW, void* stream) {
+    ISP_CHECK_ARG(GH >= 8 && GW >= 8 && OH > 1 && OW > 1 && GH % 8 == 0 && GW % 8 == 0);
+    ISP_CHECK_ARG((long)OH * 8 == (long)GH * 7 && (long)OW * 8 == (long)GW * 7);
+    return launch_jbu_kernels(proj, guidance, kc9_bf16, fix0_w, fix0_b, fix3_w, fix3_b, bys, bxs, range_temp, sigma_spatial, B,
+                              GH, GW, OH, OW, stream);
 }
 
 extern "C" int isp_jbu_blend(const void* kc_bf16, void* kc9_bf16, int B, int GH, int GW, int OH, int OW, void* stream) {

@@ -544,6 +544,18 @@ def jbu_kernels(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial):
     return kc
 
 
+def jbu_kernels_resized(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial, OH, OW):
+    """jbu_blend(jbu_kernels(...), OH, OW) in one launch -> kc9 [B,OH,OW,9,16] bf16."""
+    B, GH, GW, _ = proj.shape
+    bys = jbu_tables(GH, proj.device)[0]
+    bxs = jbu_tables(GW, proj.device)[1]
+    kc9 = torch.empty(B, OH, OW, 9, 16, device=proj.device, dtype=BF16)
+    check(_lib.lib().isp_jbu_kernels_resized(_p(proj), _p(g), _p(kc9), _p(f0w), _p(f0b), _p(f3w), _p(f3b), _p(bys), _p(bxs),
+                                             float(range_temp), float(sigma_spatial), B, GH, GW, OH, OW, _stream()),
+          "isp_jbu_kernels_resized")
+    return kc9
+
+
 def jbu_apply(src, kc):
     """src [B,h,w,C] bf16 NHWC, kc [B,2h,2w,8,16] bf16 -> [B,2h,2w,C] bf16."""
     _need(src, BF16, "src")
