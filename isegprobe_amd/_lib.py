@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "libisegprobe_hip.so")  # env override: kernel A/B experiments
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ISP_F32, ISP_BF16 = 0, 1
 EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16, EP_BIAS_QGELU_SAVE_BF16, EP_MUL_DQGELU_BF16 = range(14)
