@@ -6,7 +6,7 @@
 
 One "step" = one forward pass of the whole path over one synthetic batch per GPU:
 click maps -> normalise -> DINOv2-S/14 (clicks injected before the blocks) -> FeatUp JBU x16
--> bilinear resize to the image size -> ConvSegHead -> logits   (BASELINE.json configs[1]:
+-> bilinear resize to the image size (fused into the last JBU stage) -> ConvSegHead -> logits   (BASELINE.json configs[1]:
 "DINOv2-S/14 + FeatUp JBU, 448x448 batch=32, forward-only").  The metric's "featurizer +
 upsampler" stages are inside the timed region together with the seg head and the click-map
 generator that north_star places on the same path (more work, never less); their separate
@@ -119,8 +119,22 @@ def stage_times(model, image, points, iters=5):
 
         out["click_maps+normalize_ms"] = timed(lambda: (model.prepare_input(image), model.dist_maps(img, points)))
         out["featurizer_ms"] = timed(lambda: model.backbone.forward_fused_clicks(img, prev, maps, model.embed_coords))
-        out["upsampler_ms"] = timed(lambda: model.upsampler(source=feats, guidance=img))
-        out["resize+head_ms"] = timed(lambda: model._resize_and_head(img, hr))
+        stack = getattr(model.upsampler, "upsampler", None)
+        if getattr(model, "fold_upsampler_affine", False) and hasattr(stack, "forward_stages"):
+            # the route the timed step takes: JBU stages (last one fused with the resize to the image size), the
+            # stack's final fix-up folded into the head's first conv
+            hr_f = stack.forward_stages(feats, img, out_size=img.shape[2:])
+            Wf, bf, alpha = stack.fixup_affine()
+            out["upsampler(+resize)_ms"] = timed(lambda: stack.forward_stages(feats, img, out_size=img.shape[2:]))
+            out["head_ms"] = timed(lambda: model.head.forward_folded_affine(hr_f, Wf, bf, alpha))
+            out["featurizer+upsampler_images_per_sec"] = image.shape[0] / (
+                (out["click_maps+normalize_ms"] + out["featurizer_ms"] + out["upsampler(+resize)_ms"]) * 1e-3)
+            out["note"] = "same kernels as the timed step; plugin-by-plugin route (unfolded fix-up GEMM, separate resize): " \
+                          f"upsampler {timed(lambda: model.upsampler(source=feats, guidance=img)):.2f} ms, " \
+                          f"resize+head {timed(lambda: model._resize_and_head(img, hr)):.2f} ms"
+        else:
+            out["upsampler_ms"] = timed(lambda: model.upsampler(source=feats, guidance=img))
+            out["resize+head_ms"] = timed(lambda: model._resize_and_head(img, hr))
     return out
 
 
@@ -233,7 +247,8 @@ def main():
         if not args.no_stages:
             try:
                 st = stage_times(model, image, points)
-                st["featurizer+upsampler_images_per_sec"] = args.batch / ((st["featurizer_ms"] + st["upsampler_ms"]) * 1e-3)
+                if "upsampler_ms" in st:
+                    st["featurizer+upsampler_images_per_sec"] = args.batch / ((st["featurizer_ms"] + st["upsampler_ms"]) * 1e-3)
                 line["stages"] = st
             except Exception as exc:  # the headline number must survive a failure of the extras
                 line["stages"] = {"error": repr(exc)}
