@@ -20,7 +20,9 @@
 
 namespace {
 
-constexpr int QB = 128;  // queries per block
+// queries per block = 32 per wave; NW = 4 waves (128 queries), or 8 (256) for very long query sequences with short
+// key sequences (LoftUp: 200 k pixels x 1 k keys), where every block streams ALL keys of its (batch, head) through LDS
+// and the kernel sits on the L2 -> LDS staging rate: twice the queries per streamed key byte.
 constexpr int KB = 64;   // keys per tile
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -48,8 +50,8 @@ struct Geo {
     }
 };
 
-template <int HD>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                         const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H,
                                                         int Lq, int Lk, long qsb, long qsl, long qsh, long ksb, long ksl,
                                                         long ksh, long osb, long osl, long osh, float c /* scale*log2e */,
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     const int r = lane & 31, hh = lane >> 5;
 
     // ---- Q fragments (B operand of S^T = K Q^T): element j <-> d = 16kk + 8hh + j
+    constexpr int QB = 32 * NW;
     const long qrow = (long)blockIdx.x * QB + wid * 32 + r;
     const bf16_t* qp = Q + (size_t)b * qsb + (size_t)(qrow < Lq ? qrow : Lq - 1) * qsl + (size_t)h * qsh + 8 * hh;
     bf16x8 qf[KK];
@@ -73,11 +76,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     // ---- DMA assignment: each operand tile = PIECES pieces of 1 KiB; wave w takes pieces w, w+4, ...
     const bf16_t* kbase = K + (size_t)b * ksb + (size_t)h * ksh;
     const bf16_t* vbase = V + (size_t)b * ksb + (size_t)h * ksh;
-    constexpr int PPW = G::PIECES / 4;
+    static_assert(G::PIECES % NW == 0);
+    constexpr int PPW = G::PIECES / NW;
     int prow[PPW], kch[PPW], vch[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int piece = wid + 4 * i;
+        const int piece = wid + NW * i;
         prow[i] = piece * G::ROWS_PER_PIECE + lane / G::CHUNKS;
         const int pch = lane % G::CHUNKS;
         kch[i] = G::kswz(prow[i], pch);
@@ -89,8 +93,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         for (int i = 0; i < PPW; ++i) {
             int key = base + prow[i];
             key = key < Lk ? key : Lk - 1;
-            glds16(kbase + (size_t)key * ksl + kch[i] * 8, buf + (wid + 4 * i) * 1024);
-            glds16(vbase + (size_t)key * ksl + vch[i] * 8, buf + G::TILE + (wid + 4 * i) * 1024);
+            glds16(kbase + (size_t)key * ksl + kch[i] * 8, buf + (wid + NW * i) * 1024);
+            glds16(vbase + (size_t)key * ksl + vch[i] * 8, buf + G::TILE + (wid + NW * i) * 1024);
         }
     };
 
@@ -220,19 +224,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     }
 }
 
-template <int HD>
+template <int HD, int NW = 4>
 int launch_attention(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, long qsb,
                      long qsl, long qsh, long ksb, long ksl, long ksh, long osb, long osl, long osh, float scale,
                      float* lse, long lse_ld, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = attention_kernel<HD>;
+    constexpr int QB = 32 * NW;
+    auto kern = attention_kernel<HD, NW>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<HD>::LDS) != hipSuccess)
             return ISP_ERR_LAUNCH;
         attr_done = true;
     }
     dim3 grid((Lq + QB - 1) / QB, B * H);
-    kern<<<grid, 256, Geo<HD>::LDS, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, H, Lq, Lk, qsb,
+    kern<<<grid, 64 * NW, Geo<HD>::LDS, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, H, Lq, Lk, qsb,
                                          qsl, qsh, ksb, ksl, ksh, osb, osl, osh, scale * 1.4426950408889634f, lse,
                                          lse_ld);
     return isp_launch_status();
@@ -255,12 +260,21 @@ static int attention_fwd_impl(const void* Q, const void* K, const void* V, void*
     if (head_dim == 64)
         return launch_attention<64>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
                                     kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
-    if (head_dim == 128)
+    if (head_dim == 128) {
+        // 256-query blocks once they still fill the chip several times over
+        if ((long)((Lq + 255) / 256) * B * H >= 2048)
+            return launch_attention<128, 8>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                                            kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
         return launch_attention<128>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
                                      kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
-    if (head_dim == 256)
+    }
+    if (head_dim == 256) {
+        if ((long)((Lq + 255) / 256) * B * H >= 2048)
+            return launch_attention<256, 8>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                                            kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
         return launch_attention<256>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
                                      kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
+    }
     return ISP_ERR_UNSUPPORTED;
 }
 
