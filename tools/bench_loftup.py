@@ -18,4 +18,4 @@ with torch.no_grad():
     for _ in range(3): y = up(src, gd)
     e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 3
-print(f"LoftUp B={B} 448^2: {ms:.2f} ms/batch = {ms/B:.2f} ms/img, {2.12*B/ms:.1f} TFLOP/s algorithmic; out {tuple(y.shape)} mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+print(f"LoftUp B={B} 448^2: {ms:.2f} ms/batch = {ms/B:.2f} ms/img, {2.12*B/ms*1e3:.0f} TFLOP/s algorithmic; out {tuple(y.shape)} mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
