@@ -3,6 +3,8 @@ core/model/iseg_probe_model.py:16-258): backbone -> upsampler -> head, every sta
 module behind the reference's plugin contracts."""
 from typing import Dict, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -71,8 +73,9 @@ class iSegProbeModel(iSegBaseModel):
         if self._fusable() and not training:
             # click maps go straight into the patch matrix: no torch.cat, no token round trip
             maps = self.dist_maps(image, points)
+            records = self._jbu_records_side_stream(image)
             feats = self.backbone.forward_fused_clicks(image, prev_mask, maps, self.embed_coords)
-            return self._after_backbone(image, feats)
+            return self._after_backbone(image, feats, records)
         return super()._forward_prepared(image, prev_mask, points)
 
     def backbone_forward(self, image: torch.Tensor, coord_features: torch.Tensor = None) -> Dict:
@@ -80,7 +83,32 @@ class iSegProbeModel(iSegBaseModel):
         backbone_features = self.backbone(image, coord_features)
         return self._after_backbone(image, backbone_features)
 
-    def _after_backbone(self, image, backbone_features):
+    def _jbu_folds(self):
+        return (self.architecture == "backbone_upsampler_head" and self.fold_upsampler_affine
+                and isinstance(self.upsampler, JBUFeatUpUpsampler) and isinstance(self.head, ConvSegHead)
+                and self.head.num_layers >= 1)
+
+    def _jbu_records_side_stream(self, image):
+        """FeatUp-JBU's kernel records depend on the image only and their kernels are VALU-bound (jbu_kernels: 59 % VALU,
+        no MFMA), the ViT's are MFMA / staging-bound: the records are computed on a second HIP stream while the
+        featurizer runs.  Returns (records, stream) or None."""
+        if not (self._jbu_folds() and image.is_cuda and os.environ.get("ISEGPROBE_JBU_SIDE_STREAM", "1") != "0"):
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None  # inside a HIP-graph capture the forward stays on one stream
+        main = torch.cuda.current_stream()
+        side = getattr(self, "_side_stream", None)
+        if side is None or side.device != image.device:
+            side = self._side_stream = torch.cuda.Stream(device=image.device)
+        side.wait_stream(main)
+        p = self.backbone.patch_size
+        with torch.cuda.stream(side):
+            recs = self.upsampler.upsampler.stage_records(image, image.shape[2] // p, image.shape[3] // p, image.shape[2:])
+        for r in recs:
+            r.record_stream(main)
+        return recs, side
+
+    def _after_backbone(self, image, backbone_features, jbu_records=None):
         if self.architecture == "backbone_upsampler_head":
             if (not (torch.is_grad_enabled() and backbone_features.requires_grad)
                     and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.head.parameters()))
@@ -89,7 +117,11 @@ class iSegProbeModel(iSegBaseModel):
                 # JBUStack ends with z = x + 0.1*conv1x1(x); that affine map commutes with the bilinear
                 # resize and folds into the head's first conv: the 2.5 TFLOP 1x1 GEMM disappears
                 # (the resize to the image size is fused into the last JBU stage when 512 -> 448-like sizes allow it)
-                hr = self.upsampler.upsampler.forward_stages(backbone_features, image, out_size=image.shape[2:])
+                records = None
+                if jbu_records is not None:
+                    records, side = jbu_records
+                    torch.cuda.current_stream().wait_stream(side)
+                hr = self.upsampler.upsampler.forward_stages(backbone_features, image, out_size=image.shape[2:], records=records)
                 if image.size()[2:] != hr.size()[2:]:
                     hr = nchw_view(ops.resize_nhwc(to_nhwc_bf16(hr), image.shape[2], image.shape[3], "bilinear"))
                 Wf, bf, alpha = self.upsampler.upsampler.fixup_affine()

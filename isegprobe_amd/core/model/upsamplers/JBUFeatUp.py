@@ -67,9 +67,10 @@ class JBULearnedRange(nn.Module):
         proj = ops.jbu_range_proj(small, P["w0"], P["b0"], P["w3"], P["b3"])
         return ops.jbu_kernels(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"])
 
-    def run(self, source_nhwc, guidance):
+    def run(self, source_nhwc, guidance, kc=None):
         # composite kernels on the low-res grid, applied by MFMA: no x2 map in HBM
-        kc = self.kernels(guidance, source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2)
+        if kc is None:
+            kc = self.kernels(guidance, source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2)
         return ops.jbu_apply(source_nhwc, kc)
 
     @staticmethod
@@ -78,16 +79,21 @@ class JBULearnedRange(nn.Module):
         onto exactly 7 output ones (FeatUp's x16 map vs. a patch-14 image: 512 -> 448)."""
         return GH % 8 == 0 and GW % 8 == 0 and OH * 8 == GH * 7 and OW * 8 == GW * 7
 
-    def run_resized(self, source_nhwc, guidance, OH, OW):
-        """resize_bilinear(run(source), OH, OW) as one operator: the stage's kernel records are blended onto the output
-        grid (guidance-only, cached with them) and applied to the source directly (isp_jbu_apply_resized)."""
-        GH, GW = source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2
+    def kernels_resized(self, guidance, GH, GW, OH, OW):
+        """Kernel records of this stage blended onto the OH x OW grid of the model's bilinear resize (guidance-only,
+        cached like ``kernels``); the stage's own records are never stored: the kernel blends them on the way out."""
         P = self.packed()
-        def build():  # the stage's own records are never stored: the kernel blends them on the way out
+
+        def build():
             small = ops.adaptive_avg_pool(guidance, GH, GW)
             proj = ops.jbu_range_proj(small, P["w0"], P["b0"], P["w3"], P["b3"])
             return ops.jbu_kernels_resized(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"], OH, OW)
-        kc9 = self._gcache.get(guidance, id(P), (GH, GW, OH, OW), build)
+        return self._gcache.get(guidance, id(P), (GH, GW, OH, OW), build)
+
+    def run_resized(self, source_nhwc, guidance, OH, OW, kc9=None):
+        """resize_bilinear(run(source), OH, OW) as one operator (isp_jbu_apply_resized on the blended records)."""
+        if kc9 is None:
+            kc9 = self.kernels_resized(guidance, source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2, OH, OW)
         return ops.jbu_apply_resized(source_nhwc, kc9)
 
 
@@ -101,19 +107,31 @@ class JBUStack(nn.Module):
         self.fixup_proj = nn.Sequential(nn.Dropout2d(0.2), nn.Conv2d(feat_dim, feat_dim, kernel_size=1))
         self._packed = PackedCache()
 
-    def forward_stages(self, source, guidance, out_size=None):
+    def forward_stages(self, source, guidance, out_size=None, records=None):
         """The four x2 stages WITHOUT the final fix-up  x + 0.1*conv1x1(x).  The fix-up is a per-pixel
         affine map; iSegProbeModel folds it (through the linear resize) into the seg head's first conv.
         With ``out_size`` the model's bilinear resize to the image size (iseg_probe_model.py:120-129) is fused into the
         last stage when the sizes allow it (otherwise the caller resizes as before)."""
         x = to_nhwc_bf16(source)
+        if records is None:
+            records = self.stage_records(guidance, x.shape[1], x.shape[2], out_size)
+        for up, kc in zip((self.up1, self.up2, self.up3), records[:3]):
+            x = up.run(x, None, kc)
+        if records[3].shape[3] == 9:  # records of the resized grid
+            return nchw_view(self.up4.run_resized(x, None, records[3].shape[1], records[3].shape[2], records[3]))
+        return nchw_view(self.up4.run(x, None, records[3]))
+
+    def stage_records(self, guidance, h, w, out_size=None):
+        """The kernel records of the four stages for an h x w source: functions of the guidance only, so they can be
+        computed before (or, on another stream, while) the featurizer runs."""
         guidance = guidance.float().contiguous()
-        for up in (self.up1, self.up2, self.up3):
-            x = up.run(x, guidance)
-        GH, GW = x.shape[1] * 2, x.shape[2] * 2
+        recs = [up.kernels(guidance, h << (i + 1), w << (i + 1)) for i, up in enumerate((self.up1, self.up2, self.up3))]
+        GH, GW = h << 4, w << 4
         if out_size is not None and JBULearnedRange.resize_fusable(GH, GW, int(out_size[0]), int(out_size[1])):
-            return nchw_view(self.up4.run_resized(x, guidance, int(out_size[0]), int(out_size[1])))
-        return nchw_view(self.up4.run(x, guidance))
+            recs.append(self.up4.kernels_resized(guidance, GH, GW, int(out_size[0]), int(out_size[1])))
+        else:
+            recs.append(self.up4.kernels(guidance, GH, GW))
+        return recs
 
     def fixup_affine(self):
         """(W [C,C], b [C], alpha): z = x + alpha * (W x + b)."""
