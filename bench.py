@@ -157,8 +157,8 @@ def cpu_baseline(model_sd, size, upsampler, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--upsampler", default="jbu_featup")
