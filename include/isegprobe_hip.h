@@ -290,6 +290,16 @@ long isp_next_points_workspace_bytes(int B, int H, int W);
 int isp_next_points(const float* pred, const float* gt, float* points, const unsigned* rand32, int B, int H, int W, int P,
                     int click_indx, float pred_thresh, void* workspace, void* stream);
 
+/* ---- fp32-accurate products on the bf16 engine (core/model/precise.py; the "logits within 1e-3 fp32" gate of the
+ * reference comparison).  isp_split_bf16x3 writes an fp32 [rows, K] matrix (row stride ld_in) as bf16 [rows, 3*Kpad]:
+ * activations layout [hi | hi | lo] (weights_layout = 0) or weights layout [hi | lo | hi] (1), hi = bf16(v),
+ * lo = bf16(v - hi), v = scale * act(x) with act 0 none / 1 ReLU / 2 GELU(erf); columns K..Kpad are zero.  A GEMM or conv
+ * over the tripled depth then accumulates hi.whi + hi.wlo + lo.whi in fp32.  isp_softmax_rows_f32: in-place softmax over
+ * the first `cols` entries of each fp32 row (the rest of the row, up to ld, is zeroed). */
+int isp_split_bf16x3(const float* x, long ld_in, void* out_bf16, long rows, int K, int Kpad, int weights_layout, int act,
+                     float scale, void* stream);
+int isp_softmax_rows_f32(float* x, long rows, int cols, long ld, void* stream);
+
 /* ---- On-box roofline probes (diagnostics; tools/peaks.py): a register-resident v_mfma_f32_16x16x32_bf16 loop
  * (blocks x 4 waves x iters x 16 MFMAs; operands read once from a 64 Ki-element bf16 seed: zeros vs random bits show the
  * clock the chip holds) and a float4 copy of `bytes` bytes. */

@@ -142,6 +142,12 @@ class iSegProbeModel(iSegBaseModel):
                 hr_features = nchw_view(ops.resize_nhwc(x, image.shape[2], image.shape[3], "bilinear"))
         return self.head(hr_features)
 
+    def forward_fp32(self, image: torch.Tensor, points: torch.Tensor) -> Dict:
+        """forward() with fp32-accurate arithmetic ("three bf16 products", core/model/precise.py): the checking mode
+        behind north_star's "logits within 1e-3 fp32" gate.  DINOv2 + identity / bilinear + conv heads only."""
+        from .precise import forward_fp32
+        return forward_fp32(self, image, points)
+
     def get_lowres_highres_feats(self, image: torch.Tensor, points: torch.Tensor) -> Tuple:
         """Low / high resolution features for PCA dumps (iseg_probe_model.py:136-174)."""
         image, prev_mask = self.prepare_input(image)

@@ -1,0 +1,167 @@
+"""fp32-accurate forward of the probed path on the bf16 MFMA engine (the "logits within 1e-3 fp32" gate of
+BASELINE.json's north_star; the product path is the bf16 one and is held to 1e-2).
+
+Every contraction (patch embedding, the ViT's linears, QK^T, PV, the head's 3x3 convs and classifier) runs as
+"three bf16 products": an fp32 operand is split into hi = bf16(x) and lo = bf16(x - hi); laid out along K as
+[hi | hi | lo] against weights [whi | wlo | whi] the existing GEMM / conv kernels accumulate hi.whi + hi.wlo + lo.whi
+in fp32 (isp_split_bf16x3; the dropped lo.wlo term is 2^-18 relative).  Everything between the contractions stays
+fp32: the residual stream, LayerNorm (fp32 in and out), softmax (isp_softmax_rows_f32), GELU / ReLU (applied by the
+split kernel on the way into the next contraction), the align_corners bilinear resizes (isp_resize_bilinear_ac_nchw_f32).
+torch is used for layout only (unfold, permute, padding copies).  Three to four times the work of the bf16 path and
+unfused: a checking mode, not the fast path.
+
+Scope: DINOv2 featurizer with clicks injected before the backbone (or none), identity / bilinear upsampler,
+ConvSegHead / SimpleConvSegHead -- BASELINE.json configs[0], the reference's own CPU-runnable configuration
+(models/sbd/dinov2/patch-embed_bilinear.py:40, core/model/iseg_probe_model.py:110-134).
+"""
+import torch
+import torch.nn.functional as F
+
+from ... import hip_ops as ops
+from ..._lib import EP_BIAS_F32, EP_TOKENS_F32, IspError
+from .featurizers.DINOv2 import LN_EPS
+
+
+class _WeightSplits:
+    """[whi | wlo | whi] images of the parameters, rebuilt when a parameter changes (data pointer / version)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, key, params, build):
+        sig = tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._c.get(key)
+        if hit is None or hit[0] != sig:
+            with torch.no_grad():
+                hit = (sig, build())
+            self._c[key] = hit
+        return hit[1]
+
+
+def _w3(cache, key, weight2d_fn, *params):
+    return cache.get(key, params, lambda: ops.split3(weight2d_fn().detach().float().contiguous(), weights=True))
+
+
+def _linear(x, w3, bias, act=None, scale=1.0):
+    """fp32 [M,K] x W^T (+ bias) -> fp32 [M,N]; `act` / `scale` apply to x first."""
+    return ops.linear(ops.split3(x, act=act, scale=scale), w3, bias, None, out_dtype=torch.float32)
+
+
+def _residual(x, h, w3, bias, gamma, act=None):
+    ops.linear_residual_(x, ops.split3(h, act=act), w3, bias, gamma)
+
+
+def _attention(qkv, B, L, heads, scale):
+    """softmax(q k^T * scale) v per (batch, head) from the packed fp32 qkv [B*L, 3*heads*64] (attention.py:54-71)."""
+    D = heads * 64
+    Lp = (L + 3) // 4 * 4  # GEMM output columns come in fours: zero key rows, masked out by the softmax
+    out = torch.empty(B * L, D, device=qkv.device, dtype=torch.float32)
+    kp = torch.zeros(Lp, 64, device=qkv.device, dtype=torch.float32)
+    vt = torch.zeros(64, Lp, device=qkv.device, dtype=torch.float32)
+    for b in range(B):
+        rows = qkv[b * L:(b + 1) * L]
+        for h in range(heads):
+            q, k, v = (rows[:, i * D + h * 64: i * D + (h + 1) * 64] for i in range(3))
+            kp[:L].copy_(k)
+            vt[:, :L].copy_(v.t())
+            s = ops.linear(ops.split3(q, scale=scale), ops.split3(kp, weights=True), None, None, out_dtype=torch.float32)
+            ops.softmax_rows_(s, L)
+            ops.gemm(ops.split3(s), ops.split3(vt, weights=True),
+                     ops._epilogue(EP_BIAS_F32, out[b * L:(b + 1) * L, h * 64:(h + 1) * 64], D, None))
+    return out
+
+
+def _vit(featurizer, cache, image, coord):
+    """DINOv2 forward (DINOv2.py:500-546) -> fp32 features [B, h, w, D]; `coord` = [prev_mask | click maps] or None."""
+    m = featurizer.model
+    p = featurizer.patch_size
+    B, _, H, W = image.shape
+    if H % p or W % p:
+        raise AssertionError(f"Input image size {H}x{W} is not a multiple of patch size {p}")
+    D, heads = m.embed_dim, m.num_heads
+    h, w = H // p, W // p
+    T = h * w
+    # patch embedding(s) as one GEMM over the concatenated K axis: unfold is layout only
+    cols = [F.unfold(image, p, stride=p)]
+    if coord is not None:
+        cols.append(F.unfold(coord, p, stride=p))
+    A = torch.cat(cols, dim=1).transpose(1, 2).reshape(B * T, -1).contiguous()
+    return A, (B, T, h, w, D, heads)
+
+
+def forward_fp32(model, image, points):
+    """iSegProbeModel.forward (iseg_base_model.py:67-89 + iseg_probe_model.py:110-134) with fp32-accurate arithmetic."""
+    from .featurizers import DINOv2Featurizer
+    from .heads.conv_heads import _StackedHead
+    from .upsamplers.basic_upsamplers import BilinearUpsampler, IdentityUpsampler
+    fz, head, up = model.backbone, model.head, model.upsampler
+    if not isinstance(fz, DINOv2Featurizer) or fz.feats_injection_mode not in ("before_backbone", "no_injection"):
+        raise IspError("forward_fp32 covers the DINOv2 featurizer with clicks injected before the backbone (or none)")
+    if not isinstance(up, (BilinearUpsampler, IdentityUpsampler)) or not isinstance(head, _StackedHead):
+        raise IspError("forward_fp32 covers the identity / bilinear upsamplers and the stacked conv heads")
+    cache = model.__dict__.setdefault("_fp32_splits", _WeightSplits())
+    with torch.no_grad():
+        image, prev_mask = model.prepare_input(image)
+        coord = None
+        if fz.feats_injection_mode == "before_backbone":
+            coord = model.maps_transform(model.get_coord_features(image, prev_mask, points))
+        m = fz.model
+        A, (B, T, h, w, D, heads) = _vit(fz, cache, image, coord)
+        H, W = image.shape[2:]
+        L = T + 1
+        pw, pb = m.patch_embed.proj.weight, m.patch_embed.proj.bias
+        if coord is not None:
+            cw, cb = model.embed_coords.proj.weight, model.embed_coords.proj.bias
+            w3 = _w3(cache, "embed", lambda: torch.cat((pw.flatten(1), cw.flatten(1)), dim=1), pw, cw)
+            bias = (pb.detach().float() + cb.detach().float()).contiguous()
+        else:
+            w3 = _w3(cache, "embed", lambda: pw.flatten(1), pw)
+            bias = pb.detach().float().contiguous()
+        table, cls_row = fz._pos_embed(H, W)
+        x = torch.empty(B * L, D, device=image.device, dtype=torch.float32)
+        ops.gemm(ops.split3(A), w3, ops._epilogue(EP_TOKENS_F32, x, D, bias, None, table, T))
+        x.view(B, L, D)[:, 0].copy_(cls_row)
+        f32 = lambda t: t.detach().float().contiguous()
+        for i, blk in enumerate(m.blocks):
+            g1 = f32(blk.ls1.gamma) if hasattr(blk.ls1, "gamma") else None
+            g2 = f32(blk.ls2.gamma) if hasattr(blk.ls2, "gamma") else None
+            y = ops.layernorm(x, f32(blk.norm1.weight), f32(blk.norm1.bias), LN_EPS, out_dtype=torch.float32)
+            qkv = _linear(y, _w3(cache, ("qkv", i), lambda: blk.attn.qkv.weight, blk.attn.qkv.weight), f32(blk.attn.qkv.bias))
+            att = _attention(qkv, B, L, heads, 64 ** -0.5)
+            _residual(x, att, _w3(cache, ("proj", i), lambda: blk.attn.proj.weight, blk.attn.proj.weight),
+                      f32(blk.attn.proj.bias), g1)
+            y = ops.layernorm(x, f32(blk.norm2.weight), f32(blk.norm2.bias), LN_EPS, out_dtype=torch.float32)
+            hid = _linear(y, _w3(cache, ("fc1", i), lambda: blk.mlp.fc1.weight, blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias))
+            _residual(x, hid, _w3(cache, ("fc2", i), lambda: blk.mlp.fc2.weight, blk.mlp.fc2.weight),
+                      f32(blk.mlp.fc2.bias), g2, act="gelu")
+        feats = ops.layernorm(x, f32(m.norm.weight), f32(m.norm.bias), LN_EPS, out_dtype=torch.float32,
+                              group_out=T, skip=1, rows_out=B * T)  # [B*T, D] = NHWC [B,h,w,D]
+        if isinstance(up, BilinearUpsampler) and (h, w) != (H, W):
+            planes = feats.view(B, h, w, D).permute(0, 3, 1, 2).contiguous()
+            planes = ops.resize_bilinear_nchw_f32(planes, H, W)
+            y = planes.permute(0, 2, 3, 1).contiguous()
+        else:
+            y = feats.view(B, h, w, D)
+        Bh, Hh, Wh, C = y.shape
+        act = None
+        for j, layer in enumerate(head.convs):
+            cw_ = layer.conv.weight
+            N = cw_.shape[0]
+            k = head.kernel_size
+            if k == 3:
+                w3 = _w3(cache, ("conv", j), lambda: cw_.permute(0, 2, 3, 1).reshape(N * 9, C), cw_).view(N, -1)
+                a3 = ops.split3(y.reshape(-1, C), act=act).view(Bh, Hh, Wh, -1)
+                y = ops.conv3x3(a3, w3, f32(layer.conv.bias), None, out_dtype=torch.float32)
+            else:  # SimpleConvSegHead: 1x1 convs
+                w3 = _w3(cache, ("conv", j), lambda: cw_.flatten(1), cw_)
+                y = _linear(y.reshape(-1, C), w3, f32(layer.conv.bias), act=act).view(Bh, Hh, Wh, N)
+            C, act = N, "relu"
+        clw, clb = head.classifier.weight, head.classifier.bias
+        ncls = clw.shape[0]
+        npad = (ncls + 3) // 4 * 4
+        wc3 = _w3(cache, "cls", lambda: F.pad(clw.flatten(1), (0, 0, 0, npad - ncls)), clw)
+        bias = F.pad(clb.detach().float(), (0, npad - ncls)).contiguous()
+        logits = _linear(y.reshape(-1, C), wc3, bias, act=act)[:, :ncls]
+        logits = logits.reshape(Bh, Hh, Wh, ncls).permute(0, 3, 1, 2).contiguous()
+        logits = model._to_image_size(logits, (H, W))
+    return {"instances": logits, "instances_aux": None}

@@ -475,3 +475,64 @@ extern "C" int isp_sum_partials_f32(const float* partial, float* out, long M, in
     sum_partials_kernel<<<(unsigned)(((M + 3) / 4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(partial, out, M, slots, bias);
     return isp_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------
+// fp32-accurate products on the bf16 MFMA engine ("three bf16 products"): x = hi + lo with hi = bf16(x),
+// lo = bf16(x - hi) (|x - hi - lo| <= 2^-17 |x|), so  x . w  ~=  hi.whi + hi.wlo + lo.whi  (the dropped lo.wlo term is
+// 2^-18 relative).  Laid out along K the three products are ONE GEMM / conv of 3x the depth with fp32 accumulation:
+// activations [hi | hi | lo], weights [whi | wlo | whi].  This kernel writes either layout from an fp32 matrix, with an
+// optional activation (the fp32 epilogues of the engine carry none) and scale on the way in.  K is zero-padded to Kpad.
+// Used by core/model/precise.py for the "logits within 1e-3 of the fp32 reference" gate; not on the bf16 product path.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ x, long ld_in, bf16_t* __restrict__ out,
+                                                            long rows, int K, int Kpad, int weights, int act, float scale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * Kpad) return;
+    const long r = idx / Kpad;
+    const int k = (int)(idx - r * Kpad);
+    float v = k < K ? x[r * ld_in + k] : 0.f;
+    if (act == 1) v = fmaxf(v, 0.f);
+    if (act == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    v *= scale;
+    const bf16_t hi = f2bf(v);
+    const bf16_t lo = f2bf(v - bf2f(hi));
+    bf16_t* o = out + r * (3L * Kpad) + k;
+    o[0] = hi;
+    o[Kpad] = weights ? lo : hi;
+    o[2L * Kpad] = weights ? hi : lo;
+}
+
+extern "C" int isp_split_bf16x3(const float* x, long ld_in, void* out_bf16, long rows, int K, int Kpad, int weights_layout,
+                                int act, float scale, void* stream) {
+    ISP_CHECK_ARG(x && out_bf16 && rows > 0 && K > 0 && Kpad >= K && ld_in >= K && act >= 0 && act <= 2);
+    const long total = rows * Kpad;
+    split_bf16x3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        x, ld_in, (bf16_t*)out_bf16, rows, K, Kpad, weights_layout, act, scale);
+    return isp_launch_status();
+}
+
+// in-place softmax over the first `cols` entries of every row of an fp32 [rows, ld] matrix; entries [cols, ld) become 0
+// (zero-padded key columns).  One wave per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, long rows, int cols, long ld) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* p = x + row * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, p[c]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const float e = expf(p[c] - m);
+        p[c] = e;
+        s += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float inv = 1.f / s;
+    for (int c = lane; c < (int)ld; c += 64) p[c] = c < cols ? p[c] * inv : 0.f;
+}
+
+extern "C" int isp_softmax_rows_f32(float* x, long rows, int cols, long ld, void* stream) {
+    ISP_CHECK_ARG(x && rows > 0 && cols > 0 && ld >= cols);
+    softmax_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(x, rows, cols, ld);
+    return isp_launch_status();
+}

@@ -785,3 +785,25 @@ def next_points(pred, gt, points, click_indx, rand32, pred_thresh=0.49, workspac
     check(_lib.lib().isp_next_points(_p(pred), _p(gt), _p(points), _p(r32), B, H, W, points.shape[1] // 2,
                                      int(click_indx), float(pred_thresh), _p(workspace), _stream()), "isp_next_points")
     return points, workspace
+
+
+# ---------------------------------------------------------------- fp32-accurate products (core/model/precise.py)
+def split3(x, weights=False, act=None, scale=1.0, K=None):
+    """fp32 [rows, K] (last-dim contiguous, any row stride) -> bf16 [rows, 3*Kpad]: [hi|hi|lo] (activations) or
+    [hi|lo|hi] (weights=True); Kpad = K rounded up to 64.  act in (None, 'relu', 'gelu') and scale apply first."""
+    if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
+        raise IspError("split3 expects a CUDA fp32 matrix with contiguous rows")
+    rows = x.shape[0]
+    K = x.shape[1] if K is None else K
+    Kpad = (K + 63) // 64 * 64
+    out = torch.empty(rows, 3 * Kpad, device=x.device, dtype=BF16)
+    check(_lib.lib().isp_split_bf16x3(_p(x), x.stride(0), _p(out), rows, K, Kpad, int(weights),
+                                      {None: 0, "relu": 1, "gelu": 2}[act], float(scale), _stream()), "isp_split_bf16x3")
+    return out
+
+
+def softmax_rows_(x, cols):
+    """In-place softmax over the first `cols` columns of each row of a contiguous fp32 matrix; the rest becomes 0."""
+    _need(x, torch.float32, "x")
+    check(_lib.lib().isp_softmax_rows_f32(_p(x), x.shape[0], cols, x.shape[1], _stream()), "isp_softmax_rows_f32")
+    return x

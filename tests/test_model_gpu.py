@@ -102,6 +102,38 @@ def test_s14_bilinear_vs_oracle(size, B):
     assert _mask_agreement(y, ref) == 1.0
 
 
+@pytest.mark.parametrize("up,size,B", [("bilinear", 224, 2), ("identity", 224, 1), ("bilinear", 112, 2)])
+def test_s14_fp32_mode_vs_oracle(up, size, B):
+    """north_star's fp32 gate: iSegProbeModel.forward_fp32 (fp32-accurate "three bf16 products" arithmetic on the
+    same kernels) against the fp32 CPU oracle -- logits within 1e-3 (BASELINE.json configs[0]: DINOv2-S/14 + bilinear,
+    fixed 224).  The bf16 product path on the same inputs is held to 1e-2 by the tests above."""
+    from oracle import model as omodel
+    model = build_model(up, vit=S14, img=(size, size))
+    seeded_(model, 321)
+    with torch.no_grad():
+        model.backbone.model.pos_embed.mul_(0.3)
+    w = {k: v.clone() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(11)
+    torch.manual_seed(11)
+    image = torch.rand(B, 4, size, size)
+    image[:, 3] = (image[:, 3] > 0.8).float()
+    points = torch.from_numpy(rand_points(rng, B, 24, size, size))
+    cfg = dict(patch=14, depth=12, heads=6, upsampler=up, injection="before_backbone",
+               with_prev_mask=True, use_disks=True, norm_radius=5)
+    torch.set_num_threads(16)
+    ref = omodel.forward(image, points, w, cfg)
+    model = model.cuda()
+    y = model.forward_fp32(image.cuda(), points.cuda())["instances"].cpu()
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    err = (y - ref).abs()
+    with torch.no_grad():
+        e16 = (model(image.cuda(), points.cuda())["instances"].cpu() - ref).abs().max().item()
+    print(f"fp32 mode {up}@{size}: max|logit err| = {err.max():.3g} rms {err.pow(2).mean().sqrt():.3g} "
+          f"(bf16 path: {e16:.3g}); logit rms {ref.pow(2).mean().sqrt():.3f}")
+    assert err.max().item() < 1e-3
+    assert ((y > 0) == (ref > 0)).all() or (ref.abs()[(y > 0) != (ref > 0)] < 1e-3).all()
+
+
 @pytest.mark.parametrize("up,size,params", [
     ("jbu_featup", 448, {"backbone_type": "dinov2"}),                 # BASELINE configs[1] = the bench workload
     ("loftup", 224, {"upsampler_path": None, "n_dim": 384}),           # configs[2] at the reference's crop size
