@@ -72,7 +72,7 @@ def test_jbu_stages_and_stack_vs_oracle():
     assert err.pow(2).mean().sqrt().item() < 5e-3 * max(1.0, ref.pow(2).mean().sqrt().item())
 
 
-@pytest.mark.parametrize("h,w", [(4, 8), (8, 4), (16, 16)])
+@pytest.mark.parametrize("h,w", [(4, 8), (8, 4), (16, 16), (5, 7), (3, 9)])
 def test_jbu_last_stage_fused_with_resize(h, w):
     """JBUStack.forward_stages(out_size=image size): the last x2 stage and the model's bilinear resize as ONE operator
     (isp_jbu_blend + isp_jbu_apply_resized) against stage -> isp_resize (both bf16 paths) and against the fp32 oracle
