@@ -71,22 +71,17 @@ def _attention(qkv, B, L, heads, scale):
     return out
 
 
-def _vit(featurizer, cache, image, coord):
-    """DINOv2 forward (DINOv2.py:500-546) -> fp32 features [B, h, w, D]; `coord` = [prev_mask | click maps] or None."""
-    m = featurizer.model
+def _patch_matrix(featurizer, image, coord):
+    """im2col of the image (and, before-backbone injection, of [prev_mask | click maps]) for the patch embedding(s) as
+    ONE GEMM over the concatenated K axis (DINOv2.py:518-523): fp32 [B*T, (3 + 3) * p * p].  unfold is layout only."""
     p = featurizer.patch_size
     B, _, H, W = image.shape
     if H % p or W % p:
         raise AssertionError(f"Input image size {H}x{W} is not a multiple of patch size {p}")
-    D, heads = m.embed_dim, m.num_heads
-    h, w = H // p, W // p
-    T = h * w
-    # patch embedding(s) as one GEMM over the concatenated K axis: unfold is layout only
     cols = [F.unfold(image, p, stride=p)]
     if coord is not None:
         cols.append(F.unfold(coord, p, stride=p))
-    A = torch.cat(cols, dim=1).transpose(1, 2).reshape(B * T, -1).contiguous()
-    return A, (B, T, h, w, D, heads)
+    return torch.cat(cols, dim=1).transpose(1, 2).reshape(B * (H // p) * (W // p), -1).contiguous()
 
 
 def forward_fp32(model, image, points):
@@ -106,8 +101,10 @@ def forward_fp32(model, image, points):
         if fz.feats_injection_mode == "before_backbone":
             coord = model.maps_transform(model.get_coord_features(image, prev_mask, points))
         m = fz.model
-        A, (B, T, h, w, D, heads) = _vit(fz, cache, image, coord)
-        H, W = image.shape[2:]
+        A = _patch_matrix(fz, image, coord)
+        B, _, H, W = image.shape
+        h, w = H // fz.patch_size, W // fz.patch_size
+        T, D, heads = h * w, m.embed_dim, m.num_heads
         L = T + 1
         pw, pb = m.patch_embed.proj.weight, m.patch_embed.proj.bias
         if coord is not None:
