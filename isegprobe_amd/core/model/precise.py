@@ -10,9 +10,9 @@ split kernel on the way into the next contraction), the align_corners bilinear r
 torch is used for layout only (unfold, permute, padding copies).  Three to four times the work of the bf16 path and
 unfused: a checking mode, not the fast path.
 
-Scope: DINOv2 featurizer with clicks injected before the backbone (or none), identity / bilinear upsampler,
+Scope: DINOv2 featurizer with clicks injected before the backbone (or none), identity / bilinear / LiFT upsampler,
 ConvSegHead / SimpleConvSegHead -- BASELINE.json configs[0], the reference's own CPU-runnable configuration
-(models/sbd/dinov2/patch-embed_bilinear.py:40, core/model/iseg_probe_model.py:110-134).
+(models/sbd/dinov2/patch-embed_bilinear.py:40, core/model/iseg_probe_model.py:110-134), and the LiFT probes.
 """
 import torch
 import torch.nn.functional as F
@@ -84,16 +84,75 @@ def _patch_matrix(featurizer, image, coord):
     return torch.cat(cols, dim=1).transpose(1, 2).reshape(B * (H // p) * (W // p), -1).contiguous()
 
 
+def _conv3x3(cache, key, y, weight4d, bias, act, params):
+    """3x3 / pad 1 conv on fp32 NHWC `y` with weight [N, C, 3, 3] (already BatchNorm-folded where applicable); `act`
+    applies to the input on the way in.  -> fp32 NHWC [B, H, W, N]."""
+    B, H, W, C = y.shape
+    N = weight4d.shape[0]
+    w3 = cache.get(key, params, lambda: ops.split3(weight4d.detach().float().permute(0, 2, 3, 1).reshape(N * 9, C).contiguous(),
+                                                   weights=True)).view(N, -1)
+    a3 = ops.split3(y.reshape(-1, C), act=act).view(B, H, W, -1)
+    return ops.conv3x3(a3, w3, bias.detach().float().contiguous(), None, out_dtype=torch.float32)
+
+
+def _conv3x3_s2(cache, key, x_nchw, weight4d, bias, params):
+    """3x3 / stride 2 / pad 1 conv on fp32 NCHW planes as im2col (unfold: layout only) + one split GEMM -> fp32 NCHW."""
+    B, C, H, W = x_nchw.shape
+    N = weight4d.shape[0]
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    A = F.unfold(x_nchw, 3, padding=1, stride=2).transpose(1, 2).reshape(B * Ho * Wo, C * 9).contiguous()
+    w3 = cache.get(key, params, lambda: ops.split3(weight4d.detach().float().flatten(1).contiguous(), weights=True))
+    y = ops.linear(ops.split3(A), w3, bias.detach().float().contiguous(), None, out_dtype=torch.float32)
+    return y.view(B, Ho, Wo, N).permute(0, 3, 1, 2).contiguous()
+
+
+def _lift(up, cache, feats_nhwc, image):
+    """LiFT(imgs=image, x=features) (reference LiFT.py:106-122) in fp32-accurate arithmetic -> fp32 NHWC [B,2h,2w,C].
+    Eval-mode BatchNorm is folded into the conv weights (as on the bf16 path); ReLU on a materialised tensor and the
+    adaptive max pool (a selection, exact in any precision) go through torch."""
+    from .upsamplers.LiFT import _fold
+    L = up.lift
+    B, h, w, C = feats_nhwc.shape
+    bn_params = lambda conv, bn: (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    def folded(name, conv, bn):
+        return cache.get(("lift_fold", name), bn_params(conv, bn), lambda: _fold(conv, bn))
+    g = image.float().contiguous()
+    w1, b1 = folded("ic1a", L.image_convs_1[0], L.image_convs_1[1])
+    a = torch.relu_(_conv3x3_s2(cache, ("lift", "ic1a"), g, w1, b1, bn_params(L.image_convs_1[0], L.image_convs_1[1])))
+    w2, b2 = folded("ic1b", L.image_convs_1[3], L.image_convs_1[4])
+    a = torch.relu_(_conv3x3_s2(cache, ("lift", "ic1b"), a, w2, b2, bn_params(L.image_convs_1[3], L.image_convs_1[4])))
+    i1 = F.adaptive_max_pool2d(a, (2 * h, 2 * w))                                   # [B,32,2h,2w]
+    w3_, b3 = folded("ic2", L.image_convs_2[0], L.image_convs_2[1])
+    i2 = torch.relu_(_conv3x3_s2(cache, ("lift", "ic2"), i1, w3_, b3, bn_params(L.image_convs_2[0], L.image_convs_2[1])))
+    xin = torch.cat((feats_nhwc, i2.permute(0, 2, 3, 1)), dim=3).reshape(B * h * w, C + 32).contiguous()
+    upw, upb = L.up1.up.weight, L.up1.up.bias                                        # ConvTranspose2d [cin, n, 2, 2]
+    n = upw.shape[1]
+    wup3 = cache.get(("lift", "up"), (upw,), lambda: ops.split3(
+        upw.detach().float().permute(2, 3, 1, 0).reshape(4 * n, C + 32).contiguous(), weights=True))
+    t = ops.linear(ops.split3(xin), wup3, upb.detach().float().repeat(4).contiguous(), None, out_dtype=torch.float32)
+    t = t.view(B, h, w, 2, 2, n).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * h, 2 * w, n)   # the four taps -> pixel shuffle
+    cat = torch.cat((t, i1.permute(0, 2, 3, 1)), dim=3).contiguous()
+    dc = L.up1.conv_1.double_conv
+    wa, ba = folded("dc1", dc[0], dc[1])
+    y = _conv3x3(cache, ("lift", "dc1"), cat, wa, ba, None, bn_params(dc[0], dc[1]))
+    wb, bb = folded("dc2", dc[3], dc[4])
+    y = _conv3x3(cache, ("lift", "dc2"), y, wb, bb, "relu", bn_params(dc[3], dc[4]))
+    wo3 = _w3(cache, ("lift", "outc"), lambda: L.outc.weight.flatten(1), L.outc.weight)
+    out = _linear(y.reshape(-1, y.shape[3]), wo3, L.outc.bias.detach().float().contiguous(), act="relu")
+    return out.view(B, 2 * h, 2 * w, C)
+
+
 def forward_fp32(model, image, points):
     """iSegProbeModel.forward (iseg_base_model.py:67-89 + iseg_probe_model.py:110-134) with fp32-accurate arithmetic."""
     from .featurizers import DINOv2Featurizer
     from .heads.conv_heads import _StackedHead
     from .upsamplers.basic_upsamplers import BilinearUpsampler, IdentityUpsampler
+    from .upsamplers.LiFT import LiFTUpsampler
     fz, head, up = model.backbone, model.head, model.upsampler
     if not isinstance(fz, DINOv2Featurizer) or fz.feats_injection_mode not in ("before_backbone", "no_injection"):
         raise IspError("forward_fp32 covers the DINOv2 featurizer with clicks injected before the backbone (or none)")
-    if not isinstance(up, (BilinearUpsampler, IdentityUpsampler)) or not isinstance(head, _StackedHead):
-        raise IspError("forward_fp32 covers the identity / bilinear upsamplers and the stacked conv heads")
+    if not isinstance(up, (BilinearUpsampler, IdentityUpsampler, LiFTUpsampler)) or not isinstance(head, _StackedHead):
+        raise IspError("forward_fp32 covers the identity / bilinear / LiFT upsamplers and the stacked conv heads")
     cache = model.__dict__.setdefault("_fp32_splits", _WeightSplits())
     with torch.no_grad():
         image, prev_mask = model.prepare_input(image)
@@ -133,12 +192,14 @@ def forward_fp32(model, image, points):
                       f32(blk.mlp.fc2.bias), g2, act="gelu")
         feats = ops.layernorm(x, f32(m.norm.weight), f32(m.norm.bias), LN_EPS, out_dtype=torch.float32,
                               group_out=T, skip=1, rows_out=B * T)  # [B*T, D] = NHWC [B,h,w,D]
-        if isinstance(up, BilinearUpsampler) and (h, w) != (H, W):
-            planes = feats.view(B, h, w, D).permute(0, 3, 1, 2).contiguous()
-            planes = ops.resize_bilinear_nchw_f32(planes, H, W)
+        y = feats.view(B, h, w, D)
+        if isinstance(up, LiFTUpsampler):
+            y = _lift(up, cache, y, image)
+        if not isinstance(up, IdentityUpsampler) and tuple(y.shape[1:3]) != (H, W):
+            # BilinearUpsampler.forward (basic_upsamplers.py:28-33) / the model's resize of a learned upsampler's
+            # output to the image size (iseg_probe_model.py:120-129): bilinear, align_corners=True, on fp32 planes
+            planes = ops.resize_bilinear_nchw_f32(y.permute(0, 3, 1, 2).contiguous(), H, W)
             y = planes.permute(0, 2, 3, 1).contiguous()
-        else:
-            y = feats.view(B, h, w, D)
         Bh, Hh, Wh, C = y.shape
         act = None
         for j, layer in enumerate(head.convs):
