@@ -224,6 +224,10 @@ int isp_minmax_nchw_f32(const float* x, float* out_c2, float* workspace, int B, 
 int isp_loftup_fourier_cn(const float* image, const float* minmax_c2, const float* freqs, const float* bias_sin,
                           const float* bias_cos, const float* gamma, const float* beta, void* out_bf16, int B, int H,
                           int W, int n_freqs, int ldo, float eps, void* stream);
+/* same, fp32 output (the fp32 checking mode) */
+int isp_loftup_fourier_cn_f32(const float* image, const float* minmax_c2, const float* freqs, const float* bias_sin,
+                              const float* bias_cos, const float* gamma, const float* beta, float* out_f32, int B, int H, int W,
+                              int n_freqs, int ldo, float eps, void* stream);
 
 /* ---- LiFT image pyramid (LiFT.py:70-91,106-112): 3x3 / stride 2 / pad 1 conv to 32 channels with
  * folded eval-BatchNorm + ReLU (input NCHW f32 with 3 channels, or NHWC bf16 with 32), weights

@@ -84,6 +84,7 @@ SIGNATURES = {
     "isp_fuse_flip_sigmoid": [_vp, _vp, _l, _i, _i, _i, _vp],
     "isp_minmax_nchw_f32": [_vp, _vp, _vp, _i, _i, _l, _vp],
     "isp_loftup_fourier_cn": [_vp] * 8 + [_i, _i, _i, _i, _i, _f, _vp],
+    "isp_loftup_fourier_cn_f32": [_vp] * 8 + [_i, _i, _i, _i, _i, _f, _vp],
     "isp_conv3x3_s2_c32": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "isp_adaptive_max_pool_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_tn_gemm_bf16_atomic": [_vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _i, _i, _i, _i, _i, _vp],

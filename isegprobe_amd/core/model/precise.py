@@ -10,9 +10,10 @@ split kernel on the way into the next contraction), the align_corners bilinear r
 torch is used for layout only (unfold, permute, padding copies).  Three to four times the work of the bf16 path and
 unfused: a checking mode, not the fast path.
 
-Scope: DINOv2 featurizer with clicks injected before the backbone (or none), identity / bilinear / LiFT upsampler,
+Scope: DINOv2 featurizer with clicks injected before the backbone (or none), identity / bilinear / LiFT / LoftUp upsampler,
 ConvSegHead / SimpleConvSegHead -- BASELINE.json configs[0], the reference's own CPU-runnable configuration
-(models/sbd/dinov2/patch-embed_bilinear.py:40, core/model/iseg_probe_model.py:110-134), and the LiFT probes.
+(models/sbd/dinov2/patch-embed_bilinear.py:40, core/model/iseg_probe_model.py:110-134), and the LiFT / LoftUp probes
+(configs[2]-[4]).  FeatUp JBU has no fp32 mode (its kernel records and apply are bf16 by construction).
 """
 import torch
 import torch.nn.functional as F
@@ -142,17 +143,107 @@ def _lift(up, cache, feats_nhwc, image):
     return out.view(B, 2 * h, 2 * w, C)
 
 
+def _cross_attention(q, k, v, B, Lq, Lk, heads, hd, scale):
+    """nn.MultiheadAttention's core (loftup/layers.py:186-202): per (batch, head) softmax(q k^T * scale) v on fp32
+    [B*Lq, heads*hd] queries and [B*Lk, heads*hd] keys / values (hd need not be a multiple of anything)."""
+    dev = q.device
+    Lkp, hdp = (Lk + 3) // 4 * 4, (hd + 3) // 4 * 4
+    out = torch.empty(B * Lq, heads * hd, device=dev, dtype=torch.float32)
+    kp = torch.zeros(Lkp, hd, device=dev, dtype=torch.float32)
+    vt = torch.zeros(hdp, Lkp, device=dev, dtype=torch.float32)
+    o = torch.empty(Lq, hdp, device=dev, dtype=torch.float32)
+    for b in range(B):
+        for h in range(heads):
+            sl = slice(h * hd, (h + 1) * hd)
+            kp[:Lk].copy_(k[b * Lk:(b + 1) * Lk, sl])
+            vt[:hd, :Lk].copy_(v[b * Lk:(b + 1) * Lk, sl].t())
+            s = ops.linear(ops.split3(q[b * Lq:(b + 1) * Lq, sl], scale=scale), ops.split3(kp, weights=True), None, None,
+                           out_dtype=torch.float32)
+            ops.softmax_rows_(s, Lk)
+            ops.gemm(ops.split3(s), ops.split3(vt, weights=True), ops._epilogue(EP_BIAS_F32, o, hdp, None))
+            out[b * Lq:(b + 1) * Lq, sl].copy_(o[:, :hd])
+    return out
+
+
+def _loftup(up, cache, feats_nhwc, image):
+    """LoftUp.forward + the channel-norm wrapper (reference loftup/loftup.py:100-149, layers.py) in fp32-accurate
+    arithmetic -> fp32 NHWC [B,H,W,C].  Eval BatchNorm folded; ReLU on the materialised query map goes through torch."""
+    lu, cn = up.upsampler.upsampler, up.upsampler.channelnorm
+    B, h, w, C = feats_nhwc.shape
+    g = image.float().contiguous()
+    H, W = g.shape[2:]
+    heads = lu.num_heads
+    c = C + lu.lr_pe_dim
+    hd = c // heads
+    M, T = B * H * W, h * w
+    f32 = lambda t: t.detach().float().contiguous()
+    dev = g.device
+    # LR tokens: ChannelNorm(source) ++ sine PE of the LR grid (a table of the learnt biases and (h, w))
+    kv = torch.empty(B, T, c, device=dev, dtype=torch.float32)
+    kv[:, :, :C] = ops.layernorm(feats_nhwc.reshape(-1, C), f32(cn.norm.weight), f32(cn.norm.bias), cn.norm.eps,
+                                 out_dtype=torch.float32).view(B, T, C)
+    gh, gw = torch.linspace(-1, 1, h, device=dev), torch.linspace(-1, 1, w, device=dev)
+    grid = torch.stack(torch.meshgrid(gh, gw, indexing="ij"))
+    fr = torch.exp(torch.linspace(-2, 10, 5, device=dev)).reshape(5, 1, 1, 1)
+    pb = lu.lr_pe.biases.detach().float()
+    pe = torch.cat([torch.sin(grid.unsqueeze(0) * fr + pb[0].reshape(5, 2, 1, 1)).reshape(10, h, w),
+                    torch.cos(grid.unsqueeze(0) * fr + pb[1].reshape(5, 2, 1, 1)).reshape(10, h, w)], 0)
+    kv[:, :, C:] = pe.permute(1, 2, 0).reshape(T, 20)
+    kv = kv.view(B * T, c)
+    # queries: Fourier features -> ChannelNorm -> 2 x (conv3x3 + folded BN + ReLU)
+    fin = 10 * lu.n_freqs + 3
+    ff = lu.fourier_feat[1]
+    fc = lu.first_conv
+    x = ops.loftup_fourier_cn(g, ops.minmax_nchw(g), torch.exp(torch.linspace(-2, 10, lu.n_freqs)).to(dev),
+                              f32(ff.biases[0].reshape(-1)), f32(ff.biases[1].reshape(-1)), f32(fc[0].norm.weight),
+                              f32(fc[0].norm.bias), fin, fc[0].norm.eps, out_dtype=torch.float32)
+
+    def fold(conv, bn):
+        sc = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+        return (conv.weight.detach().float() * sc[:, None, None, None],
+                (conv.bias.detach().float() - bn.running_mean.float()) * sc + bn.bias.detach().float())
+    bnp = lambda conv, bn: (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    w1, b1 = cache.get(("loftup_fold", 1), bnp(fc[1], fc[2]), lambda: fold(fc[1], fc[2]))
+    w2, b2 = cache.get(("loftup_fold", 2), bnp(fc[4], fc[5]), lambda: fold(fc[4], fc[5]))
+    x = _conv3x3(cache, ("loftup", "conv1"), x, w1, b1, None, bnp(fc[1], fc[2]))
+    x = _conv3x3(cache, ("loftup", "conv2"), x, w2, b2, "relu", bnp(fc[4], fc[5]))
+    x = torch.relu_(x).view(M, c)
+    scale = hd ** -0.5
+    for li, (ca, ffn) in enumerate(lu.ca_transformer.layers):
+        ipw, ipb = ca.attention.in_proj_weight, ca.attention.in_proj_bias
+        qn = ops.layernorm(x, f32(ca.norm_q.weight), f32(ca.norm_q.bias), ca.norm_q.eps, out_dtype=torch.float32)
+        kn = ops.layernorm(kv, f32(ca.norm_kv.weight), f32(ca.norm_kv.bias), ca.norm_kv.eps, out_dtype=torch.float32)
+        wq, wk, wv = (_w3(cache, ("loftup", li, n), lambda i=i: ipw[i * c:(i + 1) * c], ipw) for i, n in enumerate("qkv"))
+        q = _linear(qn, wq, f32(ipb[:c]))
+        k = _linear(kn, wk, f32(ipb[c:2 * c]))
+        v = _linear(kn, wv, f32(ipb[2 * c:]))
+        a = _cross_attention(q, k, v, B, H * W, T, heads, hd, scale)
+        op = ca.attention.out_proj
+        _residual(x, a, _w3(cache, ("loftup", li, "o"), lambda: op.weight, op.weight), f32(op.bias), None)  # x += attn
+        n0, l1, l2 = ffn.net[0], ffn.net[1], ffn.net[4]
+        f = ops.layernorm(x, f32(n0.weight), f32(n0.bias), n0.eps, out_dtype=torch.float32)
+        f = _linear(f, _w3(cache, ("loftup", li, "ff1"), lambda: l1.weight, l1.weight), f32(l1.bias))
+        _residual(x, f, _w3(cache, ("loftup", li, "ff2"), lambda: l2.weight, l2.weight), f32(l2.bias), None, act="gelu")
+    nrm = lu.ca_transformer.norm
+    xn = ops.layernorm(x, f32(nrm.weight), f32(nrm.bias), nrm.eps, out_dtype=torch.float32)
+    fcv, fln = lu.final_conv[0], lu.final_conv[1]
+    y = _linear(xn, _w3(cache, ("loftup", "fin"), lambda: fcv.weight.flatten(1), fcv.weight), f32(fcv.bias))
+    out = ops.layernorm(y, f32(fln.weight), f32(fln.bias), fln.eps, out_dtype=torch.float32)
+    return out.view(B, H, W, C)
+
+
 def forward_fp32(model, image, points):
     """iSegProbeModel.forward (iseg_base_model.py:67-89 + iseg_probe_model.py:110-134) with fp32-accurate arithmetic."""
     from .featurizers import DINOv2Featurizer
     from .heads.conv_heads import _StackedHead
     from .upsamplers.basic_upsamplers import BilinearUpsampler, IdentityUpsampler
     from .upsamplers.LiFT import LiFTUpsampler
+    from .upsamplers.LoftUp import LoftUpUpsampler
     fz, head, up = model.backbone, model.head, model.upsampler
     if not isinstance(fz, DINOv2Featurizer) or fz.feats_injection_mode not in ("before_backbone", "no_injection"):
         raise IspError("forward_fp32 covers the DINOv2 featurizer with clicks injected before the backbone (or none)")
-    if not isinstance(up, (BilinearUpsampler, IdentityUpsampler, LiFTUpsampler)) or not isinstance(head, _StackedHead):
-        raise IspError("forward_fp32 covers the identity / bilinear / LiFT upsamplers and the stacked conv heads")
+    if not isinstance(up, (BilinearUpsampler, IdentityUpsampler, LiFTUpsampler, LoftUpUpsampler)) or not isinstance(head, _StackedHead):
+        raise IspError("forward_fp32 covers the identity / bilinear / LiFT / LoftUp upsamplers and the stacked conv heads")
     cache = model.__dict__.setdefault("_fp32_splits", _WeightSplits())
     with torch.no_grad():
         image, prev_mask = model.prepare_input(image)
@@ -195,6 +286,8 @@ def forward_fp32(model, image, points):
         y = feats.view(B, h, w, D)
         if isinstance(up, LiFTUpsampler):
             y = _lift(up, cache, y, image)
+        elif isinstance(up, LoftUpUpsampler):
+            y = _loftup(up, cache, y, image)
         if not isinstance(up, IdentityUpsampler) and tuple(y.shape[1:3]) != (H, W):
             # BilinearUpsampler.forward (basic_upsamplers.py:28-33) / the model's resize of a learned upsampler's
             # output to the image size (iseg_probe_model.py:120-129): bilinear, align_corners=True, on fp32 planes

@@ -58,13 +58,14 @@ __device__ __forceinline__ float linspace_pm1(int i, int n) {
 // output row of `ldo` bf16 (channels past 203 zero-filled).
 //   feats5 = [grid_h, grid_w, c0, c1, c2],  ci = (img - lo_i) / max(hi_i - lo_i, 1e-4) - 0.5
 //   sin block: idx = f*5 + m -> sin(feats5[m] * freq[f] + bias_sin[idx]);  cos block likewise.
+template <class TOut>  // bf16 (product path) or fp32 (the fp32 checking mode, core/model/precise.py)
 __global__ __launch_bounds__(256) void loftup_fourier_cn_kernel(const float* __restrict__ img,
                                                                  const float* __restrict__ mm /* [3][2] lo,hi */,
                                                                  const float* __restrict__ freqs,
                                                                  const float* __restrict__ bias_sin,
                                                                  const float* __restrict__ bias_cos,
                                                                  const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                                 const float* __restrict__ beta, TOut* __restrict__ out,
                                                                  int H, int W, int F, int ldo, float eps, long npix) {
     const int lane = threadIdx.x & 63;
     const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -113,11 +114,15 @@ __global__ __launch_bounds__(256) void loftup_fourier_cn_kernel(const float* __r
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     const float rstd = 1.0f / sqrtf(sq / (float)nfeat + eps);
-    bf16_t* orow = out + pix * ldo;
+    TOut* orow = out + pix * ldo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ch = lane + 64 * i;
-        if (ch < ldo) orow[ch] = ch < nfeat ? f2bf((v[i] - mean) * rstd * gamma[ch] + beta[ch]) : (bf16_t)0;
+        if (ch < ldo) {
+            const float o = ch < nfeat ? (v[i] - mean) * rstd * gamma[ch] + beta[ch] : 0.f;
+            if constexpr (sizeof(TOut) == 4) orow[ch] = o;
+            else orow[ch] = f2bf(o);
+        }
     }
 }
 
@@ -140,7 +145,18 @@ extern "C" int isp_loftup_fourier_cn(const float* image, const float* minmax_c2,
     ISP_CHECK_ARG(image && minmax_c2 && freqs && bias_sin && bias_cos && gamma && beta && out_bf16);
     ISP_CHECK_ARG(B > 0 && H > 0 && W > 0 && n_freqs > 0 && 10 * n_freqs + 3 <= 256 && ldo >= 10 * n_freqs + 3 && ldo <= 256);
     const long npix = (long)B * H * W;
-    loftup_fourier_cn_kernel<<<(unsigned)((npix + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+    loftup_fourier_cn_kernel<bf16_t><<<(unsigned)((npix + 3) / 4), 256, 0, (hipStream_t)stream>>>(
         image, minmax_c2, freqs, bias_sin, bias_cos, gamma, beta, (bf16_t*)out_bf16, H, W, n_freqs, ldo, eps, npix);
+    return isp_launch_status();
+}
+
+extern "C" int isp_loftup_fourier_cn_f32(const float* image, const float* minmax_c2, const float* freqs, const float* bias_sin,
+                                         const float* bias_cos, const float* gamma, const float* beta, float* out_f32, int B,
+                                         int H, int W, int n_freqs, int ldo, float eps, void* stream) {
+    ISP_CHECK_ARG(image && minmax_c2 && freqs && bias_sin && bias_cos && gamma && beta && out_f32);
+    ISP_CHECK_ARG(B > 0 && H > 0 && W > 0 && n_freqs > 0 && 10 * n_freqs + 3 <= 256 && ldo >= 10 * n_freqs + 3 && ldo <= 256);
+    const long npix = (long)B * H * W;
+    loftup_fourier_cn_kernel<float><<<(unsigned)((npix + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+        image, minmax_c2, freqs, bias_sin, bias_cos, gamma, beta, out_f32, H, W, n_freqs, ldo, eps, npix);
     return isp_launch_status();
 }

@@ -632,14 +632,14 @@ def minmax_nchw(x):
     return out
 
 
-def loftup_fourier_cn(image, mm, freqs, bias_sin, bias_cos, gamma, beta, ldo, eps=1e-5):
-    """image [B,3,H,W] f32 -> ChannelNorm(Fourier features) [B,H,W,ldo] bf16 (zero-padded channels)."""
+def loftup_fourier_cn(image, mm, freqs, bias_sin, bias_cos, gamma, beta, ldo, eps=1e-5, out_dtype=BF16):
+    """image [B,3,H,W] f32 -> ChannelNorm(Fourier features) [B,H,W,ldo] bf16 (or fp32), zero-padded channels."""
     _need(image, torch.float32, "image")
     B, _, H, W = image.shape
-    out = torch.empty(B, H, W, ldo, device=image.device, dtype=BF16)
-    check(_lib.lib().isp_loftup_fourier_cn(_p(image), _p(mm), _p(freqs), _p(bias_sin), _p(bias_cos), _p(gamma),
-                                           _p(beta), _p(out), B, H, W, freqs.numel(), ldo, float(eps), _stream()),
-          "isp_loftup_fourier_cn")
+    out = torch.empty(B, H, W, ldo, device=image.device, dtype=out_dtype)
+    fn = _lib.lib().isp_loftup_fourier_cn if out_dtype == BF16 else _lib.lib().isp_loftup_fourier_cn_f32
+    check(fn(_p(image), _p(mm), _p(freqs), _p(bias_sin), _p(bias_cos), _p(gamma), _p(beta), _p(out), B, H, W,
+             freqs.numel(), ldo, float(eps), _stream()), "isp_loftup_fourier_cn")
     return out
 
 
