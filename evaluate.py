@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--logs", default=None, help="directory for the results table / IoU pickles (default: a temp dir)")
     ap.add_argument("--host-clicker", action="store_true",
                     help="robot user + IoU on the host (numpy/scipy) as in the reference, instead of the device clicker")
+    ap.add_argument("--fp32", action="store_true",
+                    help="checking mode: fp32-accurate arithmetic (model.forward_fp32, three bf16 products; 3-4x slower)")
     args = ap.parse_args()
 
     import isegprobe_amd
@@ -62,6 +64,8 @@ def main():
             upsampler_cfg={"type": args.upsampler, "params": up_params},
             use_disks=True, norm_radius=5, with_prev_mask=True)
     model = model.to(device).eval()
+    if args.fp32:  # the predictor calls net(image, points): route it through the fp32-accurate forward
+        model.forward = model.forward_fp32
 
     tmp = None
     if args.synthetic:
