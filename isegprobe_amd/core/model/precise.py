@@ -240,16 +240,19 @@ def forward_fp32(model, image, points):
     from .upsamplers.LiFT import LiFTUpsampler
     from .upsamplers.LoftUp import LoftUpUpsampler
     fz, head, up = model.backbone, model.head, model.upsampler
-    if not isinstance(fz, DINOv2Featurizer) or fz.feats_injection_mode not in ("before_backbone", "no_injection"):
-        raise IspError("forward_fp32 covers the DINOv2 featurizer with clicks injected before the backbone (or none)")
+    if not isinstance(fz, DINOv2Featurizer) or fz.feats_injection_mode not in ("before_backbone", "after_backbone",
+                                                                                "no_injection"):
+        raise IspError("forward_fp32 covers the DINOv2 featurizer (clicks before / after the backbone, or none)")
     if not isinstance(up, (BilinearUpsampler, IdentityUpsampler, LiFTUpsampler, LoftUpUpsampler)) or not isinstance(head, _StackedHead):
         raise IspError("forward_fp32 covers the identity / bilinear / LiFT / LoftUp upsamplers and the stacked conv heads")
     cache = model.__dict__.setdefault("_fp32_splits", _WeightSplits())
     with torch.no_grad():
         image, prev_mask = model.prepare_input(image)
-        coord = None
+        coord = coord_after = None
         if fz.feats_injection_mode == "before_backbone":
             coord = model.maps_transform(model.get_coord_features(image, prev_mask, points))
+        elif fz.feats_injection_mode == "after_backbone":  # DINOv2.py:509-516: click tokens added to the final features
+            coord_after = model.maps_transform(model.get_coord_features(image, prev_mask, points))
         m = fz.model
         A = _patch_matrix(fz, image, coord)
         B, _, H, W = image.shape
@@ -283,6 +286,11 @@ def forward_fp32(model, image, points):
                       f32(blk.mlp.fc2.bias), g2, act="gelu")
         feats = ops.layernorm(x, f32(m.norm.weight), f32(m.norm.bias), LN_EPS, out_dtype=torch.float32,
                               group_out=T, skip=1, rows_out=B * T)  # [B*T, D] = NHWC [B,h,w,D]
+        if coord_after is not None:
+            p_ = fz.patch_size
+            Ac = F.unfold(coord_after, p_, stride=p_).transpose(1, 2).reshape(B * T, -1).contiguous()
+            cw, cb = model.embed_coords.proj.weight, model.embed_coords.proj.bias
+            feats = feats + _linear(Ac, _w3(cache, "embed_after", lambda: cw.flatten(1), cw), f32(cb))
         y = feats.view(B, h, w, D)
         if isinstance(up, LiFTUpsampler):
             y = _lift(up, cache, y, image)

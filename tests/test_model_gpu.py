@@ -220,6 +220,26 @@ def test_tiny_lift_model_vs_golden(golden):
     assert _mask_agreement(y, ref, TOL_TINY) == 1.0
 
 
+@pytest.mark.parametrize("up", ["bilinear", "identity", "bilinear_after", "lift", "loftup"])
+def test_fp32_mode_vs_reference_golden(golden, up):
+    """forward_fp32 against logits produced by the REFERENCE's own code (tests/golden/gen_golden.py, fp32 on CPU):
+    north_star's "logits within 1e-3 fp32" on the fixture models, for every upsampler the fp32 mode covers and both
+    click-injection points."""
+    g = golden("model_tiny")
+    base = up.replace("_after", "")
+    params = {"lift": {"lift_path": None, "n_dim": 128, "patch": 14}, "loftup": {"upsampler_path": None, "n_dim": 128}}.get(base)
+    model = build_model(base, "after_backbone" if up.endswith("_after") else "before_backbone", upsampler_params=params)
+    missing, unexpected = model.load_state_dict({**weights_from(g, "common_w"), **weights_from(g, base + "_w")}, strict=False)
+    assert not unexpected and all(("mask_token" in k or "num_batches_tracked" in k) for k in missing), missing
+    y = model.cuda().forward_fp32(torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["points"]).cuda())["instances"].cpu()
+    ref = torch.from_numpy(g[up + "_logits"])
+    assert y.shape == ref.shape
+    err = (y - ref).abs()
+    print(f"fp32 mode vs reference golden [{up}]: max {err.max():.3g} rms {err.pow(2).mean().sqrt():.3g} "
+          f"(ref rms {ref.pow(2).mean().sqrt():.3f})")
+    assert err.max().item() < 1e-3
+
+
 @pytest.mark.parametrize("feat_type", ["key", "token"])
 @pytest.mark.parametrize("inj", ["before_backbone", "after_backbone"])
 def test_dino_vit_featurizer_vs_golden(golden, feat_type, inj):
