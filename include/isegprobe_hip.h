@@ -294,6 +294,16 @@ long isp_next_points_workspace_bytes(int B, int H, int W);
 int isp_next_points(const float* pred, const float* gt, float* points, const unsigned* rand32, int B, int H, int W, int P,
                     int click_indx, float pred_thresh, void* workspace, void* stream);
 
+/* ---- FeatUp JBU stage in plain fp32, as the published algorithm states it (the fp32 checking mode and an on-device
+ * cross-check of the composite-kernel formulation above): per-pixel 49-tap kernels k [B,GH,GW,49] from proj [B,GH,GW,32]
+ * and the pooled guidance [B,3,GH,GW] (fix-up MLP weights fp32: fixup_proj.0 [49,52], fixup_proj.3 [49,49]);
+ * F.interpolate(bicubic, align_corners=False) x2 on NHWC fp32; the reflect-padded 7x7 adaptive convolution. */
+int isp_jbu_kernels_f32(const float* proj, const float* guidance, float* k_out, const float* fix0_w, const float* fix0_b,
+                        const float* fix3_w, const float* fix3_b, float range_temp, float sigma_spatial, int B, int GH, int GW,
+                        void* stream);
+int isp_bicubic_x2_nhwc_f32(const float* src, float* out, int B, int h, int w, int C, void* stream);
+int isp_adaptive_conv7_nhwc_f32(const float* hr, const float* k49, float* out, int B, int GH, int GW, int C, void* stream);
+
 /* ---- fp32-accurate products on the bf16 engine (core/model/precise.py; the "logits within 1e-3 fp32" gate of the
  * reference comparison).  isp_split_bf16x3 writes an fp32 [rows, K] matrix (row stride ld_in) as bf16 [rows, 3*Kpad]:
  * activations layout [hi | hi | lo] (weights_layout = 0) or weights layout [hi | lo | hi] (1), hi = bf16(v),

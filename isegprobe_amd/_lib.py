@@ -58,6 +58,9 @@ SIGNATURES = {
     "isp_conv3x3_wgrad_bf16_atomic": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "isp_next_points_workspace_bytes": [_i, _i, _i],
     "isp_next_points": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
+    "isp_jbu_kernels_f32": [_vp] * 7 + [_f, _f, _i, _i, _i, _vp],
+    "isp_bicubic_x2_nhwc_f32": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "isp_adaptive_conv7_nhwc_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "isp_split_bf16x3": [_vp, _l, _vp, _l, _i, _i, _i, _i, _f, _vp],
     "isp_softmax_rows_f32": [_vp, _l, _i, _l, _vp],
     "isp_probe_mfma_bf16": [_vp, _vp, _i, _i, _vp],

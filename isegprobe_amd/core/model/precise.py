@@ -10,10 +10,10 @@ split kernel on the way into the next contraction), the align_corners bilinear r
 torch is used for layout only (unfold, permute, padding copies).  Three to four times the work of the bf16 path and
 unfused: a checking mode, not the fast path.
 
-Scope: DINOv2 featurizer with clicks injected before the backbone (or none), identity / bilinear / LiFT / LoftUp upsampler,
+Scope: DINOv2 featurizer (clicks before / after the backbone, or none), identity / bilinear / LiFT / LoftUp / FeatUp-JBU upsampler,
 ConvSegHead / SimpleConvSegHead -- BASELINE.json configs[0], the reference's own CPU-runnable configuration
 (models/sbd/dinov2/patch-embed_bilinear.py:40, core/model/iseg_probe_model.py:110-134), and the LiFT / LoftUp probes
-(configs[2]-[4]).  FeatUp JBU has no fp32 mode (its kernel records and apply are bf16 by construction).
+(configs[1]-[4]).  FeatUp JBU runs as the published stage-by-stage algorithm in plain fp32 (csrc/jbu_f32.hip).
 """
 import torch
 import torch.nn.functional as F
@@ -232,6 +232,30 @@ def _loftup(up, cache, feats_nhwc, image):
     return out.view(B, H, W, C)
 
 
+def _jbu(up, cache, feats_nhwc, image):
+    """JBUStack.forward (FeatUp, called at JBUFeatUp.py:30-32 of the reference): four x2 stages on the image pooled to
+    each stage's size, then x + 0.1 * conv1x1(x) -- in plain fp32, stage by stage as the published algorithm states it
+    (csrc/jbu_f32.hip), not through the composite-kernel formulation of the product path."""
+    stack = up.upsampler
+    g = image.float().contiguous()
+    x = feats_nhwc.contiguous()
+    f32 = lambda t: t.detach().float().contiguous()
+    for st in (stack.up1, stack.up2, stack.up3, stack.up4):
+        B, h, w, C = x.shape
+        small = ops.adaptive_avg_pool(g, 2 * h, 2 * w)
+        proj = ops.jbu_range_proj(small, f32(st.range_proj[0].weight.flatten(1)), f32(st.range_proj[0].bias),
+                                  f32(st.range_proj[3].weight.flatten(1)), f32(st.range_proj[3].bias))
+        x = ops.jbu_stage_f32(x, proj, small, f32(st.fixup_proj[0].weight.flatten(1)), f32(st.fixup_proj[0].bias),
+                              f32(st.fixup_proj[3].weight.flatten(1)), f32(st.fixup_proj[3].bias),
+                              float(st.range_temp.item()), float(st.sigma_spatial.item()))
+    conv = stack.fixup_proj[1]
+    B, H, W, C = x.shape
+    y = x.reshape(-1, C).clone()
+    ops.linear_residual_(y, ops.split3(x.reshape(-1, C)), _w3(cache, ("jbu", "fix"), lambda: conv.weight.flatten(1), conv.weight),
+                         f32(conv.bias), torch.full((C,), 0.1, device=x.device, dtype=torch.float32))
+    return y.view(B, H, W, C)
+
+
 def forward_fp32(model, image, points):
     """iSegProbeModel.forward (iseg_base_model.py:67-89 + iseg_probe_model.py:110-134) with fp32-accurate arithmetic."""
     from .featurizers import DINOv2Featurizer
@@ -239,12 +263,14 @@ def forward_fp32(model, image, points):
     from .upsamplers.basic_upsamplers import BilinearUpsampler, IdentityUpsampler
     from .upsamplers.LiFT import LiFTUpsampler
     from .upsamplers.LoftUp import LoftUpUpsampler
+    from .upsamplers.JBUFeatUp import JBUFeatUpUpsampler
     fz, head, up = model.backbone, model.head, model.upsampler
     if not isinstance(fz, DINOv2Featurizer) or fz.feats_injection_mode not in ("before_backbone", "after_backbone",
                                                                                 "no_injection"):
         raise IspError("forward_fp32 covers the DINOv2 featurizer (clicks before / after the backbone, or none)")
-    if not isinstance(up, (BilinearUpsampler, IdentityUpsampler, LiFTUpsampler, LoftUpUpsampler)) or not isinstance(head, _StackedHead):
-        raise IspError("forward_fp32 covers the identity / bilinear / LiFT / LoftUp upsamplers and the stacked conv heads")
+    if not isinstance(up, (BilinearUpsampler, IdentityUpsampler, LiFTUpsampler, LoftUpUpsampler, JBUFeatUpUpsampler)) or \
+            not isinstance(head, _StackedHead):
+        raise IspError("forward_fp32 covers the identity / bilinear / LiFT / LoftUp / FeatUp-JBU upsamplers and the stacked conv heads")
     cache = model.__dict__.setdefault("_fp32_splits", _WeightSplits())
     with torch.no_grad():
         image, prev_mask = model.prepare_input(image)
@@ -296,6 +322,8 @@ def forward_fp32(model, image, points):
             y = _lift(up, cache, y, image)
         elif isinstance(up, LoftUpUpsampler):
             y = _loftup(up, cache, y, image)
+        elif isinstance(up, JBUFeatUpUpsampler):
+            y = _jbu(up, cache, y, image)
         if not isinstance(up, IdentityUpsampler) and tuple(y.shape[1:3]) != (H, W):
             # BilinearUpsampler.forward (basic_upsamplers.py:28-33) / the model's resize of a learned upsampler's
             # output to the image size (iseg_probe_model.py:120-129): bilinear, align_corners=True, on fp32 planes

@@ -807,3 +807,20 @@ def softmax_rows_(x, cols):
     _need(x, torch.float32, "x")
     check(_lib.lib().isp_softmax_rows_f32(_p(x), x.shape[0], cols, x.shape[1], _stream()), "isp_softmax_rows_f32")
     return x
+
+
+def jbu_stage_f32(src, proj, small, f0w, f0b, f3w, f3b, range_temp, sigma_spatial):
+    """One FeatUp-JBU stage in plain fp32: src [B,h,w,C] f32 NHWC, proj [B,2h,2w,32] f32 (jbu_range_proj of `small`),
+    small [B,3,2h,2w] f32 -> [B,2h,2w,C] f32 (per-pixel kernels, bicubic x2, adaptive 7x7 conv)."""
+    for t, n in ((src, "src"), (proj, "proj"), (small, "small"), (f0w, "f0w"), (f3w, "f3w")):
+        _need(t, torch.float32, n)
+    B, h, w, C = src.shape
+    GH, GW = 2 * h, 2 * w
+    k = torch.empty(B, GH, GW, 49, device=src.device, dtype=torch.float32)
+    check(_lib.lib().isp_jbu_kernels_f32(_p(proj), _p(small), _p(k), _p(f0w), _p(f0b), _p(f3w), _p(f3b), float(range_temp),
+                                         float(sigma_spatial), B, GH, GW, _stream()), "isp_jbu_kernels_f32")
+    hr = torch.empty(B, GH, GW, C, device=src.device, dtype=torch.float32)
+    check(_lib.lib().isp_bicubic_x2_nhwc_f32(_p(src), _p(hr), B, h, w, C, _stream()), "isp_bicubic_x2_nhwc_f32")
+    out = torch.empty_like(hr)
+    check(_lib.lib().isp_adaptive_conv7_nhwc_f32(_p(hr), _p(k), _p(out), B, GH, GW, C, _stream()), "isp_adaptive_conv7_nhwc_f32")
+    return out

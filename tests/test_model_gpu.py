@@ -102,13 +102,15 @@ def test_s14_bilinear_vs_oracle(size, B):
     assert _mask_agreement(y, ref) == 1.0
 
 
-@pytest.mark.parametrize("up,size,B", [("bilinear", 224, 2), ("identity", 224, 1), ("bilinear", 112, 2), ("lift", 224, 1), ("loftup", 224, 1)])
+@pytest.mark.parametrize("up,size,B", [("bilinear", 224, 2), ("identity", 224, 1), ("bilinear", 112, 2), ("lift", 224, 1), ("loftup", 224, 1),
+                                       ("jbu_featup", 224, 1), ("jbu_featup", 448, 1)])
 def test_s14_fp32_mode_vs_oracle(up, size, B):
     """north_star's fp32 gate: iSegProbeModel.forward_fp32 (fp32-accurate "three bf16 products" arithmetic on the
     same kernels) against the fp32 CPU oracle -- logits within 1e-3 (BASELINE.json configs[0]: DINOv2-S/14 + bilinear,
     fixed 224).  The bf16 product path on the same inputs is held to 1e-2 by the tests above."""
     from oracle import model as omodel
-    params = {"lift": {"lift_path": None, "n_dim": 384, "patch": 14}, "loftup": {"upsampler_path": None, "n_dim": 384}}.get(up)
+    params = {"lift": {"lift_path": None, "n_dim": 384, "patch": 14}, "loftup": {"upsampler_path": None, "n_dim": 384},
+              "jbu_featup": {"backbone_type": "dinov2"}}.get(up)
     model = build_model(up, vit=S14, img=(size, size), upsampler_params=params)
     seeded_(model, 321)
     with torch.no_grad():

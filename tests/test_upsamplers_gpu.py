@@ -113,6 +113,33 @@ def test_jbu_last_stage_fused_with_resize(h, w):
     assert tuple(other.shape) == (2, C, 16 * h, 16 * w)
 
 
+def test_jbu_composite_stage_vs_plain_fp32_stage():
+    """The product path's composite-kernel / MFMA JBU stage against the stage-by-stage fp32 kernels of csrc/jbu_f32.hip
+    (per-pixel 49-tap kernels, bicubic x2, adaptive 7x7 conv): two separate derivations of the published algorithm."""
+    from isegprobe_amd import hip_ops as ops
+    from isegprobe_amd.core.model.upsamplers import JBUFeatUpUpsampler
+    torch.manual_seed(3)
+    C = 128
+    up = seeded_(JBUFeatUpUpsampler("dinov2", feat_dim=C), 9).cuda()
+    st = up.upsampler.up2
+    with torch.no_grad():
+        st.range_temp.fill_(0.7)
+        st.sigma_spatial.fill_(0.9)
+    src = torch.randn(2, 12, 20, C, device="cuda")
+    g = torch.randn(2, 3, 90, 150, device="cuda")
+    f32 = lambda t: t.detach().float().contiguous()
+    small = ops.adaptive_avg_pool(g, 24, 40)
+    proj = ops.jbu_range_proj(small, f32(st.range_proj[0].weight.flatten(1)), f32(st.range_proj[0].bias),
+                              f32(st.range_proj[3].weight.flatten(1)), f32(st.range_proj[3].bias))
+    ref = ops.jbu_stage_f32(src.to(torch.bfloat16).float(), proj, small, f32(st.fixup_proj[0].weight.flatten(1)),
+                            f32(st.fixup_proj[0].bias), f32(st.fixup_proj[3].weight.flatten(1)), f32(st.fixup_proj[3].bias),
+                            0.7, 0.9)
+    y = st.run(src.to(torch.bfloat16), g).float()
+    err = (y - ref).abs()
+    assert err.max().item() < 3e-2 * max(1.0, ref.abs().max().item())
+    assert err.pow(2).mean().sqrt().item() < 5e-3 * max(1.0, ref.pow(2).mean().sqrt().item())
+
+
 def test_attention_hd256():
     """head_dim 197 zero-padded to 256: LoftUp(n_dim=768)'s cross-attention (BASELINE configs[4])."""
     from isegprobe_amd import hip_ops as ops
