@@ -72,6 +72,66 @@ def _attention(qkv, B, L, heads, scale):
     return out
 
 
+def _vit_trunk(fz, cache, x, B, T):
+    """The transformer blocks on the fp32 token stream x [B*(T+1), D] (block.py:92-117, attention.py:54-71, mlp.py:34-40;
+    modified in place) and the read-out: final LayerNorm with the cls row dropped (DINOv2.py:533-546), or, for the DINO
+    ViT-S/16 featurizer with feat_type="key", the keys of the last block (DINO.py:583-590).  -> fp32 [B*T, D]."""
+    from .featurizers.DINO import DINOFeaturizer
+    m = fz.model
+    D, heads = m.embed_dim, m.num_heads
+    if D // heads != 64:
+        raise IspError("forward_fp32 is built for head_dim 64")
+    L = T + 1
+    f32 = lambda t: t.detach().float().contiguous()
+    last_keys = isinstance(fz, DINOFeaturizer) and fz.feat_type == "key"
+    nblk = len(m.blocks)
+    for i, blk in enumerate(m.blocks):
+        g1 = f32(blk.ls1.gamma) if hasattr(blk.ls1, "gamma") else None
+        g2 = f32(blk.ls2.gamma) if hasattr(blk.ls2, "gamma") else None
+        y = ops.layernorm(x, f32(blk.norm1.weight), f32(blk.norm1.bias), LN_EPS, out_dtype=torch.float32)
+        qkv = _linear(y, _w3(cache, ("qkv", i), lambda: blk.attn.qkv.weight, blk.attn.qkv.weight), f32(blk.attn.qkv.bias))
+        if last_keys and i == nblk - 1:
+            k = qkv.view(B, L, 3, heads, 64)[:, 1:, 1]                     # [B,T,heads,64], cls removed
+            return k.permute(0, 1, 3, 2).reshape(B * T, D).contiguous()    # channel = d*heads + head
+        att = _attention(qkv, B, L, heads, 64 ** -0.5)
+        _residual(x, att, _w3(cache, ("proj", i), lambda: blk.attn.proj.weight, blk.attn.proj.weight),
+                  f32(blk.attn.proj.bias), g1)
+        y = ops.layernorm(x, f32(blk.norm2.weight), f32(blk.norm2.bias), LN_EPS, out_dtype=torch.float32)
+        hid = _linear(y, _w3(cache, ("fc1", i), lambda: blk.mlp.fc1.weight, blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias))
+        _residual(x, hid, _w3(cache, ("fc2", i), lambda: blk.mlp.fc2.weight, blk.mlp.fc2.weight),
+                  f32(blk.mlp.fc2.bias), g2, act="gelu")
+    return ops.layernorm(x, f32(m.norm.weight), f32(m.norm.bias), LN_EPS, out_dtype=torch.float32,
+                         group_out=T, skip=1, rows_out=B * T)  # [B*T, D] = NHWC [B,h,w,D]
+
+
+def featurizer_fp32(fz, image, additional_features=None):
+    """DINOv2Featurizer / DINOFeaturizer .forward(x, additional_features) (DINOv2.py:500-546, DINO.py:529-611) in
+    fp32-accurate arithmetic: image [B,3,H,W] (already normalised), click tokens [B,T,D] or None -> [B,D,h,w] fp32."""
+    cache = fz.__dict__.setdefault("_fp32_splits", _WeightSplits())
+    with torch.no_grad():
+        m = fz.model
+        p = fz.patch_size
+        image = image.float().contiguous()
+        B, _, H, W = image.shape
+        h, w = H // p, W // p
+        T, D = h * w, m.embed_dim
+        mode = fz.feats_injection_mode
+        inject = additional_features is not None and mode != "no_injection"
+        A = _patch_matrix(fz, image, None)
+        pw, pb = m.patch_embed.proj.weight, m.patch_embed.proj.bias
+        table, cls_row = fz._pos_embed(H, W)
+        x = torch.empty(B * (T + 1), D, device=image.device, dtype=torch.float32)
+        ops.gemm(ops.split3(A), _w3(cache, "embed_img", lambda: pw.flatten(1), pw),
+                 ops._epilogue(EP_TOKENS_F32, x, D, pb.detach().float().contiguous(), None, table, T))
+        x.view(B, T + 1, D)[:, 0].copy_(cls_row)
+        if inject and mode == "before_backbone":
+            x.view(B, T + 1, D)[:, 1:] += additional_features.float()
+        feats = _vit_trunk(fz, cache, x, B, T)
+        if inject and mode == "after_backbone":
+            feats = feats + additional_features.float().reshape(B * T, D)
+        return feats.view(B, h, w, D).permute(0, 3, 1, 2)
+
+
 def _patch_matrix(featurizer, image, coord):
     """im2col of the image (and, before-backbone injection, of [prev_mask | click maps]) for the patch embedding(s) as
     ONE GEMM over the concatenated K axis (DINOv2.py:518-523): fp32 [B*T, (3 + 3) * p * p].  unfold is layout only."""
@@ -298,20 +358,7 @@ def forward_fp32(model, image, points):
         ops.gemm(ops.split3(A), w3, ops._epilogue(EP_TOKENS_F32, x, D, bias, None, table, T))
         x.view(B, L, D)[:, 0].copy_(cls_row)
         f32 = lambda t: t.detach().float().contiguous()
-        for i, blk in enumerate(m.blocks):
-            g1 = f32(blk.ls1.gamma) if hasattr(blk.ls1, "gamma") else None
-            g2 = f32(blk.ls2.gamma) if hasattr(blk.ls2, "gamma") else None
-            y = ops.layernorm(x, f32(blk.norm1.weight), f32(blk.norm1.bias), LN_EPS, out_dtype=torch.float32)
-            qkv = _linear(y, _w3(cache, ("qkv", i), lambda: blk.attn.qkv.weight, blk.attn.qkv.weight), f32(blk.attn.qkv.bias))
-            att = _attention(qkv, B, L, heads, 64 ** -0.5)
-            _residual(x, att, _w3(cache, ("proj", i), lambda: blk.attn.proj.weight, blk.attn.proj.weight),
-                      f32(blk.attn.proj.bias), g1)
-            y = ops.layernorm(x, f32(blk.norm2.weight), f32(blk.norm2.bias), LN_EPS, out_dtype=torch.float32)
-            hid = _linear(y, _w3(cache, ("fc1", i), lambda: blk.mlp.fc1.weight, blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias))
-            _residual(x, hid, _w3(cache, ("fc2", i), lambda: blk.mlp.fc2.weight, blk.mlp.fc2.weight),
-                      f32(blk.mlp.fc2.bias), g2, act="gelu")
-        feats = ops.layernorm(x, f32(m.norm.weight), f32(m.norm.bias), LN_EPS, out_dtype=torch.float32,
-                              group_out=T, skip=1, rows_out=B * T)  # [B*T, D] = NHWC [B,h,w,D]
+        feats = _vit_trunk(fz, cache, x, B, T)
         if coord_after is not None:
             p_ = fz.patch_size
             Ac = F.unfold(coord_after, p_, stride=p_).transpose(1, 2).reshape(B * T, -1).contiguous()

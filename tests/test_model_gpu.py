@@ -260,6 +260,43 @@ def test_dino_vit_featurizer_vs_golden(golden, feat_type, inj):
     assert err < 3e-2 * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("inj", ["before_backbone", "after_backbone", "no_injection"])
+@pytest.mark.parametrize("tag", ["sq", "rect", "native"])
+def test_featurizer_fp32_mode_vs_reference_golden(golden, inj, tag):
+    """DINOv2 featurizer in the fp32 checking mode against the reference-generated features (1e-3 gate)."""
+    from isegprobe_amd.core.model.featurizers import DINOv2Featurizer
+    from isegprobe_amd.core.model.precise import featurizer_fp32
+    from helpers import TINY_VIT
+    g = golden("vit_tiny")
+    f = DINOv2Featurizer("custom", inj, vit_kwargs=TINY_VIT)
+    f.model.load_state_dict(weights_from(g, "w"), strict=False)
+    f = f.cuda().eval()
+    y = featurizer_fp32(f, torch.from_numpy(g[f"{inj}_{tag}_x"]).cuda(), torch.from_numpy(g[f"{inj}_{tag}_clicks"]).cuda()).cpu()
+    ref = torch.from_numpy(g[f"{inj}_{tag}_y"])
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("feat_type", ["key", "token"])
+@pytest.mark.parametrize("inj", ["before_backbone", "after_backbone"])
+def test_dino_vit_featurizer_fp32_mode_vs_reference_golden(golden, feat_type, inj):
+    """DINO ViT-S/16 featurizer (last-block keys or tokens) in the fp32 checking mode vs the reference-generated features."""
+    from isegprobe_amd.core.model.precise import featurizer_fp32
+    from isegprobe_amd.core.utils.model_builder import ModelBuilder
+    g = golden("dino_tiny")
+    f = ModelBuilder().load_featurizer("vit", dict(arch="vit_small", patch_size=16, feat_type=feat_type, feats_injection_mode=inj,
+                                                   vit_kwargs=dict(img_size=64, embed_dim=128, depth=2, num_heads=2)))
+    f.model.load_state_dict(weights_from(g, "w"))
+    f = f.cuda().eval()
+    tag = f"{feat_type}_{inj}"
+    y = featurizer_fp32(f, torch.from_numpy(g[tag + "_x"]).cuda(), torch.from_numpy(g[tag + "_clicks"]).cuda()).cpu()
+    ref = torch.from_numpy(g[tag + "_y"])
+    assert y.shape == ref.shape
+    err = (y - ref).abs().max().item()
+    print(f"DINO fp32 mode [{tag}]: max err {err:.3g} (ref max {ref.abs().max():.3g})")
+    assert err < 1e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_simple_vit_click_encoder_vs_golden(golden):
     from isegprobe_amd.core.utils.model_builder import ModelBuilder
     g = golden("simple_vit_tiny")
