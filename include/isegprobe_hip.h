@@ -307,7 +307,7 @@ int isp_adaptive_conv7_nhwc_f32(const float* hr, const float* k49, float* out, i
 /* ---- fp32-accurate products on the bf16 engine (core/model/precise.py; the "logits within 1e-3 fp32" gate of the
  * reference comparison).  isp_split_bf16x3 writes an fp32 [rows, K] matrix (row stride ld_in) as bf16 [rows, 3*Kpad]:
  * activations layout [hi | hi | lo] (weights_layout = 0) or weights layout [hi | lo | hi] (1), hi = bf16(v),
- * lo = bf16(v - hi), v = scale * act(x) with act 0 none / 1 ReLU / 2 GELU(erf); columns K..Kpad are zero.  A GEMM or conv
+ * lo = bf16(v - hi), v = scale * act(x) with act 0 none / 1 ReLU / 2 GELU(erf) / 3 QuickGELU; columns K..Kpad are zero.  A GEMM or conv
  * over the tripled depth then accumulates hi.whi + hi.wlo + lo.whi in fp32.  isp_softmax_rows_f32: in-place softmax over
  * the first `cols` entries of each fp32 row (the rest of the row, up to ld, is zeroed). */
 int isp_split_bf16x3(const float* x, long ld_in, void* out_bf16, long rows, int K, int Kpad, int weights_layout, int act,

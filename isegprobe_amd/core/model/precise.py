@@ -132,6 +132,58 @@ def featurizer_fp32(fz, image, additional_features=None):
         return feats.view(B, h, w, D).permute(0, 3, 1, 2)
 
 
+def maskclip_featurizer_fp32(fz, image, additional_features=None):
+    """MaskCLIPFeaturizer.forward (MaskCLIP.py:41-92, maskclip/model.py:251-263,321-430) in fp32-accurate arithmetic:
+    CLIP ViT with ln_pre, QuickGELU blocks, the last block's VALUE path only (no attention, no residual), ln_post and
+    the output projection -> [B, output_dim, h, w] fp32.  (The reference casts CLIP to fp16 on CUDA; the fixtures and
+    this mode are the fp32 computation.)"""
+    cache = fz.__dict__.setdefault("_fp32_splits", _WeightSplits())
+    with torch.no_grad():
+        v = fz.model.visual
+        p = fz.patch_size
+        image = image.float().contiguous()
+        B, _, H, W = image.shape
+        h, w = H // p, W // p
+        T, D, heads = h * w, v.width, v.heads
+        mode = fz.feats_injection_mode
+        before = additional_features is not None and mode == "before_backbone"
+        after = additional_features is not None and mode == "after_backbone"
+        f32 = lambda t: t.detach().float().contiguous()
+        table, cls_row = fz._pos(w, h, H, W) if before else fz._pos(h, w, H, W)  # (the reference's swapped grid, kept)
+        A = F.unfold(image, p, stride=p).transpose(1, 2).reshape(B * T, -1).contiguous()
+        x = torch.empty(B * (T + 1), D, device=image.device, dtype=torch.float32)
+        ops.gemm(ops.split3(A), _w3(cache, "conv1", lambda: v.conv1.weight.flatten(1), v.conv1.weight),
+                 ops._epilogue(EP_TOKENS_F32, x, D, torch.zeros(D, device=image.device), None, table, T))
+        x.view(B, T + 1, D)[:, 0].copy_(cls_row)
+        if before:
+            x.view(B, T + 1, D)[:, 1:] += additional_features.float()
+        x = ops.layernorm(x, f32(v.ln_pre.weight), f32(v.ln_pre.bias), 1e-5, out_dtype=torch.float32)
+        blocks = list(v.transformer.resblocks)
+        for i, blk in enumerate(blocks):
+            a = ops.layernorm(x, f32(blk.ln_1.weight), f32(blk.ln_1.bias), 1e-5, out_dtype=torch.float32)
+            ipw, ipb = blk.attn.in_proj_weight, blk.attn.in_proj_bias
+            wo = _w3(cache, ("out", i), lambda: blk.attn.out_proj.weight, blk.attn.out_proj.weight)
+            if i == len(blocks) - 1:  # forward_v: value projection -> out projection, nothing else
+                vin = _linear(a, _w3(cache, ("v", i), lambda: ipw[-D:], ipw), f32(ipb[-D:]))
+                vout = _linear(vin, wo, f32(blk.attn.out_proj.bias))
+                break
+            qkv = _linear(a, _w3(cache, ("qkv", i), lambda: ipw, ipw), f32(ipb))
+            att = _attention(qkv, B, T + 1, heads, 64 ** -0.5)
+            _residual(x, att, wo, f32(blk.attn.out_proj.bias), None)
+            m = ops.layernorm(x, f32(blk.ln_2.weight), f32(blk.ln_2.bias), 1e-5, out_dtype=torch.float32)
+            m = _linear(m, _w3(cache, ("fc", i), lambda: blk.mlp.c_fc.weight, blk.mlp.c_fc.weight), f32(blk.mlp.c_fc.bias))
+            _residual(x, m, _w3(cache, ("pj", i), lambda: blk.mlp.c_proj.weight, blk.mlp.c_proj.weight),
+                      f32(blk.mlp.c_proj.bias), None, act="quick_gelu")
+        post = ops.layernorm(vout, f32(v.ln_post.weight), f32(v.ln_post.bias), 1e-5, out_dtype=torch.float32,
+                             group_out=T, skip=1, rows_out=B * T)
+        nout = v.output_dim
+        npad = (nout + 3) // 4 * 4
+        feats = _linear(post, _w3(cache, "proj", lambda: F.pad(v.proj.t(), (0, 0, 0, npad - nout)), v.proj), None)[:, :nout]
+        if after:
+            feats = feats + additional_features.float().reshape(B * T, nout)
+        return feats.reshape(B, h, w, nout).permute(0, 3, 1, 2)
+
+
 def _patch_matrix(featurizer, image, coord):
     """im2col of the image (and, before-backbone injection, of [prev_mask | click maps]) for the patch embedding(s) as
     ONE GEMM over the concatenated K axis (DINOv2.py:518-523): fp32 [B*T, (3 + 3) * p * p].  unfold is layout only."""

@@ -492,6 +492,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     float v = k < K ? x[r * ld_in + k] : 0.f;
     if (act == 1) v = fmaxf(v, 0.f);
     if (act == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == 3) v = v / (1.0f + expf(-1.702f * v));  // CLIP's QuickGELU
     v *= scale;
     const bf16_t hi = f2bf(v);
     const bf16_t lo = f2bf(v - bf2f(hi));
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 
 extern "C" int isp_split_bf16x3(const float* x, long ld_in, void* out_bf16, long rows, int K, int Kpad, int weights_layout,
                                 int act, float scale, void* stream) {
-    ISP_CHECK_ARG(x && out_bf16 && rows > 0 && K > 0 && Kpad >= K && ld_in >= K && act >= 0 && act <= 2);
+    ISP_CHECK_ARG(x && out_bf16 && rows > 0 && K > 0 && Kpad >= K && ld_in >= K && act >= 0 && act <= 3);
     const long total = rows * Kpad;
     split_bf16x3_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         x, ld_in, (bf16_t*)out_bf16, rows, K, Kpad, weights_layout, act, scale);

@@ -798,7 +798,7 @@ def split3(x, weights=False, act=None, scale=1.0, K=None):
     Kpad = (K + 63) // 64 * 64
     out = torch.empty(rows, 3 * Kpad, device=x.device, dtype=BF16)
     check(_lib.lib().isp_split_bf16x3(_p(x), x.stride(0), _p(out), rows, K, Kpad, int(weights),
-                                      {None: 0, "relu": 1, "gelu": 2}[act], float(scale), _stream()), "isp_split_bf16x3")
+                                      {None: 0, "relu": 1, "gelu": 2, "quick_gelu": 3}[act], float(scale), _stream()), "isp_split_bf16x3")
     return out
 
 

@@ -297,6 +297,26 @@ def test_dino_vit_featurizer_fp32_mode_vs_reference_golden(golden, feat_type, in
     assert err < 1e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("inj", ["before_backbone", "after_backbone", "no_injection"])
+def test_maskclip_featurizer_fp32_mode_vs_reference_golden(golden, inj):
+    from isegprobe_amd.core.model.precise import maskclip_featurizer_fp32
+    from isegprobe_amd.core.utils.model_builder import ModelBuilder
+    g = golden("maskclip_tiny")
+    if inj + "_x" not in g:
+        pytest.skip("no fixture for this injection mode")
+    f = ModelBuilder().load_featurizer("mask_clip", dict(model_name="tiny", feats_injection_mode=inj,
+                                                          visual_kwargs=dict(input_resolution=64, patch_size=16, width=128,
+                                                                             layers=3, heads=2, output_dim=64)))
+    f.model.load_state_dict(weights_from(g, "w"))
+    f = f.cuda().eval()
+    y = maskclip_featurizer_fp32(f, torch.from_numpy(g[inj + "_x"]).cuda(), torch.from_numpy(g[inj + "_clicks"]).cuda()).cpu()
+    ref = torch.from_numpy(g[inj + "_y"])
+    assert y.shape == ref.shape
+    err = (y - ref).abs().max().item()
+    print(f"MaskCLIP fp32 mode [{inj}]: max err {err:.3g} (ref max {ref.abs().max():.3g})")
+    assert err < 1e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_simple_vit_click_encoder_vs_golden(golden):
     from isegprobe_amd.core.utils.model_builder import ModelBuilder
     g = golden("simple_vit_tiny")
