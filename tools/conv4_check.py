@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""8-wave vs 4-wave patch conv (ISEGPROBE_CONV_ENGINE=4): outputs must be bit-identical; times both."""
+"""8-wave (ISEGPROBE_CONV_ENGINE=8) vs 4-wave patch conv (the default): outputs must be bit-identical; times both."""
 import os, subprocess, sys
 code = r'''
 import os, sys, torch
@@ -35,8 +35,6 @@ for relu_in in (False, True):
 print(tag, " | ".join(res))
 '''
 for eng in ("8", "4", "8", "4"):
-    env = dict(os.environ)
-    env.pop("ISEGPROBE_CONV_ENGINE", None)
-    if eng != "8": env["ISEGPROBE_CONV_ENGINE"] = eng
+    env = dict(os.environ, ISEGPROBE_CONV_ENGINE=eng)  # "8": the 8-wave patch kernel, "4": the one-wave-per-SIMD kernel (default)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     print((r.stdout.strip().splitlines() or ["?"])[-1], r.stderr.strip().splitlines()[-2:] if r.returncode else "", flush=True)
