@@ -50,3 +50,25 @@ def test_bbox_helpers():
     assert expand_bbox((5, 8, 10, 20), 1.4, 6) == (4, 10, 7, 23)   # height max(5.6, 6) = 6, width 15.4
     assert clamp_bbox((-3, 25, 2, 40), 0, 19, 0, 29) == (0, 19, 2, 29)
     assert abs(get_bbox_iou((0, 9, 0, 9), (5, 14, 0, 9)) - (5 / 15)) < 1e-9
+
+
+def test_jbu_resize_fusion_condition():
+    """Host logic of the fused last-JBU-stage + resize: only the 8:7 geometry (FeatUp's x16 map vs a patch-14 image)
+    qualifies, and within it src = dst * (GH-1)/(OH-1) never leaves the 8-row group of its 7 output rows -- the property
+    the no-halo blend in jbu_kernels_kernel<BLEND> / jbu_apply_resized_kernel relies on (checked here in the float32
+    arithmetic the kernels use)."""
+    import numpy as np
+    from isegprobe_amd.core.model.upsamplers.JBUFeatUp import JBULearnedRange
+    ok = JBULearnedRange.resize_fusable
+    assert ok(512, 512, 448, 448) and ok(256, 384, 224, 336) and ok(64, 128, 56, 112)
+    assert not ok(512, 512, 447, 448) and not ok(512, 512, 512, 512) and not ok(500, 512, 448, 448) and not ok(36, 36, 32, 31)
+    for m in (1, 2, 5, 9, 16, 32, 64, 100):
+        GH, OH = 8 * m, 7 * m
+        s = np.float32(GH - 1) / np.float32(OH - 1) if OH > 1 else np.float32(0)
+        Y = np.arange(OH, dtype=np.float32)
+        y0 = (s * Y).astype(np.int32)
+        y1 = np.minimum(y0 + 1, GH - 1)
+        grp = np.arange(OH) // 7
+        assert (y0 // 8 == grp).all() and (y1 // 8 == grp).all(), m
+        # and the 16-column group of a 14-pixel strip
+        assert (y0 // 16 == np.arange(OH) // 14).all() and (y1 // 16 == np.arange(OH) // 14).all(), m
