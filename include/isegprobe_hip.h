@@ -259,9 +259,12 @@ int isp_tn_gemm_bf16_atomic(const void* P, long ldp, const void* Q, long ldq, fl
  * fp32 atomics).  Autograd of ConvModule.conv.weight, heads/conv_heads.py:51-73 under trainer.py:219-226. */
 int isp_conv3x3_wgrad_bf16_atomic(const void* g, const void* x, float* dw, int B, int H, int W, int C, int N, void* stream);
 int isp_relu_mask_colsum(const void* dy, const void* y, void* g, float* colsum, long M, int N, void* stream);
-/* dx_colsum (nullable, [C], caller-zeroed): += column sums of dx = bias gradient of the conv that produced x */
+/* dx_colsum (nullable, [C], caller-zeroed): += column sums of dx = bias gradient of the conv that produced x.
+ * relu_mask != 0: x is the output of a conv+ReLU layer and dx = (x > 0) * g * w (that layer's ReLU backward fused in);
+ * relu_mask == 0: x is a signed feature map (SimpleClassifierHead, heads/conv_heads.py:10-24; num_layers == 0) and
+ * dx = g * w. */
 int isp_classifier_bwd(const float* grad_logits, const void* x, const float* w, void* dx, float* dw, float* db,
-                       float* dx_colsum, long M, int C, void* stream);
+                       float* dx_colsum, long M, int C, int relu_mask, void* stream);
 int isp_resize_bilinear_ac_nhwc_bwd(const void* dout, void* din, int B, int h, int w, int H, int W, int C, void* stream);
 
 /* ---- layout converters between the plugin API (NCHW f32) and the kernels (NHWC bf16).

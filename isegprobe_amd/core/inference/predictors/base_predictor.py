@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from .... import hip_ops as ops
-from ...model._guidance_cache import guidance_scope
+from ...model._guidance_cache import guidance_scope, storage_epoch
 from ..clicker import Click, Clicker
 from ..transforms import AddHorizontalFlip, BaseTransform, LimitLongestSide, SigmoidForPred
 
@@ -167,16 +167,19 @@ class BasePredictor(object):
         P = points.shape[1] // 2
         key = (id(self.net), tuple(image_nd.shape))
         g = self._graphs.get(key)
-        if g is None or g.capacity < P:
+        stale = g is not None and g.epoch != storage_epoch()  # cache storage the graph points into has moved
+        if g is None or stale or g.capacity < P:
             if g is None and len(self._graphs) >= 4:  # images of many sizes without zoom-in: bound the graph pool
                 self._graphs.pop(next(iter(self._graphs)))
-            capacity = max(24, 2 * P) if g is None else max(2 * g.capacity, P)
+            capacity = max(24, 2 * P) if g is None else (max(2 * g.capacity, P) if g.capacity < P else g.capacity)
+            self._graphs.pop(key, None)
+            del g
             g = self._graphs[key] = _ClickGraph(self.net, image_nd, points, capacity, token)
-            g.token = token
+            g.token, g.epoch = token, storage_epoch()
         elif g.token != token:
             # the guidance changed (new image / zoom-in ROI): one eager pass refreshes the click-independent
             # upsampler work INTO the cache's existing storage (the captured graph keeps pointing at it) and is
-            # itself this click's result
+            # itself this click's result; if that pass had to move storage the epoch check re-captures next time
             g.token = token
             with guidance_scope(token):
                 return self.net(image_nd, points)["instances"]

@@ -103,10 +103,13 @@ class Conv1x1ReluFn(torch.autograd.Function):
 
 
 class ClassifierFn(torch.autograd.Function):
-    """1x1 conv C -> 1 on a post-ReLU NHWC bf16 map -> logits [B,1,H,W] fp32."""
+    """1x1 conv C -> 1 on an NHWC bf16 map -> logits [B,1,H,W] fp32.  ``post_relu``: x is the output of a conv+ReLU
+    layer, whose ReLU mask the backward kernel then applies to dx in the same pass; for a signed x (the "linear"
+    head, a conv head with num_layers = 0) dx is the plain g * w."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, post_relu=False):
+        ctx.post_relu = bool(post_relu)
         B, H, W, C = x.shape
         w = weight.detach().float().reshape(-1).contiguous()
         out = ops.classifier(x, w, float(bias.detach().float().item())).view(B, 1, H, W)
@@ -117,10 +120,10 @@ class ClassifierFn(torch.autograd.Function):
     def backward(ctx, gl):
         x, weight = ctx.saved_tensors
         w = weight.detach().float().reshape(-1).contiguous()
-        dx, dw, db = ops.classifier_bwd(gl.float().reshape(-1), x, w)
-        # NB: dx carries the ReLU mask of x (x is the output of a conv+ReLU layer); the producing
-        # layer's backward masks again with the same mask, which is idempotent.
-        return (dx if ctx.needs_input_grad[0] else None), dw.view_as(weight), db.view(1)
+        dx, dw, db = ops.classifier_bwd(gl.float().reshape(-1), x, w, relu_mask=ctx.post_relu)
+        # NB: with post_relu dx carries the ReLU mask of x; the producing layer's backward masks again with the
+        # same mask, which is idempotent.
+        return (dx if ctx.needs_input_grad[0] else None), dw.view_as(weight), db.view(1), None
 
 
 class ResizeBilinearFn(torch.autograd.Function):

@@ -39,36 +39,68 @@ def _tensors(v):
     return list(v) if isinstance(v, (tuple, list)) else [v]
 
 
-class GuidanceCache:
-    """Per-module memo, valid while (token, guidance shape/device, packed-weight identity) stay the same.
+_epoch = [0]
 
-    Pointer stability: when the token changes but the rebuilt tensors have the shapes of the ones they
-    replace, the new values are copied INTO the old storage.  A captured HIP graph of the click-dependent
-    part (predictors/base_predictor.py) therefore keeps reading valid addresses across zoom-in ROI changes;
-    only the guidance-only producers are re-run (eagerly) when the image changes."""
+
+def storage_epoch():
+    """Bumped whenever ANY guidance cache allocates, replaces or drops storage.  A captured HIP graph holds raw
+    pointers into that storage, so it is only replayable while the epoch it was captured under still stands
+    (predictors/base_predictor.py re-captures otherwise)."""
+    return _epoch[0]
+
+
+class _Slot:
+    __slots__ = ("token", "data", "fresh")
 
     def __init__(self):
-        self.key, self.data, self.fresh = None, {}, set()
+        self.token, self.data, self.fresh = None, {}, set()
+
+
+class GuidanceCache:
+    """Per-module memo: one slot per geometry (guidance shape, device, packed-weight identity), each valid while its
+    token stands.
+
+    Pointer stability: a slot's tensors stay alive while the slot does, and when the token changes but the rebuilt
+    tensors have the shapes of the ones they replace, the new values are copied INTO the old storage.  A captured
+    HIP graph of the click-dependent part (predictors/base_predictor.py) therefore keeps reading valid addresses
+    across zoom-in ROI changes and across geometries that alternate (ZoomIn(skip_clicks=1): click 1 at the image
+    size, later clicks at the zoom size; images of different sizes); only the guidance-only producers are re-run
+    (eagerly) when the image changes.  Anything that does move storage bumps ``storage_epoch()``."""
+
+    MAX_GEOMETRIES = 8
+
+    def __init__(self):
+        from collections import OrderedDict
+        self.slots = OrderedDict()
 
     def get(self, guidance, weights_id, name, build):
         tok = current_token()
         if tok is None:
             return build()
-        key = (tok, tuple(guidance.shape), str(guidance.device), weights_id)
-        if key != self.key:
-            if self.key is not None and key[1:] != self.key[1:]:
-                self.data = {}  # other geometry / weights: nothing to reuse
-            self.key, self.fresh = key, set()
-        if name not in self.fresh:
+        geom = (tuple(guidance.shape), str(guidance.device), weights_id)
+        slot = self.slots.get(geom)
+        if slot is None:
+            while len(self.slots) >= self.MAX_GEOMETRIES:
+                self.slots.popitem(last=False)
+                _epoch[0] += 1
+            slot = self.slots[geom] = _Slot()
+        else:
+            self.slots.move_to_end(geom)
+        if slot.token != tok:
+            slot.token, slot.fresh = tok, set()
+        if name not in slot.fresh:
             new = build()
-            old = self.data.get(name)
+            old = slot.data.get(name)
             if old is not None and all(o.shape == n.shape and o.dtype == n.dtype for o, n in zip(_tensors(old), _tensors(new))):
                 for o, n in zip(_tensors(old), _tensors(new)):
                     o.copy_(n)
             else:
-                self.data[name] = new
-            self.fresh.add(name)
-        return self.data[name]
+                slot.data[name] = new
+                _epoch[0] += 1
+            slot.fresh.add(name)
+        return slot.data[name]
 
     def clear(self):
-        self.key, self.data, self.fresh = None, {}, set()
+        if self.slots:
+            _epoch[0] += 1
+        self.slots.clear()

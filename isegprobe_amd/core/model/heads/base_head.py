@@ -26,11 +26,12 @@ class BaseClassifierHead(nn.Module):
             lambda: (self.classifier.weight.detach().float().reshape(-1).contiguous(),
                      float(self.classifier.bias.detach().float().item())))
 
-    def _classify(self, x_nhwc):
-        """1x1 conv C -> num_classes on an NHWC bf16 map -> [B, num_classes, H, W] f32."""
+    def _classify(self, x_nhwc, post_relu=False):
+        """1x1 conv C -> num_classes on an NHWC bf16 map -> [B, num_classes, H, W] f32.  ``post_relu``: x comes out of
+        a conv+ReLU layer (lets the backward fuse that ReLU's mask); never set it for a raw feature map."""
         if grad_mode(self.classifier) or (torch.is_grad_enabled() and x_nhwc.requires_grad):
             self._cls_weights()  # validates num_classes
-            return ClassifierFn.apply(x_nhwc, self.classifier.weight, self.classifier.bias)
+            return ClassifierFn.apply(x_nhwc, self.classifier.weight, self.classifier.bias, post_relu)
         w, b = self._cls_weights()
         B, H, W, _ = x_nhwc.shape
         return ops.classifier(x_nhwc, w, b).view(B, 1, H, W)

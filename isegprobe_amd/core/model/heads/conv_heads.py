@@ -83,7 +83,7 @@ class _StackedHead(BaseClassifierHead):
             return Conv3x3ReluClassifierFn.apply(y, last.weight, last.bias, self.classifier.weight, self.classifier.bias)
         for layer in layers:
             y = layer.run(y)
-        return self._classify(y)
+        return self._classify(y, post_relu=len(layers) > 0)
 
 
     def forward_folded_affine(self, x, Wf, bf, alpha):

@@ -222,9 +222,11 @@ __global__ __launch_bounds__(256) void relu_mask_colsum_kernel(const bf16_t* __r
 }
 
 // ---------------------------------------------------------------------------------------
-// 1x1 classifier backward fused with the ReLU mask of its input x (post-ReLU conv output):
-//   dx[m][c] = x[m][c] > 0 ? g[m] * w[c] : 0     dw[c] += sum_m g[m] * x[m][c]     db += sum_m g[m]
+// 1x1 classifier backward, optionally fused with the ReLU mask of its input x (MASK: x is a post-ReLU conv output;
+// otherwise x is a signed feature map -- the "linear" head, or a conv head with num_layers = 0 -- and dx is unmasked):
+//   dx[m][c] = (!MASK || x[m][c] > 0) ? g[m] * w[c] : 0     dw[c] += sum_m g[m] * x[m][c]     db += sum_m g[m]
 //   dxsum[c] += sum_m dx[m][c]   (optional: the bias gradient of the conv that produced x)
+template <bool MASK>
 __global__ __launch_bounds__(256) void classifier_bwd_kernel(const float* __restrict__ gl, const bf16_t* __restrict__ x,
                                                               const float* __restrict__ w, bf16_t* __restrict__ dx,
                                                               float* __restrict__ dw, float* __restrict__ db,
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void classifier_bwd_kernel(const float* __rest
             const float xlo = __uint_as_float(pb[e] << 16), xhi = __uint_as_float(pb[e] & 0xffff0000u);
             s[0][2 * e] += gm * xlo;
             s[0][2 * e + 1] += gm * xhi;
-            o[e] = pack2bf(xlo > 0.f ? gm * wv[2 * e] : 0.f, xhi > 0.f ? gm * wv[2 * e + 1] : 0.f);
+            o[e] = pack2bf(!MASK || xlo > 0.f ? gm * wv[2 * e] : 0.f, !MASK || xhi > 0.f ? gm * wv[2 * e + 1] : 0.f);
             s[1][2 * e] += __uint_as_float(o[e] << 16);
             s[1][2 * e + 1] += __uint_as_float(o[e] & 0xffff0000u);
         }
@@ -522,11 +524,16 @@ extern "C" int isp_relu_mask_colsum(const void* dy, const void* y, void* g, floa
 }
 
 extern "C" int isp_classifier_bwd(const float* grad_logits, const void* x, const float* w, void* dx, float* dw,
-                                  float* db, float* dx_colsum, long M, int C, void* stream) {
+                                  float* db, float* dx_colsum, long M, int C, int relu_mask, void* stream) {
     ISP_CHECK_ARG(grad_logits && x && w && dx && dw && db && M > 0 && C > 0 && C % 8 == 0);
     ISP_CHECK_ARG(C <= RED_MAX_N);
-    classifier_bwd_kernel<<<(unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(
-        grad_logits, (const bf16_t*)x, w, (bf16_t*)dx, dw, db, dx_colsum, M, C);
+    const unsigned grid = (unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    if (relu_mask)
+        classifier_bwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(grad_logits, (const bf16_t*)x, w, (bf16_t*)dx, dw, db,
+                                                                          dx_colsum, M, C);
+    else
+        classifier_bwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(grad_logits, (const bf16_t*)x, w, (bf16_t*)dx, dw, db,
+                                                                           dx_colsum, M, C);
     return isp_launch_status();
 }
 

@@ -712,9 +712,10 @@ def relu_mask_colsum(dy, y, want_colsum=True):
     return g, cs
 
 
-def classifier_bwd(grad_logits, x, w, want_dx_colsum=False):
-    """grad_logits [M] f32, x [M,C] bf16 (post-ReLU), w [C] f32 -> (dx bf16 masked by x>0, dw [C], db [1])
-    (+ the column sums of dx, i.e. the bias gradient of the conv that produced x, when asked)."""
+def classifier_bwd(grad_logits, x, w, want_dx_colsum=False, relu_mask=True):
+    """grad_logits [M] f32, x [M,C] bf16, w [C] f32 -> (dx bf16, dw [C], db [1]) (+ the column sums of dx, i.e. the
+    bias gradient of the conv that produced x, when asked).  ``relu_mask``: x is a post-ReLU map and dx is masked by
+    x > 0 (the producing layer's ReLU backward); pass False when x is a signed feature map."""
     grad_logits = _need(grad_logits.contiguous(), torch.float32, "grad_logits")
     _need(x, BF16, "x")
     C = x.shape[-1]
@@ -724,7 +725,8 @@ def classifier_bwd(grad_logits, x, w, want_dx_colsum=False):
     db = torch.zeros(1, device=x.device, dtype=torch.float32)
     cs = torch.zeros(C, device=x.device, dtype=torch.float32) if want_dx_colsum else None
     check(_lib.lib().isp_classifier_bwd(_p(grad_logits), _p(x), _p(w), _p(dx), _p(dw), _p(db),
-                                        _p(cs) if cs is not None else None, M, C, _stream()), "isp_classifier_bwd")
+                                        _p(cs) if cs is not None else None, M, C, int(bool(relu_mask)), _stream()),
+          "isp_classifier_bwd")
     return (dx, dw, db, cs) if want_dx_colsum else (dx, dw, db)
 
 

@@ -491,38 +491,122 @@ def gen_model():
     save("model_tiny", **out)
 
 
+def _two_blob_scene(rng, H, W):
+    """Synthetic interactive-segmentation scene: two bright ellipses on a noisy background; the TARGET is one of
+    them, the other is a distractor of the same brightness -- only the clicks say which is which."""
+    yy, xx = np.mgrid[:H, :W]
+    while True:
+        cy, cx = rng.uniform(0.25 * H, 0.75 * H, 2), rng.uniform(0.2 * W, 0.8 * W, 2)
+        ry, rx = rng.uniform(0.10 * H, 0.22 * H, 2), rng.uniform(0.08 * W, 0.2 * W, 2)
+        m = [((yy - cy[i]) / ry[i]) ** 2 + ((xx - cx[i]) / rx[i]) ** 2 <= 1 for i in range(2)]
+        if not (m[0] & m[1]).any() and m[0].sum() > 20 and m[1].sum() > 20:
+            break
+    img = rng.uniform(0, 1, (H, W, 3)) * 0.25 + (m[0] | m[1])[..., None] * rng.uniform(0.45, 0.7, 3)
+    return img.astype(np.float32), m[0], m[1]
+
+
+def _train_click_model(model, steps=500, seed=61):
+    """A few hundred CPU Adam steps of the REFERENCE tiny model (head + click patch-embed; frozen random backbone)
+    on the two-blob task so that its prediction responds to clicks and straddles 0.5 (with seeded random weights
+    the mask is all-positive at every click).  The trained weights are stored in the fixture."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    params = [p for n, p in model.named_parameters() if n.startswith(("head.", "embed_coords."))]
+    for n, p in model.named_parameters():
+        p.requires_grad_(n.startswith(("head.", "embed_coords.")))
+    opt = torch.optim.Adam(params, lr=2e-3)
+    H = W = 56
+    P = 4
+    for step in range(steps):
+        imgs, pts, tgts = [], [], []
+        for _ in range(8):
+            img, tgt, other = _two_blob_scene(rng, H, W)
+            pt = -np.ones((2 * P, 3), np.float32)
+            # the distractor belongs to the mask until a negative click lands on it: the robot user then has
+            # false positives to click on, and a negative click visibly changes the prediction
+            n_neg, on_other = rng.integers(0, 3), rng.random() < 0.7
+            label = tgt if (n_neg > 0 and on_other) else (tgt | other)
+            k = 0
+            for pol, region, n in ((0, tgt, rng.integers(1, 4)), (1, other if on_other else ~(tgt | other), n_neg)):
+                rr, cc = np.nonzero(region)
+                for i in range(n):
+                    j = rng.integers(len(rr))
+                    pt[pol * P + i] = (rr[j], cc[j], k)
+                    k += 1
+            mode = rng.integers(3)  # previous mask: empty / both blobs / the label
+            prev = np.zeros((H, W), np.float32) if mode == 0 else ((tgt | other) if mode == 1 else label).astype(np.float32)
+            imgs.append(np.concatenate([img.transpose(2, 0, 1), prev[None]], 0))
+            pts.append(pt)
+            tgts.append(label.astype(np.float32)[None])
+        x, p, t = (torch.from_numpy(np.stack(a)) for a in (imgs, pts, tgts))
+        loss = nn.functional.binary_cross_entropy_with_logits(model(x, p)["instances"], t)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if step % 100 == 0 or step == steps - 1:
+            print(f"  click-model training step {step}: bce {loss.item():.4f}")
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model.eval()
+
+
+INFERENCE_CASES = {  # tag -> ZoomIn kwargs (None: no zoom-in; the 140x196 image is a multiple of the patch size)
+    "nozoom": None,
+    "zoom": {"skip_clicks": -1, "target_size": (56, 56), "min_crop_size": 30},
+    "zoom_skip1": {"skip_clicks": 1, "target_size": (56, 56), "min_crop_size": 30},  # reference default skip_clicks
+}
+
+
 def gen_inference():
-    """BasePredictor fusion (flip + zoom-in + sigmoid), robot clicker, IoU, NoC."""
+    """BasePredictor fusion (flip + zoom-in + sigmoid), robot clicker, IoU, NoC -- on a model whose masks depend on
+    the clicks (trained here), so that thresholds, ROI updates and the click sequence are all exercised."""
     from core.inference.clicker import Clicker
     from core.inference.evaluation import evaluate_sample
     from core.inference.predictors import get_predictor
     from core.inference.utils import compute_noc_metric, get_iou
     rng = np.random.default_rng(6)
     out = {}
-    model = build_ref_model("bilinear", seed=60)
+    model = _train_click_model(build_ref_model("bilinear", seed=60))
     for k, v in sd_np(model).items():
         out["w::" + k] = v
-    H0, W0 = 90, 120
+    H0, W0 = 140, 196
     yy, xx = np.mgrid[:H0, :W0]
-    gt = (((yy - 45) / 28.0) ** 2 + ((xx - 70) / 36.0) ** 2 <= 1).astype(np.int32)
-    gt[40:50, 20:30] = -1  # ignore region
-    image = (rng.uniform(0, 1, (H0, W0, 3)) * 60 + gt[..., None].clip(0) * 120).astype(np.uint8)
+    tgt = ((yy - 62) / 30.0) ** 2 + ((xx - 120) / 38.0) ** 2 <= 1
+    tgt |= ((yy - 95) / 14.0) ** 2 + ((xx - 150) / 16.0) ** 2 <= 1       # a lobe: not one clean ellipse
+    other = ((yy - 80) / 24.0) ** 2 + ((xx - 42) / 26.0) ** 2 <= 1        # distractor of the same brightness
+    gt = tgt.astype(np.int32)
+    gt[100:110, 96:112] = -1  # ignore region
+    image = (rng.uniform(0, 1, (H0, W0, 3)) * 64 + (tgt | other)[..., None] * np.array([150, 130, 120])).astype(np.uint8)
     out["image_u8"], out["gt"] = image, gt
-    for tag, zoom in (("nozoom", None),
-                      ("zoom", {"skip_clicks": -1, "target_size": (56, 56)})):
-        predictor = get_predictor(model, "NoBRS", torch.device("cpu"), prob_thresh=0.5,
-                                  zoom_in_params=zoom)
-        if zoom is None:
-            # without zoom the net must see a multiple of 14: crop the image
-            img_c, gt_c = image[:84, :112], gt[:84, :112]
-        else:
-            img_c, gt_c = image, gt
-        clicks, ious, probs = evaluate_sample(img_c, gt_c, predictor, max_iou_thr=1.01,
-                                              pred_thr=0.5, max_clicks=6)
-        out[f"{tag}_clicks"] = np.array([(c.coords[0], c.coords[1], int(c.is_positive)) for c in clicks],
-                                        dtype=np.int64)
+    n_clicks = 8
+    any_negative = False
+    for tag, zoom in INFERENCE_CASES.items():
+        predictor = get_predictor(model, "NoBRS", torch.device("cpu"), prob_thresh=0.5, zoom_in_params=zoom)
+        masks, rois = [], []
+
+        def record(image_, gt_, pred_probs, sample_id, click_indx, clicks_list):
+            masks.append(np.packbits(pred_probs > 0.5))
+            z = predictor.zoom_in
+            rois.append((-1, -1, -1, -1) if z is None or z._object_roi is None else tuple(int(v) for v in z._object_roi))
+
+        clicks, ious, probs = evaluate_sample(image, gt, predictor, max_iou_thr=1.01, pred_thr=0.5,
+                                              max_clicks=n_clicks, callback=record)
+        out[f"{tag}_clicks"] = np.array([(c.coords[0], c.coords[1], int(c.is_positive)) for c in clicks], dtype=np.int64)
         out[f"{tag}_ious"] = ious
         out[f"{tag}_probs"] = probs.astype(np.float32)
+        out[f"{tag}_mask_bits"] = np.stack(masks)
+        out[f"{tag}_rois"] = np.array(rois, dtype=np.int64)
+        # the fixture must not be degenerate (round-1 one had an all-positive mask and a constant IoU)
+        frac = [np.unpackbits(m)[:H0 * W0].mean() for m in masks]
+        print(f"  {tag}: ious {np.round(ious, 3)}  positive fraction {np.round(frac, 3)}  "
+              f"negative clicks {int((out[f'{tag}_clicks'][:, 2] == 0).sum())}  distinct ROIs {len(set(rois))}")
+        assert len(set(np.round(ious, 4))) >= 4, "IoU must change across clicks"
+        assert all(0.01 < f < 0.95 for f in frac), "masks must straddle the threshold"
+        assert ious.max() > 0.6
+        any_negative = any_negative or bool((out[f"{tag}_clicks"][:, 2] == 0).any())
+        if zoom is not None:
+            assert len(set(r for r in rois if r[0] >= 0)) >= 2, "the zoom-in ROI must change at least once"
+    assert any_negative, "at least one case must place a negative click"
     # clicker known answers
     pred = np.zeros_like(gt, dtype=bool)
     ck = Clicker(gt_mask=gt)

@@ -28,14 +28,15 @@ S14 = dict(img_size=518, patch_size=14, embed_dim=384, depth=12, num_heads=6)
 
 
 def build_model(upsampler="bilinear", injection="before_backbone", vit=None, img=(56, 56), upsampler_params=None,
-                head_layers=2):
+                head_layers=2, head_type="convhead"):
     from isegprobe_amd.core.model import iSegProbeModel
     vit = vit or TINY_VIT
     D = vit["embed_dim"]
     return iSegProbeModel(
         backbone_cfg={"type": "dinov2", "params": {"arch": "custom", "feats_injection_mode": injection,
                                                    "vit_kwargs": vit}},
-        head_cfg={"type": "convhead", "params": dict(in_channels=D, num_layers=head_layers, num_classes=1)},
+        head_cfg={"type": head_type, "params": (dict(in_channels=D, num_classes=1) if head_type == "linear" else
+                                                dict(in_channels=D, num_layers=head_layers, num_classes=1))},
         embed_coords_cfg={"type": "patchEmbed", "params": dict(img_size=img, patch_size=(14, 14), embed_dim=D)},
         upsampler_cfg={"type": upsampler, "params": upsampler_params},
         use_disks=True, norm_radius=5, with_prev_mask=True).eval()

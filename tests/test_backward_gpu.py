@@ -103,6 +103,11 @@ def test_classifier_bwd(ops, M, C):
     dx2, dw2, db2, cs = ops.classifier_bwd(gl, x, w, want_dx_colsum=True)
     assert torch.equal(dx2, dx)
     assert rel(cs, dx.float().sum(0)) < 1e-3
+    # signed input (the "linear" head / num_layers = 0): no ReLU mask on dx
+    xs = torch.randn(M, C, device="cuda").to(BF)
+    dx3, dw3, db3 = ops.classifier_bwd(gl, xs, w, relu_mask=False)
+    assert rel(dx3, gl[:, None] * w[None, :].expand(M, C)) < 1e-2
+    assert rel(dw3, (gl[:, None] * xs.float()).sum(0)) < 1e-3
 
 
 @pytest.mark.parametrize("M,N", [(5000, 128), (300, 384), (1025, 8)])

@@ -52,6 +52,47 @@ def test_click_maps_vs_oracle(ops, disks, shape):
         np.testing.assert_allclose(out, ref, atol=1e-6, rtol=0)
 
 
+@pytest.mark.parametrize("case", ["int_p1", "int_p3", "frac_p3", "int_p24", "noneg_p3", "frac_p24_224"])
+def test_click_maps_vs_reference_golden(ops, golden, case):
+    """The torch path of DistMaps (core/model/ops.py:35-77) as the REFERENCE itself computed it
+    (tests/golden/click_maps.npz): disks bit-exact incl. fractional clicks, tanh maps to 1e-6."""
+    g = golden("click_maps")
+    H, W = (int(v) for v in g[case + "_hw"])
+    pts = torch.from_numpy(g[case + "_points"]).cuda()
+    B = pts.shape[0]
+    disks = ops.click_maps(pts, H, W, 5, 1.0, True).cpu().numpy()
+    ref = np.unpackbits(g[case + "_disks_bits"])[:B * 2 * H * W].reshape(B, 2, H, W).astype(np.float32)
+    assert np.array_equal(disks, ref)
+    np.testing.assert_allclose(ops.click_maps(pts, H, W, 5, 1.0, False).cpu().numpy(), g[case + "_tanh"], atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("via_module", [False, True])
+@pytest.mark.parametrize("case", ["p2", "p5", "half"])
+def test_click_maps_round_clicks_vs_compiled_cython_golden(ops, golden, case, via_module):
+    """The drop-in for the reference's ONLY native entry point: get_dist_maps (core/utils/cython/_get_dist_maps.pyx:18-64)
+    + its host loop and post-processing (core/model/ops.py:15-34,72-75) == isp_click_maps_fwd(round_clicks=1) /
+    DistMaps(cpu_mode=True).  Golden = the Cython reference compiled and run in the build container
+    (tests/golden/dist_maps_bfs.npz; the 'half' case pins round-half-even on .5 coordinates).  The BFS returns squared
+    distances; norm_delimeter 1 feeds the disk threshold (bit-exact), norm_delimeter 5 = radius*scale feeds tanh."""
+    g = golden("dist_maps_bfs")
+    H, W = (int(v) for v in g[case + "_hw"])
+    pts = torch.from_numpy(g[case + "_points"][None]).cuda()
+    ref_disks = (g[case + "_d1"] <= np.float32(25.0)).astype(np.float32)[None]
+    ref_tanh = np.tanh(np.sqrt(g[case + "_d5"]) * np.float32(2))[None]
+    if via_module:
+        from isegprobe_amd.core.model.ops import DistMaps
+        x = torch.zeros(1, 3, H, W, device="cuda")
+        disks = DistMaps(norm_radius=5, spatial_scale=1.0, cpu_mode=True, use_disks=True)(x, pts)
+        tanh = DistMaps(norm_radius=5, spatial_scale=1.0, cpu_mode=True, use_disks=False)(x, pts)
+    else:
+        disks = ops.click_maps(pts, H, W, 5, 1.0, True, round_clicks=True)
+        tanh = ops.click_maps(pts, H, W, 5, 1.0, False, round_clicks=True)
+    assert np.array_equal(disks.cpu().numpy(), ref_disks)
+    np.testing.assert_allclose(tanh.cpu().numpy(), ref_tanh, atol=1e-6, rtol=0)
+    if case == "half":  # rounding matters here: the un-rounded torch path gives other disks
+        assert not np.array_equal(ops.click_maps(pts, H, W, 5, 1.0, True).cpu().numpy(), ref_disks)
+
+
 def test_normalize(ops):
     x = torch.rand(2, 4, 28, 40, device="cuda")
     mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)

@@ -105,6 +105,40 @@ def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
     assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
 
 
+@pytest.mark.parametrize("head_type,layers", [("linear", None), ("convhead", 0), ("simple_conv", 1)])
+def test_signed_input_classifier_gradients(head_type, layers):
+    """Heads whose 1x1 classifier sees the raw, SIGNED feature map ("linear": SimpleClassifierHead,
+    heads/conv_heads.py:10-24; a conv head with num_layers = 0): the activation gradient that flows back into the
+    resize, the frozen trunk and the click patch-embed must not carry a ReLU mask (round-1 bug: it was zeroed wherever
+    the feature was <= 0).  simple_conv with one layer is the masked control.  Gradients vs autograd of the oracle."""
+    from oracle import model as omodel
+    model = build_model("bilinear", injection="before_backbone", head_type=head_type, head_layers=layers or 0)
+    seeded_(model, 9)
+    torch.manual_seed(2)
+    image = torch.rand(2, 4, 56, 56)
+    image[:, 3] = (image[:, 3] > 0.7).float()
+    points = torch.from_numpy(rand_points(np.random.default_rng(4), 2, 3, 56, 56))
+    w = {k: v.clone() for k, v in model.state_dict().items()}
+    train_keys = [k for k in w if k.startswith(("head.", "embed_coords."))]
+    for k in train_keys:
+        w[k].requires_grad_(True)
+    cfg = dict(patch=14, depth=2, heads=2, upsampler="bilinear", injection="before_backbone",
+               with_prev_mask=True, use_disks=True, norm_radius=5)
+    coef = torch.randn(2, 1, 56, 56)
+    (omodel.forward_with_grad(image, points, w, cfg) * coef).sum().backward()
+    model = model.cuda().train()
+    (model(image.cuda(), points.cuda())["instances"] * coef.cuda()).sum().backward()
+    named = dict(model.named_parameters())
+    for k in train_keys:
+        g, ref = named[k].grad.cpu(), w[k].grad
+        rms = (g - ref).pow(2).mean().sqrt().item() / (ref.pow(2).mean().sqrt().item() + 1e-12)
+        cos = torch.nn.functional.cosine_similarity(g.flatten(), ref.flatten(), dim=0).item()
+        print(f"{head_type}/{layers} {k:32s} rms-rel {rms:.3e}  cos {cos:.6f}")
+        # no ReLU between the features and the logits for the first two cases: nothing can flip, so the trunk-only
+        # agreement (cos 0.9999) must hold; a masked dx gave cos ~0.7 on embed_coords here
+        assert cos > (0.999 if head_type != "simple_conv" else 0.99), (k, cos, rms)
+
+
 # ------------------------------------------------------------------ device click simulation (SURVEY.md 8(f) rank 3)
 @pytest.mark.parametrize("B,H,W,P", [(2, 56, 70, 3), (3, 224, 224, 24), (1, 300, 448, 5), (2, 17, 9, 2)])
 def test_device_next_points_matches_oracle(B, H, W, P):
