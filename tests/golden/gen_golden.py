@@ -582,10 +582,13 @@ def gen_inference():
     any_negative = False
     for tag, zoom in INFERENCE_CASES.items():
         predictor = get_predictor(model, "NoBRS", torch.device("cpu"), prob_thresh=0.5, zoom_in_params=zoom)
-        masks, rois = [], []
+        masks, rois, near = [], [], []
 
         def record(image_, gt_, pred_probs, sample_id, click_indx, clicks_list):
             masks.append(np.packbits(pred_probs > 0.5))
+            # pixels whose probability is within the fp32 gate of the threshold (|logit| < 1e-3 <=> |p - 0.5| < 2.5e-4):
+            # the only ones an fp32-accurate implementation with another summation order may legitimately flip
+            near.append(np.packbits(np.abs(pred_probs.astype(np.float64) - 0.5) < 2.5e-4))
             z = predictor.zoom_in
             rois.append((-1, -1, -1, -1) if z is None or z._object_roi is None else tuple(int(v) for v in z._object_roi))
 
@@ -595,6 +598,8 @@ def gen_inference():
         out[f"{tag}_ious"] = ious
         out[f"{tag}_probs"] = probs.astype(np.float32)
         out[f"{tag}_mask_bits"] = np.stack(masks)
+        out[f"{tag}_near_bits"] = np.stack(near)
+        assert all(np.unpackbits(n).sum() <= 8 for n in near), "near-threshold sets must stay tiny"
         out[f"{tag}_rois"] = np.array(rois, dtype=np.int64)
         # the fixture must not be degenerate (round-1 one had an all-positive mask and a constant IoU)
         frac = [np.unpackbits(m)[:H0 * W0].mean() for m in masks]
