@@ -47,6 +47,16 @@ def forward(image, points, w, cfg):
 def forward_with_grad(image, points, w, cfg):
     """Same computation with autograd left on (weights in `w` may require grad): the oracle for the
     backward kernels."""
+    hr, size = features_with_grad(image, points, w, cfg)
+    logits = conv_head(hr, w)
+    # iseg_base_model.py:75-80 (runs even when already H x W)
+    return F.interpolate(logits, size=size, mode="bilinear", align_corners=True)
+
+
+def features_with_grad(image, points, w, cfg):
+    """Everything up to the head's input: (high-res feature map [B,C,H',W'] after the post-upsampler resize,
+    image size).  Lets a test evaluate the head on crops when the full-size head is too slow on the CPU
+    (ViT-L/14 + LiFT at 896^2: 30 TFLOP per image in the head alone)."""
     if True:
         image = image.float()
         prev = None
@@ -73,6 +83,4 @@ def forward_with_grad(image, points, w, cfg):
             hr = getattr(ups, up)(feats, image)
         if up != "identity" and hr.shape[2:] != image.shape[2:]:  # iseg_probe_model.py:120-129
             hr = F.interpolate(hr, size=image.shape[2:], mode="bilinear", align_corners=True)
-        logits = conv_head(hr, w)
-        # iseg_base_model.py:75-80 (runs even when already H x W)
-        return F.interpolate(logits, size=image.shape[2:], mode="bilinear", align_corners=True)
+        return hr, tuple(image.shape[2:])

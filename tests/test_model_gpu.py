@@ -30,6 +30,16 @@ def _close(y, ref, tol=TOL):
     return not bad.any().item()
 
 
+def _center_logits(model, ref):
+    """Seeded random weights tend to give logits of one sign (round 1: S/14+JBU@448 ranged -1.83..-0.16, so its mask
+    check compared two all-zero masks).  Logits are affine in the classifier bias: shift it by -median(ref) on the model
+    and on the oracle's output alike, so that the threshold cuts the map in half and mask agreement means something."""
+    delta = -ref.median().item()
+    with torch.no_grad():
+        model.head.classifier.bias.add_(delta)
+    return ref + delta
+
+
 def _mask_agreement(logits, ref, tol=TOL):
     decided = ref.abs() > tol
     return ((logits > 0) == (ref > 0))[decided].float().mean().item()
@@ -158,13 +168,16 @@ def test_s14_learned_upsamplers_vs_oracle(up, size, params):
     cfg = dict(patch=14, depth=12, heads=6, upsampler=up, injection="before_backbone",
                with_prev_mask=True, use_disks=True, norm_radius=5)
     torch.set_num_threads(16)
-    ref = omodel.forward(image, points, w, cfg)
+    ref = _center_logits(model, omodel.forward(image, points, w, cfg))
     with torch.no_grad():
         y = model.cuda()(image.cuda(), points.cuda())["instances"].cpu()
     err = (y - ref).abs()
+    flips = ((y > 0) != (ref > 0))
     print(f"S/14+{up}@{size}: max|logit err| = {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g}, "
-          f"logit range = {ref.min():.3f}..{ref.max():.3f} rms {ref.pow(2).mean().sqrt():.3f}, "
-          f"mask agreement {_mask_agreement(y, ref):.6f}")
+          f"logit range = {ref.min():.3f}..{ref.max():.3f} rms {ref.pow(2).mean().sqrt():.3f}, positive "
+          f"{float((ref > 0).float().mean()):.3f}, mask agreement {_mask_agreement(y, ref):.6f}, "
+          f"{int(flips.sum())} flips, all where |ref| < {float(ref.abs()[flips].max()) if flips.any() else 0:.2g}")
+    assert 0.3 < float((ref > 0).float().mean()) < 0.7
     assert _close(y, ref), err.max().item()
     assert _mask_agreement(y, ref) == 1.0
 
@@ -346,3 +359,134 @@ def test_maskclip_featurizer_vs_golden(golden, inj):
     assert y.shape == ref.shape
     err = (y.float().cpu() - ref).abs().max().item()
     assert err < 3e-2 * max(1.0, ref.abs().max().item()), err
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] and configs[4] at model level
+VITL = dict(img_size=518, patch_size=14, embed_dim=1024, depth=24, num_heads=16)   # DINOv2.py:438-449
+VITB = dict(img_size=518, patch_size=14, embed_dim=768, depth=12, num_heads=12)    # DINOv2.py:426-436
+
+
+def _cfg34_model(vit, up, params, size, seed):
+    model = build_model(up, vit=vit, img=(size, size), upsampler_params=params)
+    seeded_(model, seed)
+    with torch.no_grad():
+        model.backbone.model.pos_embed.mul_(0.3)
+    return model, {k: v.clone() for k, v in model.state_dict().items()}
+
+
+def test_cfg3_vitl14_lift_448_vs_oracle():
+    """BASELINE configs[3] model (ViT-L/14, D=1024, L=24, 16 heads + LiFT(1024,14) + ConvSegHead(1024,2,1)) at 448^2,
+    the whole logit map against the CPU oracle: bf16 gate |hip - ref| <= 1e-2 + 1e-2 |ref|, masks identical away from
+    the threshold; fp32 mode within 1e-3."""
+    from oracle import model as omodel
+    size = 448
+    model, w = _cfg34_model(VITL, "lift", {"lift_path": None, "n_dim": 1024, "patch": 14}, size, 77)
+    torch.manual_seed(3)
+    image = torch.rand(1, 4, size, size)
+    image[:, 3] = (image[:, 3] > 0.8).float()
+    points = torch.from_numpy(rand_points(np.random.default_rng(3), 1, 24, size, size))
+    cfg = dict(patch=14, depth=24, heads=16, upsampler="lift", injection="before_backbone",
+               with_prev_mask=True, use_disks=True, norm_radius=5)
+    torch.set_num_threads(16)
+    ref = _center_logits(model, omodel.forward(image, points, w, cfg))
+    model = model.cuda()
+    with torch.no_grad():
+        y = model(image.cuda(), points.cuda())["instances"].cpu()
+    y32 = model.forward_fp32(image.cuda(), points.cuda())["instances"].cpu()
+    err, err32 = (y - ref).abs(), (y32 - ref).abs()
+    print(f"cfg3 L/14+LiFT@448: bf16 max {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g}; fp32 mode max {err32.max():.3g}; "
+          f"logit range {ref.min():.3f}..{ref.max():.3f}, positive {float((ref > 0).float().mean()):.3f}, "
+          f"mask agreement {_mask_agreement(y, ref):.6f}")
+    assert 0.3 < float((ref > 0).float().mean()) < 0.7
+    assert _close(y, ref), err.max().item()
+    assert _mask_agreement(y, ref) == 1.0
+    assert err32.max().item() < 1e-3
+    assert ((y32 > 0) == (ref > 0)).all() or (ref.abs()[(y32 > 0) != (ref > 0)] < 1e-3).all()
+
+
+def test_cfg3_vitl14_lift_896_flip_pair_vs_oracle_crops():
+    """configs[3] at its full size: 896^2, batch 2 (the predictor's flip pair, flip.py:12-45).  The oracle computes the
+    trunk, LiFT and the x7 resize in full (4.3 TFLOP per image) and the head -- 30 TFLOP per image on the CPU -- on five
+    64x64 windows per image (corners incl. the zero-padded borders, centre), each from a window with a 2-pixel halo."""
+    from oracle import model as omodel
+    size = 896
+    model, w = _cfg34_model(VITL, "lift", {"lift_path": None, "n_dim": 1024, "patch": 14}, size, 78)
+    torch.manual_seed(4)
+    img = torch.rand(1, 4, size, size)
+    img[:, 3] = (img[:, 3] > 0.8).float()
+    image = torch.cat([img, torch.flip(img, dims=[3])])
+    pts = rand_points(np.random.default_rng(5), 1, 20, size, size)
+    mirrored = pts.copy()
+    mirrored[..., 1] = np.where(pts[..., 1] >= 0, size - 1 - pts[..., 1], -1)
+    points = torch.from_numpy(np.concatenate([pts, mirrored]))
+    cfg = dict(patch=14, depth=24, heads=16, upsampler="lift", injection="before_backbone",
+               with_prev_mask=True, use_disks=True, norm_radius=5)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        hr, _ = omodel.features_with_grad(image, points, w, cfg)
+        assert hr.shape == (2, 1024, size, size)
+        wins, refs = [], []
+        for r0, c0 in ((0, 0), (0, size - 64), (size - 64, 0), (size - 64, size - 64), (400, 416)):
+            ra, rb, ca, cb = max(r0 - 2, 0), min(r0 + 66, size), max(c0 - 2, 0), min(c0 + 66, size)
+            out = omodel.conv_head(hr[:, :, ra:rb, ca:cb].contiguous(), w)  # zero padding is right at image borders only
+            refs.append(out[:, :, r0 - ra:r0 - ra + 64, c0 - ca:c0 - ca + 64])
+            wins.append((r0, c0))
+    del hr
+    delta = -torch.cat([r.flatten() for r in refs]).median().item()  # see _center_logits
+    refs = [r + delta for r in refs]
+    with torch.no_grad():
+        model.head.classifier.bias.add_(delta)
+        y = model.cuda()(image.cuda(), points.cuda())["instances"].cpu()
+    assert y.shape == (2, 1, size, size)
+    worst, agree, n_pos = 0.0, 1.0, 0.0
+    for (r0, c0), ref in zip(wins, refs):
+        got = y[:, :, r0:r0 + 64, c0:c0 + 64]
+        assert _close(got, ref), ((r0, c0), (got - ref).abs().max().item())
+        worst = max(worst, (got - ref).abs().max().item())
+        agree = min(agree, _mask_agreement(got, ref))
+        n_pos += float((ref > 0).float().mean())
+    print(f"cfg3 L/14+LiFT@896 flip pair: max |logit err| over 10 windows {worst:.4g}, mask agreement {agree:.6f}, "
+          f"mean positive fraction {n_pos / len(wins):.3f}")
+    assert agree == 1.0
+
+
+def test_cfg4_vitb14_loftup_forward_and_gradients_vs_oracle():
+    """BASELINE configs[4] model (DINOv2-B/14: D=768, 12 heads, 12 blocks + LoftUp(768) + ConvSegHead(768,2,1)) at the
+    reference's 224^2 training crop: forward logits (bf16 gate) and the gradients of every trainable parameter
+    (embed_coords through the frozen trunk and both LoftUp cross-attention layers; head) against autograd of the oracle."""
+    from oracle import model as omodel
+    size = 224
+    model, w = _cfg34_model(VITB, "loftup", {"upsampler_path": None, "n_dim": 768}, size, 79)
+    torch.manual_seed(6)
+    image = torch.rand(1, 4, size, size)
+    image[:, 3] = (image[:, 3] > 0.8).float()
+    points = torch.from_numpy(rand_points(np.random.default_rng(6), 1, 24, size, size))
+    train_keys = [k for k in w if k.startswith(("head.", "embed_coords."))]
+    for k in train_keys:
+        w[k].requires_grad_(True)
+    cfg = dict(patch=14, depth=12, heads=12, upsampler="loftup", injection="before_backbone",
+               with_prev_mask=True, use_disks=True, norm_radius=5)
+    coef = torch.randn(1, 1, size, size)
+    torch.set_num_threads(16)
+    ref = omodel.forward_with_grad(image, points, w, cfg)
+    (ref * coef).sum().backward()
+    ref = _center_logits(model, ref.detach())
+    model = model.cuda()
+    with torch.no_grad():
+        y = model.eval()(image.cuda(), points.cuda())["instances"].cpu()
+    err = (y - ref).abs()
+    print(f"cfg4 B/14+LoftUp(768)@224: max|logit err| {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g}, logit range "
+          f"{ref.min():.3f}..{ref.max():.3f}, mask agreement {_mask_agreement(y, ref):.6f}")
+    assert _close(y, ref), err.max().item()
+    assert _mask_agreement(y, ref) == 1.0
+    model.train()
+    out = model(image.cuda(), points.cuda())["instances"]
+    (out * coef.cuda()).sum().backward()
+    named = dict(model.named_parameters())
+    for k in train_keys:
+        g, r = named[k].grad.cpu(), w[k].grad
+        rms = (g - r).pow(2).mean().sqrt().item() / (r.pow(2).mean().sqrt().item() + 1e-12)
+        cos = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
+        print(f"cfg4 grad {k:32s} rms-rel {rms:.3e}  cos {cos:.6f}")
+        assert cos > 0.975 and rms < 0.25, (k, cos, rms)
+    assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
