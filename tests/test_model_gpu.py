@@ -178,7 +178,15 @@ def test_s14_learned_upsamplers_vs_oracle(up, size, params):
           f"{float((ref > 0).float().mean()):.3f}, mask agreement {_mask_agreement(y, ref):.6f}, "
           f"{int(flips.sum())} flips, all where |ref| < {float(ref.abs()[flips].max()) if flips.any() else 0:.2g}")
     assert 0.3 < float((ref > 0).float().mean()) < 0.7
-    assert _close(y, ref), err.max().item()
+    # ABSOLUTE gates on the centred logits (no |ref|-relative allowance).  Measured (tools/diag_precision_full.py):
+    # LiFT 6.4e-3; FeatUp JBU 1.22e-2 = head quantisation floor (bf16 weights / input / hidden map: rms 1.25e-3)
+    # + four JBU stages (1.9e-3) + featurizer (1.1e-3), max = 4.7 sigma of 200 k pixels; LoftUp 1.36e-2, of which
+    # 2.75e-3 is a CONSTANT offset: rounding the head's weights to bf16 shifts the logits' 0.6 DC component by 0.45 %
+    # (the fp32 oracle on bf16-rounded head weights alone shows it).  north_star's 1e-2 holds for LiFT; the other two are
+    # held to 1.5e-2 until the upsampler intermediates / head operands move to a wider mantissa.
+    gate = {"lift": 1e-2, "jbu_featup": 1.5e-2, "loftup": 1.5e-2}[up]
+    assert err.max().item() <= gate, err.max().item()
+    assert err.pow(2).mean().sqrt().item() <= 4e-3
     assert _mask_agreement(y, ref) == 1.0
 
 
@@ -398,7 +406,7 @@ def test_cfg3_vitl14_lift_448_vs_oracle():
           f"logit range {ref.min():.3f}..{ref.max():.3f}, positive {float((ref > 0).float().mean()):.3f}, "
           f"mask agreement {_mask_agreement(y, ref):.6f}")
     assert 0.3 < float((ref > 0).float().mean()) < 0.7
-    assert _close(y, ref), err.max().item()
+    assert err.max().item() <= 1e-2, err.max().item()  # absolute
     assert _mask_agreement(y, ref) == 1.0
     assert err32.max().item() < 1e-3
     assert ((y32 > 0) == (ref > 0)).all() or (ref.abs()[(y32 > 0) != (ref > 0)] < 1e-3).all()
@@ -441,7 +449,7 @@ def test_cfg3_vitl14_lift_896_flip_pair_vs_oracle_crops():
     worst, agree, n_pos = 0.0, 1.0, 0.0
     for (r0, c0), ref in zip(wins, refs):
         got = y[:, :, r0:r0 + 64, c0:c0 + 64]
-        assert _close(got, ref), ((r0, c0), (got - ref).abs().max().item())
+        assert (got - ref).abs().max().item() <= 1e-2, ((r0, c0), (got - ref).abs().max().item())  # absolute
         worst = max(worst, (got - ref).abs().max().item())
         agree = min(agree, _mask_agreement(got, ref))
         n_pos += float((ref > 0).float().mean())
@@ -477,7 +485,7 @@ def test_cfg4_vitb14_loftup_forward_and_gradients_vs_oracle():
     err = (y - ref).abs()
     print(f"cfg4 B/14+LoftUp(768)@224: max|logit err| {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g}, logit range "
           f"{ref.min():.3f}..{ref.max():.3f}, mask agreement {_mask_agreement(y, ref):.6f}")
-    assert _close(y, ref), err.max().item()
+    assert err.max().item() <= 1.5e-2, err.max().item()  # absolute, centred logits; see test_s14_learned_upsamplers_vs_oracle
     assert _mask_agreement(y, ref) == 1.0
     model.train()
     out = model(image.cuda(), points.cuda())["instances"]
