@@ -1,17 +1,28 @@
 #!/usr/bin/env python3
 """Benchmark of the per-click dense-feature path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus 1 --steps 20 --warmup 5              # BASELINE.json configs[1] (the headline)
+    python bench.py --gpus N ...                                # spawns its own N workers (one per GPU, RCCL)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # or under torchrun
+    python bench.py --mode train --gpus N                       # configs[2]/[4]: train step with the RCCL gradient all-reduce
 
-One "step" = one forward pass of the whole path over one synthetic batch per GPU:
-click maps -> normalise -> DINOv2-S/14 (clicks injected before the blocks) -> FeatUp JBU x16
--> bilinear resize to the image size (fused into the last JBU stage) -> ConvSegHead -> logits   (BASELINE.json configs[1]:
-"DINOv2-S/14 + FeatUp JBU, 448x448 batch=32, forward-only").  The metric's "featurizer +
-upsampler" stages are inside the timed region together with the seg head and the click-map
-generator that north_star places on the same path (more work, never less); their separate
-rates are reported under "stages".  Inputs are resident in HBM before the timed region.
-Weak scaling: every rank runs its own batch, no data-path collective.
+forward mode (default).  One "step" = one forward pass of the whole path over one synthetic batch per GPU:
+click maps -> normalise -> DINOv2-S/14 (clicks injected before the blocks) -> FeatUp JBU x16 -> bilinear resize to the
+image size (fused into the last JBU stage) -> ConvSegHead -> logits (BASELINE.json configs[1]: "DINOv2-S/14 + FeatUp
+JBU, 448x448 batch=32, forward-only").  The metric's "featurizer + upsampler" stages are inside the timed region together
+with the seg head and the click-map generator that north_star places on the same path (more work, never less).  Inputs are
+resident in HBM before the timed region.  Weak scaling: every rank runs its own batch, no data-path collective
+(SURVEY.md 8(e)).
+
+train mode.  One "step" = DataParallelTrainer.step on a per-GPU minibatch: forward, NFL loss, HIP backward through the
+frozen trunk and upsampler, ONE flat-bucket all-reduce of the trainable gradients (backend "nccl" = RCCL over xGMI), Adam
+(reference core/training/trainer.py:193-314, core/utils/distributed.py:66-78).
+
+Rooflines in the JSON line (forward mode), all from HIP events on the launch stream INSIDE the timed steps:
+  roofline            the dominant kernel: the seg head's 3x3 conv (MFMA)
+  roofline_vit        the DINOv2 blocks (patch embed + 12 blocks + final norm), SURVEY.md 8(d) ViT(D,L,N) FLOPs (MFMA)
+  roofline_attention  the fused attention launches alone, L*N*4ND FLOPs over the step (MFMA)
+  roofline_upsampler  the upsampler stage (FeatUp JBU: four stages + the fused resize), its algorithmic bytes (HBM)
 """
 import argparse
 import json
@@ -26,7 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-S14 = dict(img_size=518, patch_size=14, embed_dim=384, depth=12, num_heads=6)
+VITS = {"dinov2_vits14": dict(img_size=518, patch_size=14, embed_dim=384, depth=12, num_heads=6),
+        "dinov2_vitb14": dict(img_size=518, patch_size=14, embed_dim=768, depth=12, num_heads=12),
+        "dinov2_vitl14": dict(img_size=518, patch_size=14, embed_dim=1024, depth=24, num_heads=16)}
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 
@@ -48,54 +61,106 @@ def synthetic_batch(B, S, seed, P=24):
     return image, torch.from_numpy(pts)
 
 
-def build(upsampler, size):
+def synthetic_train_batch(B, S, seed, P=24, device="cuda"):
+    """SBD-shaped train batch: image, one elliptical instance mask, its first positive click (the trainer simulates
+    the corrective clicks on the device)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[:S, :S]
+    images = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(seed))
+    gts, pts = [], -np.ones((B, 2 * P, 3), np.float32)
+    for b in range(B):
+        cy, cx, ry, rx = rng.uniform(0.3, 0.7) * S, rng.uniform(0.3, 0.7) * S, rng.uniform(0.1, 0.3) * S, rng.uniform(0.1, 0.3) * S
+        m = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1).astype(np.float32)
+        images[b] += torch.from_numpy(m)[None] * 0.5
+        gts.append(torch.from_numpy(m)[None])
+        pts[b, 0] = (int(cy), int(cx), 0)
+    return {"images": images.clamp(0, 1).to(device), "instances": torch.stack(gts).to(device),
+            "points": torch.from_numpy(pts).to(device)}
+
+
+def upsampler_params(upsampler, dim):
+    return {"jbu_featup": {"backbone_type": "dinov2", "feat_dim": dim},
+            "loftup": {"upsampler_path": None, "n_dim": dim},
+            "lift": {"lift_path": None, "n_dim": dim, "patch": 14}}.get(upsampler)
+
+
+def build(upsampler, size, arch="dinov2_vits14"):
     from helpers import build_model, seeded_
-    params = {"backbone_type": "dinov2"} if upsampler == "jbu_featup" else None
-    model = build_model(upsampler, vit=S14, img=(size, size), upsampler_params=params)
+    vit = VITS[arch]
+    model = build_model(upsampler, vit=vit, img=(size, size), upsampler_params=upsampler_params(upsampler, vit["embed_dim"]))
     seeded_(model, 2025)  # random-init weights of the named architecture (no checkpoints offline)
     with torch.no_grad():
         model.backbone.model.pos_embed.mul_(0.3)
     return model
 
 
-class ConvTimer:
-    """HIP events around every 3x3-conv launch of the timed steps (same stream as the launch).  The
-    seg head issues them through three wrappers (plain, folded-affine first layer, classifier-fused
-    last layer); all three run conv3x3_patch4_kernel_192<...> with the same algorithmic FLOPs."""
+# ---------------------------------------------------------------------------------------------- algorithmic work
+def vit_flops(D, L, hw, patch=14, in_ch=6):
+    """ViT(D,L,N) = L*N*(24 D^2 + 4 N D) + the image and click patch embeds (2 * 2*588*D*h*w)."""
+    N = hw + 1
+    return L * N * (24.0 * D * D + 4.0 * N * D) + 2.0 * in_ch * patch * patch * D * hw
 
-    NAMES = ("conv3x3", "conv3x3_folded_affine", "conv3x3_relu_classifier")
 
-    def __init__(self, ops):
-        self.ops, self.orig, self.pairs, self.flops = ops, {n: getattr(ops, n) for n in self.NAMES}, [], 0.0
+def attention_flops(D, L, hw):
+    N = hw + 1
+    return L * N * 4.0 * N * D
+
+
+def upsampler_bytes(upsampler, C, h, w, H, W, e=2):
+    """Algorithmic HBM bytes per image of the upsampler stage, SURVEY.md 8(d) (e = bytes per element on this path)."""
+    if upsampler == "jbu_featup":  # sum over stages: source read + x2 map written + 49-tap kernels; last stage writes H x W
+        total, hs, ws = 0.0, h, w
+        for s in range(4):
+            oh, ow = (2 * hs, 2 * ws) if s < 3 else (H, W)
+            total += C * (hs * ws + oh * ow) * e + 49 * (2 * hs) * (2 * ws) * e
+            hs, ws = 2 * hs, 2 * ws
+        return total + 3 * H * W * 4  # + the guidance image read once
+    if upsampler in ("bilinear", "nearest", "bicubic"):
+        return C * (h * w + H * W) * e
+    if upsampler == "loftup":
+        return H * W * (3 * 4 + C * e) + h * w * (C + 20) * e
+    if upsampler == "lift":
+        return C * (h * w + 4 * h * w) * e + 3 * H * W * 4 + C * H * W * e  # LiFT x2 + the model's resize to H x W
+    return None
+
+
+# ---------------------------------------------------------------------------------------------- in-region HIP-event timers
+class OpTimer:
+    """HIP events (on the launch stream) around every call of the named callables during the timed steps."""
+
+    def __init__(self, owner, names):
+        self.owner, self.names = owner, [n for n in names if hasattr(owner, n)]
+        self.orig, self.pairs, self.last_args = {n: getattr(owner, n) for n in self.names}, [], None
 
     def __enter__(self):
         def make(fn):
-            def timed(x, Wt, *a, **k):
+            def timed(*a, **k):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
-                y = fn(x, Wt, *a, **k)
+                y = fn(*a, **k)
                 e.record()
                 self.pairs.append((s, e))
-                B, H, W, C = x.shape
-                self.flops = 2.0 * B * H * W * C * 9 * Wt.shape[0]  # algorithmic FLOPs of one launch
+                self.last_args = a
                 return y
             return timed
         for n, fn in self.orig.items():
-            setattr(self.ops, n, make(fn))
+            setattr(self.owner, n, make(fn))
         return self
 
     def __exit__(self, *exc):
         for n, fn in self.orig.items():
-            setattr(self.ops, n, fn)
+            setattr(self.owner, n, fn)
+
+    def times_ms(self):
+        return [s.elapsed_time(e) for s, e in self.pairs]
 
     def mean_ms(self):
-        return float(np.mean([s.elapsed_time(e) for s, e in self.pairs])) if self.pairs else None
+        t = self.times_ms()
+        return float(np.mean(t)) if t else None
 
 
 def stage_times(model, image, points, iters=5):
-    """Separate HIP-event timings of the stages (outside the headline timed region)."""
-    from isegprobe_amd import hip_ops as ops  # noqa: F401
-
+    """Separate, sequential HIP-event timings of the stages (outside the headline timed region)."""
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
@@ -129,135 +194,348 @@ def stage_times(model, image, points, iters=5):
             out["head_ms"] = timed(lambda: model.head.forward_folded_affine(hr_f, Wf, bf, alpha))
             out["featurizer+upsampler_images_per_sec"] = image.shape[0] / (
                 (out["click_maps+normalize_ms"] + out["featurizer_ms"] + out["upsampler(+resize)_ms"]) * 1e-3)
-            out["note"] = "same kernels as the timed step; plugin-by-plugin route (unfolded fix-up GEMM, separate resize): " \
-                          f"upsampler {timed(lambda: model.upsampler(source=feats, guidance=img)):.2f} ms, " \
-                          f"resize+head {timed(lambda: model._resize_and_head(img, hr)):.2f} ms"
         else:
             out["upsampler_ms"] = timed(lambda: model.upsampler(source=feats, guidance=img))
             out["resize+head_ms"] = timed(lambda: model._resize_and_head(img, hr))
+            out["featurizer+upsampler_images_per_sec"] = image.shape[0] / (
+                (out["click_maps+normalize_ms"] + out["featurizer_ms"] + out["upsampler_ms"]) * 1e-3)
     return out
 
 
-def cpu_baseline(model_sd, size, upsampler, seed):
-    """The CPU oracle (kind "port": torch-CPU restatement of the reference path, pinned by the
-    golden fixtures) on ONE image of the same workload, all host threads."""
+# ---------------------------------------------------------------------------------------------- CPU baseline (oracle)
+def cpu_baseline(model_sd, size, upsampler, vit, seed, full=False):
+    """The CPU oracle (kind "port": torch-CPU restatement of the reference path, pinned by the golden fixtures) on
+    a bounded sample of the same workload, on this box's host cores: batch 1 (median of 3 runs, per-stage split) and
+    batch 8 (one run; three with --cpu-baseline-full), SURVEY.md 8(d).  A reported baseline, not the target."""
+    import torch.nn.functional as F
     from oracle import model as omodel
+    from oracle import upsamplers as ups
+    from oracle import vit as ovit
+    from oracle.click_maps import click_maps
     n = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU is 16 cores
     torch.set_num_threads(n)
-    image, points = synthetic_batch(1, size, seed)
-    cfg = dict(patch=14, depth=12, heads=6, upsampler=upsampler, injection="before_backbone",
-               with_prev_mask=True, use_disks=True, norm_radius=5)
-    t0 = time.perf_counter()
-    omodel.forward(image, points, model_sd, cfg)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 image ({size}x{size}, batch 1) through the same path, single run of {dt:.1f} s, fp32"}
+
+    def one(B):
+        image, points = synthetic_batch(B, size, seed)
+        t = [time.perf_counter()]
+        with torch.no_grad():
+            img = omodel.normalize(image[:, :3].float())
+            maps = torch.from_numpy(click_maps(points.numpy(), size, size, 5, 1.0, True))
+            coord = torch.cat((image[:, 3:], maps), 1)
+            t.append(time.perf_counter())
+            clicks = ovit.patch_tokens(coord, model_sd["embed_coords.proj.weight"], model_sd["embed_coords.proj.bias"], 14)
+            feats = ovit.dinov2_features(img, model_sd, patch=14, depth=vit["depth"], heads=vit["num_heads"],
+                                         click_tokens=clicks, injection="before_backbone", prefix="backbone.model.")
+            t.append(time.perf_counter())
+            if upsampler == "jbu_featup":
+                hr = ups.jbu_stack(feats, img, model_sd, "upsampler.upsampler.")
+            elif upsampler == "loftup":
+                hr = ups.loftup(feats, img, model_sd, "upsampler.upsampler.")
+            elif upsampler == "lift":
+                hr = ups.lift(feats, img, model_sd, "upsampler.lift.")
+            else:
+                hr = getattr(ups, upsampler)(feats, img)
+            if upsampler != "identity" and hr.shape[2:] != img.shape[2:]:
+                hr = F.interpolate(hr, size=img.shape[2:], mode="bilinear", align_corners=True)
+            t.append(time.perf_counter())
+            logits = omodel.conv_head(hr, model_sd)
+            F.interpolate(logits, size=img.shape[2:], mode="bilinear", align_corners=True)
+            t.append(time.perf_counter())
+        return np.diff(t)  # click maps + normalise, featurizer, upsampler (+resize), head
+
+    r1 = np.array([one(1) for _ in range(3)])
+    tot1 = r1.sum(1)
+    med = int(np.argsort(tot1)[1])
+    r8 = np.array([one(8) for _ in range(3 if full else 1)])
+    tot8 = np.sort(r8.sum(1))[len(r8) // 2]
+    names = ("click_maps+normalize", "featurizer", "upsampler(+resize)", "head")
+    return {"value": 1.0 / tot1[med], "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"batch 1: median of 3 runs of one {size}x{size} image through the same path ({tot1[med]:.1f} s each, fp32); "
+                      f"batch 8: {'median of 3 runs' if full else 'one run'} ({tot8:.1f} s)",
+            "batch1_runs_s": [round(float(v), 2) for v in tot1],
+            "batch1_stage_s": {k: round(float(v), 3) for k, v in zip(names, r1[med])},
+            "batch8_images_per_sec": 8.0 / float(tot8),
+            "batch8_stage_s": {k: round(float(v), 3) for k, v in zip(names, r8[int(np.argsort(r8.sum(1))[len(r8) // 2])])}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--size", type=int, default=448)
-    ap.add_argument("--upsampler", default="jbu_featup")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stages", action="store_true")
-    args = ap.parse_args()
-
+# ---------------------------------------------------------------------------------------------- workers
+def _dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = "cpu" if args.dry_run else "cuda"
+    if not args.dry_run:
+        torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://")  # RCCL
+        dist.init_process_group("gloo" if args.dry_run else "nccl", init_method="env://")  # "nccl" = RCCL
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not args.dry_run:
+            torch.cuda.synchronize()
 
+    def max_over_ranks(dt):
+        if dist is None:
+            return dt
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+    return world, rank, dist, barrier, max_over_ranks
+
+
+def _pmc_traffic(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def run_dry(args):
+    """Launch plumbing only (CPU, gloo): the ranks rendezvous, time an empty region the way the real modes do, and
+    rank 0 prints one JSON line.  Used by tests/test_distributed_cpu.py to cover `bench.py --gpus N` self-spawn."""
+    world, rank, dist, barrier, max_over_ranks = _dist_setup(args)
+    barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "mode": args.mode, "max_dt": dt}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_forward(args):
+    world, rank, dist, barrier, max_over_ranks = _dist_setup(args)
     from isegprobe_amd import hip_ops as ops
     import logging
     logging.getLogger("root").setLevel(logging.WARNING)
 
-    model = build(args.upsampler, args.size)
+    vit = VITS[args.arch]
+    model = build(args.upsampler, args.size, args.arch)
     sd = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.cuda()
     image, points = synthetic_batch(args.batch, args.size, seed=1000 + rank)
     image, points = image.cuda(), points.cuda()
+    stack = getattr(model.upsampler, "upsampler", None)
+    fused_jbu = getattr(model, "fold_upsampler_affine", False) and hasattr(stack, "forward_stages")
 
     with torch.no_grad():
         for _ in range(args.warmup):
             model(image, points)
         barrier()
-        with ConvTimer(ops) as ct:
+        with OpTimer(ops, ("conv3x3", "conv3x3_folded_affine", "conv3x3_relu_classifier")) as t_conv, \
+                OpTimer(ops, ("attention_packed_qkv",)) as t_att, \
+                OpTimer(model.backbone, ("forward_fused_clicks",)) as t_vit, \
+                OpTimer(stack if fused_jbu else model.upsampler, ("forward_stages",) if fused_jbu else ("forward",)) as t_up:
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 out = model(image, points)["instances"]
             barrier()
             dt = time.perf_counter() - t0
     assert out.shape == (args.batch, 1, args.size, args.size) and torch.isfinite(out).all()
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = max_over_ranks(dt)
 
     if rank == 0:
-        conv_ms = ct.mean_ms()
-        traffic = None  # PMC passes cannot run inside bench.py: use the committed measurement of this launch shape
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_pmc.json")))
-            if args.batch == 32 and args.size == 448:
-                traffic = pmc["derived"]["traffic_bytes_per_launch"]
-        except Exception:
-            pass
-        achieved = ct.flops / (conv_ms * 1e-3) / 1e12
+        B, S, D, L = args.batch, args.size, vit["embed_dim"], vit["depth"]
+        h = w = S // 14
+        conv_ms = t_conv.mean_ms()
+        xin, Wt = t_conv.last_args[0], t_conv.last_args[1]
+        conv_flops = 2.0 * xin.shape[0] * xin.shape[1] * xin.shape[2] * xin.shape[3] * 9 * Wt.shape[0]
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        pmc = _pmc_traffic("r02_conv_pmc.json") or _pmc_traffic("r01_conv_pmc.json")
+        traffic = None
+        if pmc is not None and B == 32 and S == 448 and args.arch == "dinov2_vits14":
+            traffic = pmc["derived"]["traffic_bytes_per_launch"]
         line = {
             "metric": "images/sec thru featurizer+upsampler @448^2 (whole per-click path: click maps, "
                       "featurizer, upsampler, seg head)",
-            "value": world * args.batch * args.steps / dt,
+            "value": world * B * args.steps / dt,
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"DINOv2-S/14 + {args.upsampler} + ConvSegHead(384,2,1), "
-                                   f"{args.size}x{args.size}, batch {args.batch}/GPU, forward-only, "
-                                   "seeded random-init weights", "per_gpu_batch": args.batch,
-                       "global_batch": world * args.batch, "image_size": args.size, "parallelism": f"replicas x{world}"},
-            "roofline": {"kernel": "conv3x3_patch4_kernel_192 (seg-head 3x3 conv, implicit GEMM, LDS-resident input patch, one wave per SIMD)",
+            "config": {"workload": f"{args.arch} + {args.upsampler} + ConvSegHead({D},2,1), {S}x{S}, batch {B}/GPU, "
+                                   "forward-only, seeded random-init weights", "per_gpu_batch": B,
+                       "global_batch": world * B, "image_size": S, "parallelism": f"replicas x{world}"},
+            "roofline": {"kernel": "conv3x3_patch4_kernel_192 (seg-head 3x3 conv, implicit GEMM, LDS-resident input patch, "
+                                   "one wave per SIMD; both launches of the step: folded-affine first conv, classifier-fused second)",
                          "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "fabric bytes per launch from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, profiles/r01_conv_pmc.json",
-                         "launch_ms": conv_ms, "flops_per_launch": ct.flops},
+                         "traffic_note": "fabric bytes per launch from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, separate --pmc passes "
+                                         "(profiles/r02_conv_pmc.json, else r01)",
+                         "launch_ms": conv_ms, "flops_per_launch": conv_flops},
         }
-        try:  # on-box probe of the dense-bf16 ceiling on random operands (profiles/r01_peaks.json; tools/peaks.py)
-            pk = json.load(open(os.path.join(ROOT, "profiles", "r01_peaks.json")))["mfma_bf16_16x16x32_register_loop_tflops"]
-            line["roofline"]["peak_measured_random_operands"] = pk["random"]
-            line["roofline"]["frac_of_measured"] = achieved / pk["random"]
-        except Exception:
-            pass
+        pk = _pmc_traffic("r01_peaks.json")
+        if pk is not None:
+            rnd = pk["mfma_bf16_16x16x32_register_loop_tflops"]["random"]
+            line["roofline"]["peak_measured_random_operands"] = rnd
+            line["roofline"]["frac_of_measured"] = achieved / rnd
+        # --- the rooflines north_star names, from HIP events inside the timed steps
+        vit_ms = t_vit.mean_ms()
+        if vit_ms:
+            fl = B * vit_flops(D, L, h * w)
+            line["roofline_vit"] = {"kernel": "DINOv2 forward: patch embed (image + clicks), blocks, final norm "
+                                              "(gemm_tile_kernel, attention_kernel<64>, layernorm)",
+                                    "bound": "mfma", "achieved": fl / (vit_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": fl / (vit_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                                    "ms_per_step": vit_ms, "flops_per_step": fl, "traffic": None,
+                                    "note": "events on the main stream; FeatUp-JBU's guidance-only kernel records run beside it on a "
+                                            "second stream (iseg_probe_model._jbu_records_side_stream)"}
+        att_ms = t_att.times_ms()
+        if att_ms:
+            per_step = float(np.sum(att_ms)) / args.steps
+            fl = B * attention_flops(D, L, h * w)
+            line["roofline_attention"] = {"kernel": "attention_kernel<64> (fused softmax(QK^T)V, LDS-staged K/V tiles)",
+                                          "bound": "mfma", "achieved": fl / (per_step * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": fl / (per_step * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                                          "launch_ms": float(np.mean(att_ms)), "launches_per_step": len(att_ms) // args.steps,
+                                          "flops_per_step": fl, "traffic": None}
+        st = None
         if not args.no_stages:
             try:
                 st = stage_times(model, image, points)
-                if "upsampler_ms" in st:
-                    st["featurizer+upsampler_images_per_sec"] = args.batch / ((st["featurizer_ms"] + st["upsampler_ms"]) * 1e-3)
                 line["stages"] = st
             except Exception as exc:  # the headline number must survive a failure of the extras
                 line["stages"] = {"error": repr(exc)}
+        up_ms_in = t_up.mean_ms()
+        up_ms_seq = None if not st else st.get("upsampler(+resize)_ms", st.get("upsampler_ms"))
+        by = upsampler_bytes(args.upsampler, D, h, w, S, S)
+        if by is not None and (up_ms_seq or up_ms_in):
+            ms = up_ms_seq or up_ms_in
+            gbs = B * by / (ms * 1e-3) / 1e9
+            line["roofline_upsampler"] = {"kernel": f"{args.upsampler} stage incl. the resize to the image size "
+                                                    "(jbu_kernels / jbu_apply / jbu_apply_resized, range proj, pooling)",
+                                          "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": gbs / HBM_PEAK_GBS, "ms_per_step": ms, "bytes_per_step": B * by,
+                                          "traffic": None,
+                                          "note": "time = the stage run on its own (stages.*): inside the step its guidance-only half "
+                                                  f"overlaps the ViT on a second stream (main-stream share {up_ms_in:.2f} ms)"
+                                          if up_ms_seq and up_ms_in else "HIP events inside the timed steps"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, args.size, args.upsampler, seed=1000)
+            line["cpu_baseline"] = cpu_baseline(sd, S, args.upsampler, vit, seed=1000, full=args.cpu_baseline_full)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_train(args):
+    world, rank, dist, barrier, max_over_ranks = _dist_setup(args)
+    import logging
+    logging.getLogger("root").setLevel(logging.WARNING)
+    from isegprobe_amd.core.training.trainer import DataParallelTrainer
+
+    vit = VITS[args.arch]
+    torch.manual_seed(0)
+    model = build(args.upsampler, args.size, args.arch).cuda()  # identical replicas: same seed on every rank
+    trainer = DataParallelTrainer(model, lr=5e-5)
+    batch = synthetic_train_batch(args.batch, args.size, seed=2000 + rank)
+    ar_ms = []
+    orig = trainer.bucket.all_reduce_mean
+
+    def timed_all_reduce(*a, **k):  # HIP events around the RCCL all-reduce (torch enqueues it on its NCCL stream and
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # joins the current one)
+        s.record()
+        r = orig(*a, **k)
+        e.record()
+        ar_ms.append((s, e))
+        return r
+    for _ in range(args.warmup):
+        trainer.step(batch, num_iters=args.sim_clicks)
+    barrier()
+    trainer.bucket.all_reduce_mean = timed_all_reduce
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(batch, num_iters=args.sim_clicks)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(loss)
+    if rank == 0:
+        B, S, D = args.batch, args.size, vit["embed_dim"]
+        nbytes = trainer.bucket.nbytes()
+        ar = float(np.mean([s.elapsed_time(e) for s, e in ar_ms])) if ar_ms else None
+        line = {
+            "metric": "images/sec, SBD-shaped train step (fwd + HIP backward + RCCL gradient all-reduce + Adam)",
+            "value": world * B * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.arch} + {args.upsampler} + ConvSegHead({D},2,1), {S}x{S} crops, batch {B}/GPU, clicks before "
+                                   f"the backbone, {args.sim_clicks} simulated corrective clicks per step, seeded random-init weights",
+                       "per_gpu_batch": B, "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}"},
+            "collective": {"op": "all_reduce(sum)/world of ONE flat fp32 bucket (trainable gradients: embed_coords + head)",
+                           "backend": "nccl (RCCL)" if world > 1 else "none (single process)", "bytes": nbytes,
+                           "ms_per_step": ar if world > 1 else 0.0,
+                           "bus_GBs": (2.0 * (world - 1) / world * nbytes / (ar * 1e-3) / 1e9) if (world > 1 and ar) else None},
+            "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _worker(rank, world, port, argv):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.argv = argv
+    main()
+
+
+def _spawn(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks here.  The parent never touches the GPU and
+    never replaces itself; it starts fresh interpreters (spawn) and waits for them."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, args.gpus, port, list(sys.argv))) for r in range(args.gpus)]
+    for p in procs:
+        p.start()
+    code = 0
+    for p in procs:
+        p.join()
+        code = code or (p.exitcode or 0)
+    raise SystemExit(code)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", choices=("forward", "train"), default="forward")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (forward: 32; train: 32)")
+    ap.add_argument("--size", type=int, default=None, help="forward: 448; train: 224 (reference crop_size, train_cfg.yaml:22)")
+    ap.add_argument("--arch", default=None, help="dinov2_vits14 (forward default, train on 1 GPU) | dinov2_vitb14 (train, "
+                                                 "configs[4]) | dinov2_vitl14")
+    ap.add_argument("--upsampler", default=None, help="forward: jbu_featup; train: loftup")
+    ap.add_argument("--sim-clicks", type=int, default=0, help="train: simulated corrective clicks (no-grad forwards) per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="batch-8 CPU baseline as the median of 3 runs (slow)")
+    ap.add_argument("--no-stages", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    train = args.mode == "train"
+    args.steps = args.steps if args.steps is not None else (10 if train else 20)
+    args.warmup = args.warmup if args.warmup is not None else (3 if train else 5)
+    args.batch = args.batch if args.batch is not None else 32
+    args.size = args.size if args.size is not None else (224 if train else 448)
+    args.arch = args.arch or ("dinov2_vitb14" if train else "dinov2_vits14")
+    args.upsampler = args.upsampler or ("loftup" if train else "jbu_featup")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _spawn(args)
+    (run_dry if args.dry_run else run_train if train else run_forward)(args)
 
 
 if __name__ == "__main__":

@@ -73,7 +73,7 @@ class DataParallelTrainer:
         self.bucket.zero()
         loss, _ = self.batch_forward(batch, num_iters)
         loss.backward()
-        work = self.bucket.all_reduce_mean(async_op=True)  # gradient step only; overlaps host-side bookkeeping
-        self.bucket.finish(work)
+        self.bucket.check_bound()     # a zero_grad(set_to_none=True) by the caller would have detached the views
+        self.bucket.all_reduce_mean()  # gradient step only: every gradient is needed, so there is nothing to overlap with
         self.optim.step()
         return loss.detach()

@@ -81,7 +81,11 @@ class GradBucket:
 
     ``params`` order is fixed at construction (must match on every rank).  The bucket is a single
     contiguous tensor on the parameters' device; ``.grad`` of each parameter becomes a view into it, so
-    backward writes straight into the bucket and no copy precedes the collective."""
+    backward writes straight into the bucket and no copy precedes the collective.
+
+    Do NOT call ``optimizer.zero_grad()`` / ``model.zero_grad()`` on these parameters (torch's default
+    ``set_to_none=True`` drops the views and the all-reduce would then average stale zeros): use ``zero()``, which
+    also re-binds any view that was dropped; ``check_bound()`` raises if a gradient no longer aliases the bucket."""
 
     def __init__(self, params, dtype=torch.float32):
         self.params = [p for p in params if p.requires_grad]
@@ -90,16 +94,30 @@ class GradBucket:
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
         self.flat = torch.zeros(sum(sizes), device=dev, dtype=dtype)
+        self._offsets = []
         off = 0
         for p, n in zip(self.params, sizes):
-            p.grad = self.flat[off:off + n].view_as(p)
+            self._offsets.append(off)
             off += n
+        self._bind()
+
+    def _bind(self):
+        for p, off in zip(self.params, self._offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+
+    def check_bound(self):
+        for p, off in zip(self.params, self._offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                raise RuntimeError("GradBucket: a parameter's .grad no longer aliases the flat bucket (zero_grad(set_to_none=True)"
+                                   " or a re-assigned .grad); use GradBucket.zero() instead of zero_grad()")
 
     def nbytes(self):
         return self.flat.numel() * self.flat.element_size()
 
     def zero(self):
         self.flat.zero_()
+        self._bind()
 
     def all_reduce_mean(self, async_op=False):
         """Average gradients across ranks (what DDP does); returns the work handle when async."""

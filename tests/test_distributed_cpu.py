@@ -81,3 +81,40 @@ def test_single_process_noops():
     b = D.GradBucket([p])
     (p * 2).sum().backward()
     assert b.all_reduce_mean() is None and torch.equal(b.flat, torch.full((3,), 2.0))
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_multi_gpu_launch_plumbing(launcher):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own two ranks (round 1 exited with SystemExit there);
+    under torch.distributed.run it uses the ranks it is given.  Dry run: CPU + gloo, no GPU work."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--mode", "train"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29641"] + cmd[1:]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["max_dt"] >= 0.02  # max over ranks, printed once
+
+
+def test_grad_bucket_survives_zero_grad():
+    """zero_grad(set_to_none=True) -- torch's default -- detaches .grad from the flat bucket; the all-reduce would then
+    average stale zeros and the replicas diverge.  check_bound() catches it, zero() re-binds the views."""
+    from isegprobe_amd.core.utils import distributed as D
+    m = torch.nn.Linear(4, 3)
+    b = D.GradBucket(m.parameters())
+    m(torch.ones(2, 4)).sum().backward()
+    assert b.flat.abs().sum() > 0
+    b.check_bound()
+    torch.optim.SGD(m.parameters(), lr=0.1).zero_grad()  # set_to_none=True
+    with pytest.raises(RuntimeError):
+        b.check_bound()
+    b.zero()
+    b.check_bound()
+    m(torch.ones(2, 4)).sum().backward()
+    assert b.flat.abs().sum() > 0 and m.weight.grad.data_ptr() == b.flat.data_ptr()

@@ -31,16 +31,18 @@ def _batch():
     return image, gt, torch.from_numpy(pts)
 
 
-def _worker(rank, world, port, out):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, out, backend="gloo"):
+    dev = rank if backend == "nccl" else 0  # RCCL wants one device per rank; gloo lets two ranks share the one GPU
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(dev), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from helpers import build_model, seeded_
     from isegprobe_amd.core.training.trainer import DataParallelTrainer
     from isegprobe_amd.core.utils import distributed as D
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(dev)
     if world > 1:
-        assert D.init_distributed("gloo")
+        assert D.init_distributed(backend)
     model = seeded_(build_model("bilinear", injection="before_backbone"), 9).cuda()
     image, gt, pts = _batch()
     sl = slice(rank * 4 // world, (rank + 1) * 4 // world)
@@ -50,8 +52,7 @@ def _worker(rank, world, port, out):
     trainer.bucket.zero()
     loss, _ = trainer.batch_forward(batch, num_iters=0)
     loss.backward()
-    work = trainer.bucket.all_reduce_mean(async_op=True)
-    trainer.bucket.finish(work)
+    trainer.bucket.all_reduce_mean()
     grads = trainer.bucket.flat.clone().cpu()
     for _ in range(2):
         trainer.step(batch, num_iters=0)
@@ -62,11 +63,16 @@ def _worker(rank, world, port, out):
         torch.distributed.destroy_process_group()
 
 
-def test_two_rank_train_step_on_one_gpu():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_train_step(backend):
+    """gloo: both ranks on the one GPU of the box.  nccl (= RCCL over xGMI, the production backend,
+    core/utils/distributed.py:66-78 / exp.py:33-36 of the reference): one GPU per rank, needs two visible devices."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one device per rank; this box has one GPU")
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, backend)) for r in range(2)]
     procs.append(ctx.Process(target=_worker, args=(0, 1, _free_port(), out)))  # the whole batch in one process
     for p in procs:
         p.start()
