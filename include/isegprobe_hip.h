@@ -229,11 +229,11 @@ int isp_loftup_fourier_cn_f32(const float* image, const float* minmax_c2, const 
                               const float* bias_cos, const float* gamma, const float* beta, float* out_f32, int B, int H, int W,
                               int n_freqs, int ldo, float eps, void* stream);
 
-/* ---- LiFT image pyramid (LiFT.py:70-91,106-112): 3x3 / stride 2 / pad 1 conv to 32 channels with
- * folded eval-BatchNorm + ReLU (input NCHW f32 with 3 channels, or NHWC bf16 with 32), weights
- * w [32][3][3][cin] f32; and F.adaptive_max_pool2d on NHWC bf16. */
+/* ---- LiFT image pyramid (LiFT.py:70-91,106-112): 3x3 / stride 2 / pad 1 conv to 32 channels (input NCHW f32 with
+ * 3 channels, or NHWC bf16 with 32), weights w [32][3][3][cin] f32; relu != 0: eval-BatchNorm folded into w/bias
+ * by the caller + ReLU; relu == 0: the raw conv, ahead of isp_bn_train_*.  And F.adaptive_max_pool2d on NHWC bf16. */
 int isp_conv3x3_s2_c32(const void* in, int in_is_nchw_f32, int cin, const float* w, const float* bias,
-                       void* out_nhwc_bf16, int B, int H, int W, void* stream);
+                       void* out_nhwc_bf16, int B, int H, int W, int relu, void* stream);
 int isp_adaptive_max_pool_nhwc_bf16(const void* in, void* out, int B, int H, int W, int OH, int OW, int C, void* stream);
 
 /* ---- BaseClassifierHead.classifier (1x1 conv C->1), heads/base_head.py:15.
@@ -258,6 +258,21 @@ int isp_tn_gemm_bf16_atomic(const void* P, long ldp, const void* Q, long ldq, fl
  * taps formed from one staged input patch (g [B,H,W,N], x [B,H,W,C] bf16 NHWC; dW fp32 [N][9*C], caller-zeroed,
  * fp32 atomics).  Autograd of ConvModule.conv.weight, heads/conv_heads.py:51-73 under trainer.py:219-226. */
 int isp_conv3x3_wgrad_bf16_atomic(const void* g, const void* x, float* dw, int B, int H, int W, int C, int N, void* stream);
+/* ---- train-mode BatchNorm2d of the frozen upsamplers.  The reference's `self.net.train()` (core/training/trainer.py:214,
+ * 431) puts EVERY module in training mode, including the BatchNorm2d layers of the frozen LiFT (LiFT.py:19-24,71-76,88)
+ * and LoftUp (loftup/loftup.py:58,63): they normalise with batch statistics and update their running ones.
+ * x, y, dy, dx: bf16 [M = B*H*W][C] (NHWC); C % 8 == 0, C <= 2048; sums / gsums: fp32 [2*C], caller-zeroed.
+ *   isp_bn_train_stats  sums = {sum_m x, sum_m x^2}
+ *   isp_bn_train_apply  y = act((x - mean) * rsqrt(var + eps) * gamma + beta) from those sums (biased variance);
+ *                       new_mean/new_var (nullable, [c_real]) = (1-momentum)*running + momentum*{mean, unbiased var}
+ *   isp_bn_train_bwd    dx of the same op for dy taken AFTER the ReLU whose output is y (y nullable: no ReLU):
+ *                       g = dy*[y>0]; dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)); gsums = {sum g, sum g*xhat} */
+int isp_bn_train_stats(const void* x, float* sums, long M, int C, void* stream);
+int isp_bn_train_apply(const void* x, const float* sums, const float* gamma, const float* beta, void* y, long M, int C,
+                       float eps, int relu, const float* running_mean, const float* running_var, float* new_mean,
+                       float* new_var, int c_real, float momentum, void* stream);
+int isp_bn_train_bwd(const void* dy, const void* x, const void* y, const float* sums, const float* gamma, float* gsums,
+                     void* dx, long M, int C, float eps, void* stream);
 int isp_relu_mask_colsum(const void* dy, const void* y, void* g, float* colsum, long M, int N, void* stream);
 /* dx_colsum (nullable, [C], caller-zeroed): += column sums of dx = bias gradient of the conv that produced x.
  * relu_mask != 0: x is the output of a conv+ReLU layer and dx = (x > 0) * g * w (that layer's ReLU backward fused in);

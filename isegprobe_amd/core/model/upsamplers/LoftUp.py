@@ -15,8 +15,10 @@ under ``LoftUpUpsampler``).  The forward pass is HIP launches only:
     image and layer at 448^2, layers.py:182-198) -- here it never exists;
   * MinMaxScaler statistics are batch-global (per-shard under data parallelism, as in the
     reference's DDP).
-Train-mode BatchNorm statistics (the reference's ``net.train()`` quirk, trainer.py:214) are not
-mirrored: the frozen upsampler always uses its running statistics.
+Train-mode BatchNorm (the reference's ``net.train()``, trainer.py:214, also flips this frozen module's two
+BatchNorm2d layers, loftup.py:58,63): with the module in training mode the two 3x3 convs run unfolded and are
+followed by the batch-statistics BatchNorm kernels (running statistics updated as torch does).  Both layers see
+the image only, so no gradient passes through them.
 """
 import math
 import os
@@ -131,11 +133,15 @@ class LoftUpUpsampler(BaseUpsampler):
         super().__init__()
         self.upsampler = load_loftup_checkpoint(upsampler_path, n_dim, lr_pe_type, lr_size)
         self._packed = PackedCache()
+        self._packed_train = PackedCache()
         self._gcache = GuidanceCache()
         self._pe_cache = {}
 
-    # ---- weight packing (bf16, padded, BN folded)
-    def packed(self):
+    def _bn_train(self):
+        return self.upsampler.upsampler.first_conv[2].training
+
+    # ---- weight packing (bf16, padded, BN folded unless the module is in training mode)
+    def packed(self, train=False):
         def build():
             lu, cn = self.upsampler.upsampler, self.upsampler.channelnorm
             dev = cn.norm.weight.device
@@ -159,9 +165,12 @@ class LoftUpUpsampler(BaseUpsampler):
                 return out
 
             def conv_bn(conv, bn, cin_p, cout_p):  # fold eval BatchNorm, [N,C,3,3] -> [Np, 9*Cp]
-                s = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
-                w = conv.weight.detach().float() * s[:, None, None, None]
-                b = (conv.bias.detach().float() - bn.running_mean.float()) * s + bn.bias.detach().float()
+                if train:  # raw conv; its BatchNorm runs on batch statistics as a separate op
+                    w, b = conv.weight.detach().float(), conv.bias.detach().float()
+                else:
+                    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+                    w = conv.weight.detach().float() * s[:, None, None, None]
+                    b = (conv.bias.detach().float() - bn.running_mean.float()) * s + bn.bias.detach().float()
                 wt = torch.zeros(cout_p, 3, 3, cin_p, device=dev)
                 wt[:w.shape[0], :, :, :w.shape[1]] = w.permute(0, 2, 3, 1)
                 return wt.reshape(cout_p, 9 * cin_p).to(BF16).contiguous(), padvec(b, cout_p)
@@ -182,6 +191,8 @@ class LoftUpUpsampler(BaseUpsampler):
                      fc_cn_eps=lu.first_conv[0].norm.eps)
             P["conv1_w"], P["conv1_b"] = conv_bn(lu.first_conv[1], lu.first_conv[2], fin_p, cp)
             P["conv2_w"], P["conv2_b"] = conv_bn(lu.first_conv[4], lu.first_conv[5], cp, cp)
+            for name, bn in (("bn1", lu.first_conv[2]), ("bn2", lu.first_conv[5])):  # affine, zero on padded channels
+                P[name + "_g"], P[name + "_bt"] = padvec(f32(bn.weight), cp), padvec(f32(bn.bias), cp)
             layers = []
             for ca, ff in lu.ca_transformer.layers:
                 E = c
@@ -208,6 +219,8 @@ class LoftUpUpsampler(BaseUpsampler):
             P["fln_w"], P["fln_b"], P["fln_eps"] = f32(lu.final_conv[1].weight), f32(lu.final_conv[1].bias), lu.final_conv[1].eps
             self._pe_cache.clear()
             return P
+        if train:  # raw weights: independent of the running statistics the train-mode forward keeps updating
+            return self._packed_train.get(self._packed_train.tensors_of(lambda: list(self.upsampler.parameters())), build)
         params = self._packed.tensors_of(lambda: list(self.upsampler.parameters()) + [b for n, b in self.upsampler.named_buffers() if "running" in n])
         return self._packed.get(params, build)
 
@@ -238,7 +251,8 @@ class LoftUpUpsampler(BaseUpsampler):
 
     def _run(self, src, guidance, save):
         """The whole upsampler on NHWC bf16 LR features; `save` (a dict) collects what the backward needs."""
-        P = self.packed()
+        train = self._bn_train()
+        P = self.packed(train)
         B, h, w, C = src.shape
         guidance = guidance.float().contiguous()
         H, W = guidance.shape[2:]
@@ -255,18 +269,24 @@ class LoftUpUpsampler(BaseUpsampler):
             mm = ops.minmax_nchw(guidance)
             f = ops.loftup_fourier_cn(guidance, mm, P["freqs"], P["bias_sin"], P["bias_cos"], P["fc_cn_w"], P["fc_cn_b"],
                                       P["fin_p"], P["fc_cn_eps"])
+            if train:
+                from .LiFT import LiFTUpsampler
+                fc = self.upsampler.upsampler.first_conv
+                f = LiFTUpsampler._bn_forward(ops.conv3x3(f, P["conv1_w"], P["conv1_b"], None), fc[2], P["bn1_g"], P["bn1_bt"])[0]
+                return LiFTUpsampler._bn_forward(ops.conv3x3(f, P["conv2_w"], P["conv2_b"], None), fc[5], P["bn2_g"],
+                                                 P["bn2_bt"])[0].view(M, cp)
             f = ops.conv3x3(f, P["conv1_w"], P["conv1_b"], "relu")
             return ops.conv3x3(f, P["conv2_w"], P["conv2_b"], "relu").view(M, cp)
-        x = self._gcache.get(guidance, id(P), "x0", image_queries)
+        x = image_queries() if train else self._gcache.get(guidance, id(P), "x0", image_queries)
         scale = P["hd"] ** -0.5
         if save is not None:
-            save.update(kv=kv, layers=[], geom=(B, h, w, C, H, W))
+            save.update(kv=kv, layers=[], geom=(B, h, w, C, H, W), train=train)
         for li, L in enumerate(P["layers"]):
             def project_q(x=x, L=L):
                 qn = ops.layernorm(x, L["nq_w"], L["nq_b"], L["nq_eps"], D=c, ld_out=cp)
                 return ops.linear(qn, L["wq"], L["bq"]).view(B, H * W, heads, hdp)
             # the first layer's queries see the image only (x is still x0)
-            q = self._gcache.get(guidance, id(P), "q0", project_q) if li == 0 else project_q()
+            q = self._gcache.get(guidance, id(P), "q0", project_q) if (li == 0 and not train) else project_q()
             kn = ops.layernorm(kv, L["nkv_w"], L["nkv_b"], L["nkv_eps"], D=c, ld_out=cp)
             k = ops.linear(kn, L["wk"], L["bk"]).view(B, T, heads, hdp)
             v = ops.linear(kn, L["wv"], L["bv"]).view(B, T, heads, hdp)
@@ -290,9 +310,9 @@ class LoftUpUpsampler(BaseUpsampler):
             save.update(x_fin=x, y=y)
         return out.view(B, H, W, C)
 
-    def _bwd_weights(self):
+    def _bwd_weights(self, train=False):
         """Transposed (data-gradient) copies of the frozen projection weights, cached with the packed set."""
-        P = self.packed()
+        P = self.packed(train)
         if "bwd" not in P:
             t = lambda w: w.float().t().contiguous().to(BF16)
             P["bwd"] = dict(fin=t(P["fin_w"]),
@@ -304,7 +324,7 @@ class LoftUpUpsampler(BaseUpsampler):
         """d out / d src applied to g_out [B,H,W,C] bf16 (all weights frozen).  Mirrors loftup.py:100-138 under
         autograd: channel-LN -> 1x1 conv -> LN -> 2 x [FF, cross-attention (dK, dV; dQ only where the queries depend
         on the LR features, i.e. not in the first layer)] -> K/V LayerNorm -> ChannelNorm of the source."""
-        P, Wt = self.packed(), self._bwd_weights()
+        P, Wt = self.packed(saved["train"]), self._bwd_weights(saved["train"])
         B, h, w, C, H, W = saved["geom"]
         c, cp, heads, hdp = P["c"], P["cp"], P["heads"], P["hdp"]
         M, T = B * H * W, h * w

@@ -37,14 +37,23 @@ def get_next_points(pred, gt, points, click_indx, pred_thresh=0.49, rng=np.rando
 
 class DataParallelTrainer:
     def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, max_num_next_clicks=3,
-                 prev_mask_drop_prob=0.0, loss=None):
+                 prev_mask_drop_prob=0.0, loss=None, frozen_bn_batch_stats=True):
+        """``frozen_bn_batch_stats`` (default, = the reference): ``net.train()`` (trainer.py:214,431) also puts the
+        BatchNorm2d layers of the frozen LiFT / LoftUp upsamplers into batch-statistics mode (forward, backward and
+        running-statistics update).  False keeps the frozen upsampler in eval mode during the training forward."""
         self.net = model
+        self.frozen_bn_batch_stats = frozen_bn_batch_stats
         self.loss_fn = loss or NormalizedFocalLossSigmoid(alpha=0.5, gamma=2)
         self.max_num_next_clicks = max_num_next_clicks
         self.prev_mask_drop_prob = prev_mask_drop_prob
         params = [p for p in model.parameters() if p.requires_grad]
         self.bucket = D.GradBucket(params)
         self.optim = torch.optim.Adam(params, lr=lr, betas=betas, eps=eps)  # trainer.py:141, optimizer.py:14-35
+
+    def _train_mode(self):
+        self.net.train()
+        if not self.frozen_bn_batch_stats and isinstance(getattr(self.net, "upsampler", None), torch.nn.Module):
+            self.net.upsampler.eval()
 
     def batch_forward(self, batch: Dict, num_iters=None):
         """trainer.py:377-477 (training branch)."""
@@ -58,7 +67,7 @@ class DataParallelTrainer:
                 net_input = torch.cat((image, prev_output), dim=1) if self.net.with_prev_mask else image
                 prev_output = torch.sigmoid(self.net(net_input, points)["instances"])
                 points = get_next_points(prev_output, gt_mask, points, click_indx + 1)
-                self.net.train()
+                self._train_mode()
             if self.net.with_prev_mask and self.prev_mask_drop_prob > 0 and num_iters > 0:
                 zero = torch.from_numpy(np.random.random(size=prev_output.size(0)) < self.prev_mask_drop_prob)
                 prev_output[zero.to(prev_output.device)] = 0
@@ -69,7 +78,7 @@ class DataParallelTrainer:
 
     def step(self, batch: Dict, num_iters=None):
         """One optimisation step; returns the (rank-local) loss as a 0-dim tensor."""
-        self.net.train()
+        self._train_mode()
         self.bucket.zero()
         loss, _ = self.batch_forward(batch, num_iters)
         loss.backward()

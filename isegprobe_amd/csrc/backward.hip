@@ -222,6 +222,139 @@ __global__ __launch_bounds__(256) void relu_mask_colsum_kernel(const bf16_t* __r
 }
 
 // ---------------------------------------------------------------------------------------
+// Train-mode BatchNorm2d on an NHWC bf16 map seen as [M = B*H*W pixels] x [C channels].  The reference's
+// `self.net.train()` (core/training/trainer.py:214,431) also flips the FROZEN upsamplers' BatchNorm2d layers
+// (LiFT.py:19-24,71-76,88; loftup/loftup.py:58,63) to batch statistics; this is that forward and its backward.
+//   stats:  sums[0][c] += sum_m x, sums[1][c] += sum_m x^2      (fp32 partials per 256-row block, then atomics)
+//   apply:  y = act((x - mean) * rstd * gamma + beta),  mean = S1/M, var = S2/M - mean^2 (biased), rstd = rsqrt(var+eps);
+//           block 0 also emits the running statistics a torch BatchNorm would hold afterwards
+//           (new = (1-momentum) old + momentum {mean, var * M/(M-1)}).
+//   bwd:    g = dy * [y > 0];  dx = gamma * rstd * (g - mean_m(g) - xhat * mean_m(g * xhat)),  xhat = (x - mean) * rstd
+//           (two passes: the two column sums, then the elementwise combine).
+__device__ __forceinline__ void bn_mean_rstd(const float* __restrict__ sums, int C, int c, long M, float eps, float& mean,
+                                             float& rstd) {
+    const double m = (double)sums[c] / (double)M;
+    const double var = fmax((double)sums[C + c] / (double)M - m * m, 0.0);
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ sums, long M, int C) {
+    float* const out[2] = {sums, sums + C};
+    stream_rows_colsum<2>(M, C, out, [&](long r, int c8, float (&s)[2][8]) {
+        const uint4 a = *reinterpret_cast<const uint4*>(x + r * C + c8 * 8);
+        const unsigned* pa = &a.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(pa[e] << 16), hi = __uint_as_float(pa[e] & 0xffff0000u);
+            s[0][2 * e] += lo;
+            s[0][2 * e + 1] += hi;
+            s[1][2 * e] += lo * lo;
+            s[1][2 * e + 1] += hi * hi;
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ sums,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        bf16_t* __restrict__ y, long M, int C, float eps, int relu,
+                                                        const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                                        float* __restrict__ new_mean, float* __restrict__ new_var, int c_real,
+                                                        float momentum) {
+    const int cv = C >> 3;
+    const long total = M * cv;
+    if (blockIdx.x == 0 && new_mean)
+        for (int c = threadIdx.x; c < c_real; c += 256) {
+            const double m = (double)sums[c] / (double)M;
+            const double var = fmax((double)sums[C + c] / (double)M - m * m, 0.0);
+            const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            new_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * m);
+            new_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unbiased);
+        }
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % cv);
+        const uint4 a = *reinterpret_cast<const uint4*>(x + idx * 8);
+        const unsigned* pa = &a.x;
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v[2] = {__uint_as_float(pa[e] << 16), __uint_as_float(pa[e] & 0xffff0000u)};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = c8 * 8 + 2 * e + k;
+                float mean, rstd;
+                bn_mean_rstd(sums, C, c, M, eps, mean, rstd);
+                v[k] = (v[k] - mean) * rstd * gamma[c] + beta[c];
+                if (relu) v[k] = fmaxf(v[k], 0.f);
+            }
+            o[e] = pack2bf(v[0], v[1]);
+        }
+        *reinterpret_cast<uint4*>(y + idx * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ y, const float* __restrict__ sums,
+                                                            float* __restrict__ gsums, long M, int C, float eps) {
+    float* const out[2] = {gsums, gsums + C};
+    stream_rows_colsum<2>(M, C, out, [&](long r, int c8, float (&s)[2][8]) {
+        const uint4 a = *reinterpret_cast<const uint4*>(dy + r * C + c8 * 8);
+        const uint4 b = *reinterpret_cast<const uint4*>(x + r * C + c8 * 8);
+        uint4 m = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);  // ones: no ReLU mask
+        if (y) m = *reinterpret_cast<const uint4*>(y + r * C + c8 * 8);
+        const unsigned *pa = &a.x, *pb = &b.x, *pm = &m.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g[2] = {__uint_as_float(pm[e] << 16) > 0.f ? __uint_as_float(pa[e] << 16) : 0.f,
+                                __uint_as_float(pm[e] & 0xffff0000u) > 0.f ? __uint_as_float(pa[e] & 0xffff0000u) : 0.f};
+            const float xv[2] = {__uint_as_float(pb[e] << 16), __uint_as_float(pb[e] & 0xffff0000u)};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float mean, rstd;
+                bn_mean_rstd(sums, C, c8 * 8 + 2 * e + k, M, eps, mean, rstd);
+                s[0][2 * e + k] += g[k];
+                s[1][2 * e + k] += g[k] * (xv[k] - mean) * rstd;
+            }
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ y, const float* __restrict__ sums,
+                                                            const float* __restrict__ gsums, const float* __restrict__ gamma,
+                                                            bf16_t* __restrict__ dx, long M, int C, float eps) {
+    const int cv = C >> 3;
+    const long total = M * cv;
+    const float inv_m = 1.f / (float)M;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % cv);
+        const uint4 a = *reinterpret_cast<const uint4*>(dy + idx * 8);
+        const uint4 b = *reinterpret_cast<const uint4*>(x + idx * 8);
+        uint4 m = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        if (y) m = *reinterpret_cast<const uint4*>(y + idx * 8);
+        const unsigned *pa = &a.x, *pb = &b.x, *pm = &m.x;
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g[2] = {__uint_as_float(pm[e] << 16) > 0.f ? __uint_as_float(pa[e] << 16) : 0.f,
+                                __uint_as_float(pm[e] & 0xffff0000u) > 0.f ? __uint_as_float(pa[e] & 0xffff0000u) : 0.f};
+            const float xv[2] = {__uint_as_float(pb[e] << 16), __uint_as_float(pb[e] & 0xffff0000u)};
+            float r[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = c8 * 8 + 2 * e + k;
+                float mean, rstd;
+                bn_mean_rstd(sums, C, c, M, eps, mean, rstd);
+                const float xhat = (xv[k] - mean) * rstd;
+                r[k] = gamma[c] * rstd * (g[k] - gsums[c] * inv_m - xhat * gsums[C + c] * inv_m);
+            }
+            o[e] = pack2bf(r[0], r[1]);
+        }
+        *reinterpret_cast<uint4*>(dx + idx * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // 1x1 classifier backward, optionally fused with the ReLU mask of its input x (MASK: x is a post-ReLU conv output;
 // otherwise x is a signed feature map -- the "linear" head, or a conv head with num_layers = 0 -- and dx is unmasked):
 //   dx[m][c] = (!MASK || x[m][c] > 0) ? g[m] * w[c] : 0     dw[c] += sum_m g[m] * x[m][c]     db += sum_m g[m]
@@ -520,6 +653,36 @@ extern "C" int isp_relu_mask_colsum(const void* dy, const void* y, void* g, floa
     ISP_CHECK_ARG(dy && y && g && M > 0 && N > 0 && N % 8 == 0 && N <= RED_MAX_N);
     relu_mask_colsum_kernel<<<(unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(
         (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)g, colsum, M, N);
+    return isp_launch_status();
+}
+
+extern "C" int isp_bn_train_stats(const void* x, float* sums, long M, int C, void* stream) {
+    ISP_CHECK_ARG(x && sums && M > 0 && C > 0 && C % 8 == 0 && C <= RED_MAX_N);
+    bn_stats_kernel<<<(unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, sums, M, C);
+    return isp_launch_status();
+}
+
+extern "C" int isp_bn_train_apply(const void* x, const float* sums, const float* gamma, const float* beta, void* y, long M, int C,
+                                  float eps, int relu, const float* running_mean, const float* running_var, float* new_mean,
+                                  float* new_var, int c_real, float momentum, void* stream) {
+    ISP_CHECK_ARG(x && sums && gamma && beta && y && M > 0 && C > 0 && C % 8 == 0 && C <= RED_MAX_N);
+    ISP_CHECK_ARG(!new_mean || (running_mean && running_var && new_var && c_real > 0 && c_real <= C));
+    const long total = M * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    bn_apply_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)x, sums, gamma, beta, (bf16_t*)y, M, C, eps, relu,
+                                                          running_mean, running_var, new_mean, new_var, c_real, momentum);
+    return isp_launch_status();
+}
+
+extern "C" int isp_bn_train_bwd(const void* dy, const void* x, const void* y, const float* sums, const float* gamma,
+                                float* gsums, void* dx, long M, int C, float eps, void* stream) {
+    ISP_CHECK_ARG(dy && x && sums && gamma && gsums && dx && M > 0 && C > 0 && C % 8 == 0 && C <= RED_MAX_N);
+    bn_bwd_stats_kernel<<<(unsigned)((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), 256, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, sums, gsums, M, C, eps);
+    const long total = M * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    bn_bwd_apply_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, sums, gsums,
+                                                              gamma, (bf16_t*)dx, M, C, eps);
     return isp_launch_status();
 }
 

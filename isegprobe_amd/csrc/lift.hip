@@ -10,7 +10,7 @@ namespace {
 // out[b, oy, ox, n] = relu(bias[n] + sum_{ky,kx,c} in(b, 2oy-1+ky, 2ox-1+kx, c) * w[n][ky][kx][c]),
 // zero padding 1.  Input either NCHW fp32 (IN_NCHW_F32) or NHWC bf16; output NHWC bf16 with
 // COUT = 32.  One thread per output pixel; weights broadcast through scalar loads.
-template <int CIN, bool IN_NCHW_F32>
+template <int CIN, bool IN_NCHW_F32, bool RELU>
 __global__ __launch_bounds__(256) void conv3x3_s2_small_kernel(const void* __restrict__ in,
                                                                 const float* __restrict__ w /* [32][3][3][CIN] */,
                                                                 const float* __restrict__ bias, bf16_t* __restrict__ out,
@@ -60,13 +60,12 @@ __global__ __launch_bounds__(256) void conv3x3_s2_small_kernel(const void* __res
         }
     }
     bf16_t* o = out + idx * 32;
+    auto act = [](float v) { return RELU ? fmaxf(v, 0.f) : v; };  // RELU off: the raw conv, ahead of a train-mode BatchNorm
 #pragma unroll
     for (int n8 = 0; n8 < 4; ++n8)
         *reinterpret_cast<uint4*>(o + n8 * 8) =
-            make_uint4(pack2bf(fmaxf(acc[n8 * 8 + 0], 0.f), fmaxf(acc[n8 * 8 + 1], 0.f)),
-                       pack2bf(fmaxf(acc[n8 * 8 + 2], 0.f), fmaxf(acc[n8 * 8 + 3], 0.f)),
-                       pack2bf(fmaxf(acc[n8 * 8 + 4], 0.f), fmaxf(acc[n8 * 8 + 5], 0.f)),
-                       pack2bf(fmaxf(acc[n8 * 8 + 6], 0.f), fmaxf(acc[n8 * 8 + 7], 0.f)));
+            make_uint4(pack2bf(act(acc[n8 * 8 + 0]), act(acc[n8 * 8 + 1])), pack2bf(act(acc[n8 * 8 + 2]), act(acc[n8 * 8 + 3])),
+                       pack2bf(act(acc[n8 * 8 + 4]), act(acc[n8 * 8 + 5])), pack2bf(act(acc[n8 * 8 + 6]), act(acc[n8 * 8 + 7])));
 }
 
 // F.adaptive_max_pool2d on NHWC bf16 (window = [floor(i*in/out), ceil((i+1)*in/out)) ), 8 ch / thread
@@ -103,18 +102,22 @@ __global__ __launch_bounds__(256) void adaptive_max_pool_nhwc_kernel(const bf16_
 }  // namespace
 
 extern "C" int isp_conv3x3_s2_c32(const void* in, int in_is_nchw_f32, int cin, const float* w, const float* bias,
-                                  void* out_nhwc_bf16, int B, int H, int W, void* stream) {
+                                  void* out_nhwc_bf16, int B, int H, int W, int relu, void* stream) {
     ISP_CHECK_ARG(in && w && bias && out_nhwc_bf16 && B > 0 && H > 0 && W > 0);
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;  // k3 s2 p1
     const long total = (long)B * OH * OW;
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
-    if (in_is_nchw_f32 && cin == 3)
-        conv3x3_s2_small_kernel<3, true><<<grid, 256, 0, s>>>(in, w, bias, (bf16_t*)out_nhwc_bf16, H, W, OH, OW, total);
-    else if (!in_is_nchw_f32 && cin == 32)
-        conv3x3_s2_small_kernel<32, false><<<grid, 256, 0, s>>>(in, w, bias, (bf16_t*)out_nhwc_bf16, H, W, OH, OW, total);
-    else
+    bf16_t* o = (bf16_t*)out_nhwc_bf16;
+    if (in_is_nchw_f32 && cin == 3) {
+        if (relu) conv3x3_s2_small_kernel<3, true, true><<<grid, 256, 0, s>>>(in, w, bias, o, H, W, OH, OW, total);
+        else conv3x3_s2_small_kernel<3, true, false><<<grid, 256, 0, s>>>(in, w, bias, o, H, W, OH, OW, total);
+    } else if (!in_is_nchw_f32 && cin == 32) {
+        if (relu) conv3x3_s2_small_kernel<32, false, true><<<grid, 256, 0, s>>>(in, w, bias, o, H, W, OH, OW, total);
+        else conv3x3_s2_small_kernel<32, false, false><<<grid, 256, 0, s>>>(in, w, bias, o, H, W, OH, OW, total);
+    } else {
         return ISP_ERR_UNSUPPORTED;
+    }
     return isp_launch_status();
 }
 

@@ -644,9 +644,9 @@ def loftup_fourier_cn(image, mm, freqs, bias_sin, bias_cos, gamma, beta, ldo, ep
 
 
 # ---------------------------------------------------------------------------------- LiFT
-def conv3x3_s2_c32(x, w, bias):
-    """3x3 stride-2 pad-1 conv to 32 channels + ReLU.  x: NCHW f32 [B,3,H,W] or NHWC bf16 [B,H,W,32];
-    w [32,3,3,cin] f32 -> NHWC bf16 [B,ceil(H/2),ceil(W/2),32]."""
+def conv3x3_s2_c32(x, w, bias, relu=True):
+    """3x3 stride-2 pad-1 conv to 32 channels (+ ReLU unless relu=False).  x: NCHW f32 [B,3,H,W] or NHWC bf16
+    [B,H,W,32]; w [32,3,3,cin] f32 -> NHWC bf16 [B,ceil(H/2),ceil(W/2),32]."""
     nchw = x.dtype == torch.float32
     _need(x, torch.float32 if nchw else BF16, "x")
     if nchw:
@@ -654,9 +654,48 @@ def conv3x3_s2_c32(x, w, bias):
     else:
         B, H, W, cin = x.shape
     out = torch.empty(B, (H + 1) // 2, (W + 1) // 2, 32, device=x.device, dtype=BF16)
-    check(_lib.lib().isp_conv3x3_s2_c32(_p(x), int(nchw), cin, _p(w), _p(bias), _p(out), B, H, W, _stream()),
+    check(_lib.lib().isp_conv3x3_s2_c32(_p(x), int(nchw), cin, _p(w), _p(bias), _p(out), B, H, W, int(bool(relu)), _stream()),
           "isp_conv3x3_s2_c32")
     return out
+
+
+def bn_train(x, gamma, beta, eps, relu=True, running=None, momentum=0.1):
+    """Train-mode BatchNorm2d (+ReLU) of an NHWC bf16 map x [..., C] with batch statistics over all leading dims.
+    gamma / beta: f32 [C] (zero on padded channels).  running = (running_mean, running_var) f32 [c_real] asks for the
+    statistics a torch BatchNorm2d would hold after this forward (returned, not written in place).
+    Returns (y bf16, sums f32 [2C] for bn_train_bwd, (new_mean, new_var) or None)."""
+    _need(x, BF16, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    sums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    check(_lib.lib().isp_bn_train_stats(_p(x), _p(sums), M, C, _stream()), "isp_bn_train_stats")
+    y = torch.empty_like(x)
+    new = None
+    rm = rv = nm = nv = None
+    c_real = 0
+    if running is not None:
+        rm, rv = (_need(t.contiguous(), torch.float32, "running") for t in running)
+        c_real = rm.numel()
+        nm, nv = torch.empty_like(rm), torch.empty_like(rv)
+        new = (nm, nv)
+    check(_lib.lib().isp_bn_train_apply(_p(x), _p(sums), _p(gamma), _p(beta), _p(y), M, C, float(eps), int(bool(relu)),
+                                        _p(rm) if rm is not None else None, _p(rv) if rv is not None else None,
+                                        _p(nm) if nm is not None else None, _p(nv) if nv is not None else None, c_real,
+                                        float(momentum), _stream()), "isp_bn_train_apply")
+    return y, sums, new
+
+
+def bn_train_bwd(dy, x, y, sums, gamma, eps):
+    """Backward of bn_train w.r.t. x: dy is the gradient behind the ReLU whose output is y (y=None: no ReLU)."""
+    _need(dy, BF16, "dy")
+    _need(x, BF16, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    gsums = torch.zeros(2 * C, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    check(_lib.lib().isp_bn_train_bwd(_p(dy), _p(x), _p(y) if y is not None else None, _p(sums), _p(gamma), _p(gsums), _p(dx),
+                                      M, C, float(eps), _stream()), "isp_bn_train_bwd")
+    return dx
 
 
 def adaptive_max_pool_nhwc(x, OH, OW):

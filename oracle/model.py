@@ -39,7 +39,9 @@ def conv_head(x, w, prefix="head.", kind="convhead"):
 def forward(image, points, w, cfg):
     """image [B,3|4,H,W] in [0,1]; points [B,2P,3].  cfg keys: patch, depth, heads,
     injection, upsampler ('identity'|'nearest'|'bilinear'|'bicubic'|'lift'|'loftup'|'jbu_featup'),
-    with_prev_mask, use_disks, norm_radius.  Returns logits [B,1,H,W]."""
+    with_prev_mask, use_disks, norm_radius; optional bn_train (batch-statistics BatchNorm in the frozen
+    upsamplers, the reference's net.train()) and bn_stats_out (dict receiving the updated running statistics).
+    Returns logits [B,1,H,W]."""
     with torch.no_grad():
         return forward_with_grad(image, points, w, cfg)
 
@@ -73,10 +75,11 @@ def features_with_grad(image, points, w, cfg):
                                 click_tokens=clicks, injection=cfg.get("injection", "before_backbone"),
                                 prefix="backbone.model.")
         up = cfg.get("upsampler", "bilinear")
+        bn_train, stats = cfg.get("bn_train", False), cfg.get("bn_stats_out")  # net.train() semantics of the frozen upsamplers
         if up == "lift":
-            hr = ups.lift(feats, image, w, "upsampler.lift.")
+            hr = ups.lift(feats, image, w, "upsampler.lift.", bn_train=bn_train, stats=stats)
         elif up == "loftup":
-            hr = ups.loftup(feats, image, w, "upsampler.upsampler.")
+            hr = ups.loftup(feats, image, w, "upsampler.upsampler.", bn_train=bn_train, stats=stats)
         elif up == "jbu_featup":
             hr = ups.jbu_stack(feats, image, w, "upsampler.upsampler.")
         else:
@@ -84,3 +87,16 @@ def features_with_grad(image, points, w, cfg):
         if up != "identity" and hr.shape[2:] != image.shape[2:]:  # iseg_probe_model.py:120-129
             hr = F.interpolate(hr, size=image.shape[2:], mode="bilinear", align_corners=True)
         return hr, tuple(image.shape[2:])
+
+
+def nfl_loss(logits, label, alpha=0.5, gamma=2.0, eps=1e-12, ignore_label=-1):
+    """NormalizedFocalLossSigmoid with the trainer's settings (core/training/losses.py:11-109, detach_delimeter=True,
+    size_average=True, no max_mult; models/defaults.py builds it with alpha 0.5, gamma 2): per-sample losses [B]."""
+    p = torch.sigmoid(logits)
+    valid = label != ignore_label
+    pt = torch.where(valid, 1.0 - (label - p).abs(), torch.ones_like(p))
+    beta = (1.0 - pt) ** gamma
+    mult = (valid.sum(dim=(-2, -1), keepdim=True) / (beta.sum(dim=(-2, -1), keepdim=True) + eps)).detach()
+    a = torch.where(label > 0.5, alpha * valid, (1.0 - alpha) * valid)
+    loss = -a * (beta * mult) * torch.log(torch.clamp(pt + eps, max=1.0)) * valid
+    return loss.flatten(1).sum(1) / (valid.flatten(1).sum(1) + eps)

@@ -24,15 +24,27 @@ def bicubic(source, guidance):
     return F.interpolate(source, guidance.shape[2:], mode="bicubic")
 
 
-def _bn_eval(x, w, prefix, eps=1e-5):
-    return F.batch_norm(x, w[prefix + "running_mean"], w[prefix + "running_var"],
-                        w[prefix + "weight"], w[prefix + "bias"], False, 0.0, eps)
+def _bn_eval(x, w, prefix, eps=1e-5, train=False, stats=None):
+    """nn.BatchNorm2d.  train=False: running statistics (eval mode).  train=True: the reference's net.train()
+    (core/training/trainer.py:214,431) also flips the FROZEN upsamplers' BatchNorm2d layers to batch statistics
+    (LiFT.py:19-24,71-76,88; loftup/loftup.py:58,63); `stats`, if given, collects the running statistics the
+    train-mode forward would leave behind (momentum 0.1, unbiased variance)."""
+    if not train:
+        return F.batch_norm(x, w[prefix + "running_mean"], w[prefix + "running_var"],
+                            w[prefix + "weight"], w[prefix + "bias"], False, 0.0, eps)
+    rm, rv = w[prefix + "running_mean"].clone(), w[prefix + "running_var"].clone()
+    y = F.batch_norm(x, rm, rv, w[prefix + "weight"], w[prefix + "bias"], True, 0.1, eps)
+    if stats is not None:
+        stats[prefix + "running_mean"], stats[prefix + "running_var"] = rm, rv
+    return y
 
 
 # --- LiFT (core/model/upsamplers/LiFT.py:47-122), eval-mode BatchNorm --------
-def lift(source, guidance, w, prefix="lift."):
+def lift(source, guidance, w, prefix="lift.", bn_train=False, stats=None):
     """LiFTUpsampler.forward(source, guidance) = LiFT(imgs=guidance, x=source) (:145-146).
     Returns [B, C, 2h, 2w]."""
+    import functools
+    _bn_eval = functools.partial(globals()["_bn_eval"], train=bn_train, stats=stats)
     g = lambda k: w[prefix + k]
     ws = {k[len(prefix):]: v for k, v in w.items() if k.startswith(prefix)}
     x = source
@@ -121,10 +133,12 @@ def _mha(q, kv, w, prefix, heads):
     return F.linear(out, w[prefix + "out_proj.weight"], w[prefix + "out_proj.bias"])
 
 
-def loftup(source, guidance, w, prefix="upsampler.", heads=4, n_freqs=20, depth=2):
+def loftup(source, guidance, w, prefix="upsampler.", heads=4, n_freqs=20, depth=2, bn_train=False, stats=None):
     """LoftUpUpsampler.forward -> UpsamplerwithChannelNorm (loftup.py:141-149) -> LoftUp.forward
-    (:100-138), lr_pe_type="sine", eval-mode BatchNorm.  Key prefixes: ``channelnorm.``
+    (:100-138), lr_pe_type="sine"; BatchNorm in eval mode unless bn_train.  Key prefixes: ``channelnorm.``
     and ``upsampler.`` under ``prefix``."""
+    import functools
+    _bn_eval = functools.partial(globals()["_bn_eval"], train=bn_train, stats=stats)
     ws = {k[len(prefix):]: v for k, v in w.items() if k.startswith(prefix)}
     g = lambda k: ws[k]
     lr = _channel_ln(source, g("channelnorm.norm.weight"), g("channelnorm.norm.bias"))

@@ -633,12 +633,65 @@ def gen_inference():
     save("inference", **out)
 
 
+def gen_train_step():
+    """the reference iSegProbeModel in .train() (trainer.py:214 -- the frozen upsamplers'
+    BatchNorm2d layers then use BATCH statistics and update their running ones), one NormalizedFocalLossSigmoid step
+    (trainer.py:451-453, losses.py:11-109; alpha 0.5, gamma 2 as models/defaults.py builds it), gradients of every
+    trainable tensor (embed_coords.proj.*, head.*), and the parameters after one Adam step (lr 5e-5, optimizer.py:14-35)."""
+    from core.training.losses import NormalizedFocalLossSigmoid
+    rng = np.random.default_rng(7)
+    torch.manual_seed(7)
+    out = {}
+    H = W = 56
+    B = 3
+    img = torch.rand(B, 4, H, W)
+    img[:, 3] = (img[:, 3] > 0.7).float()
+    pts = torch.from_numpy(rand_points(rng, B, 3, H, W))
+    gt = torch.zeros(B, 1, H, W)
+    yy, xx = np.mgrid[:H, :W]
+    for b in range(B):
+        gt[b, 0] = torch.from_numpy((((yy - 20 - 5 * b) / 14.0) ** 2 + ((xx - 30 + 4 * b) / 18.0) ** 2 <= 1).astype(np.float32))
+    gt[0, 0, 40:46, 5:15] = -1  # ignore label
+    out["image"], out["points"], out["gt"] = img.numpy(), pts.numpy(), gt.numpy()
+    tiny = dict(np.load(os.path.join(OUT, "model_tiny.npz")))  # the weights live there (same seed): not stored twice
+    for up in ("bilinear", "lift", "loftup"):
+        model = build_ref_model(up, seed=40)
+        for n, p in model.named_parameters():
+            p.requires_grad_(n.startswith(("head.", "embed_coords.")))
+        for k, v in sd_np(model).items():
+            ref = tiny[(f"{up}_w::" if k.startswith("upsampler.") else "common_w::") + k]
+            assert np.array_equal(ref, v), k
+        with torch.no_grad():  # the same batch in eval mode (running statistics): pinned next to the train-mode forward
+            out[f"{up}_eval_logits"] = model.eval()(img, pts)["instances"].numpy()
+        model.train()
+        train_names = [n for n, p in model.named_parameters() if p.requires_grad]
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, betas=(0.9, 0.999), eps=1e-8)
+        logits = model(img, pts)["instances"]
+        per_sample = NormalizedFocalLossSigmoid(alpha=0.5, gamma=2)(logits, gt)
+        loss = torch.mean(per_sample)
+        opt.zero_grad()
+        loss.backward()
+        out[f"{up}_train_logits"] = logits.detach().numpy()
+        out[f"{up}_loss_per_sample"] = per_sample.detach().numpy()
+        named = dict(model.named_parameters())
+        for n in train_names:
+            out[f"{up}_grad::" + n] = named[n].grad.numpy().copy()
+        opt.step()
+        for n in ("head.classifier.weight", "embed_coords.proj.bias"):  # the optimizer is torch's on both sides: two small tensors
+            out[f"{up}_after_adam::" + n] = named[n].detach().numpy().copy()
+        for n, b in model.named_buffers():  # running statistics after the train-mode forward (momentum 0.1)
+            if n.startswith("upsampler.") and n.endswith(("running_mean", "running_var")):
+                out[f"{up}_after_fwd::" + n] = b.numpy().copy()
+        print(f"  {up}: loss {loss.item():.5f}  |train - eval logits| max {np.abs(out[f'{up}_train_logits'] - out[f'{up}_eval_logits']).max():.3g}")
+    save("train_step", **out)
+
+
 def main():
     torch.set_num_threads(4)
     install_standins()
-    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference"]
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "train_step"]
     fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino, "simple_vit": gen_simple_vit, "maskclip": gen_maskclip,
-           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference}
+           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "train_step": gen_train_step}
     for w in which:
         fns[w]()
 

@@ -138,3 +138,40 @@ def test_maskclip_features(golden, inj):
     y = ovit.maskclip_features(torch.from_numpy(g[inj + "_x"]), weights_from(g, "w"), patch=16, heads=2,
                                click_tokens=torch.from_numpy(g[inj + "_clicks"]), injection=inj)
     np.testing.assert_allclose(y.numpy(), g[inj + "_y"], atol=2e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ one reference train step
+@pytest.mark.parametrize("up", ["bilinear", "lift", "loftup"])
+def test_train_step_vs_reference(golden, up):
+    """The reference model in .train() -- batch-statistics BatchNorm in the frozen upsamplers -- one NFL loss, its
+    gradients and the running statistics it leaves (tests/golden/train_step.npz) against the oracle in bn_train mode,
+    and the product's loss module against the reference's per-sample losses."""
+    from oracle import model as omodel
+    from isegprobe_amd.core.training.losses import NormalizedFocalLossSigmoid
+    g, tiny = golden("train_step"), golden("model_tiny")
+    w = {**weights_from(tiny, "common_w"), **weights_from(tiny, up + "_w")}
+    train_keys = [k[len(up) + 7:] for k in g if k.startswith(up + "_grad::")]
+    for k in train_keys:
+        w[k] = w[k].clone().requires_grad_(True)
+    image, points, gt = (torch.from_numpy(g[k]) for k in ("image", "points", "gt"))
+    stats = {}
+    cfg = dict(patch=14, depth=2, heads=2, upsampler=up, injection="before_backbone", with_prev_mask=True,
+               use_disks=True, norm_radius=5, bn_train=True, bn_stats_out=stats)
+    logits = omodel.forward_with_grad(image, points, w, cfg)
+    np.testing.assert_allclose(logits.detach().numpy(), g[up + "_train_logits"], atol=2e-4, rtol=1e-4)
+    per_sample = omodel.nfl_loss(logits, gt)
+    np.testing.assert_allclose(per_sample.detach().numpy(), g[up + "_loss_per_sample"], atol=1e-6, rtol=1e-4)
+    ours = NormalizedFocalLossSigmoid(alpha=0.5, gamma=2)(torch.from_numpy(g[up + "_train_logits"]), gt)
+    np.testing.assert_allclose(ours.numpy(), g[up + "_loss_per_sample"], atol=1e-7, rtol=1e-5)
+    per_sample.mean().backward()
+    for k in train_keys:
+        ref = g[f"{up}_grad::{k}"]
+        np.testing.assert_allclose(w[k].grad.numpy(), ref, atol=2e-4 * np.abs(ref).max(), rtol=1e-3)
+    for k, v in stats.items():  # running statistics after the train-mode forward
+        np.testing.assert_allclose(v.numpy(), g[f"{up}_after_fwd::upsampler.{'lift' if up == 'lift' else 'upsampler'}.{k}"],
+                                   atol=1e-5, rtol=1e-4)
+    assert (up == "bilinear") == (len(stats) == 0)
+    cfg_eval = dict(cfg, bn_train=False, bn_stats_out=None)
+    with torch.no_grad():
+        np.testing.assert_allclose(omodel.forward(image, points, {k: v.detach() for k, v in w.items()}, cfg_eval).numpy(),
+                                   g[up + "_eval_logits"], atol=2e-4, rtol=1e-4)

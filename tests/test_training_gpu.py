@@ -72,14 +72,16 @@ def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
     for k in train_keys:
         w[k].requires_grad_(True)
     cfg = dict(patch=14, depth=2, heads=2, upsampler=upsampler, injection="before_backbone",
-               with_prev_mask=True, use_disks=True, norm_radius=5)
+               with_prev_mask=True, use_disks=True, norm_radius=5,
+               bn_train=True)  # model.train() below: batch-statistics BatchNorm in the frozen LiFT / LoftUp, as in the reference
     coef = torch.randn(2, 1, 56, 56)
     ref_out = omodel.forward_with_grad(image, points, w, cfg)
     (ref_out * coef).sum().backward()
     model = model.cuda().train()
     out = model(image.cuda(), points.cuda())["instances"]
     assert out.requires_grad
-    # the training forward (statistics saved) computes the same logits as the inference path
+    # the training forward (statistics saved) computes the same logits as the no-grad path in the same mode
+    # (lift / loftup: each train-mode forward also moves the running statistics, which batch-statistics BN does not read)
     with torch.no_grad():
         assert (model(image.cuda(), points.cuda())["instances"] - out).abs().max().item() < 2e-2
     assert (out.detach().cpu() - ref_out.detach()).abs().max().item() < 2e-2 * (1 + ref_out.abs().max().item())
@@ -137,6 +139,80 @@ def test_signed_input_classifier_gradients(head_type, layers):
         # no ReLU between the features and the logits for the first two cases: nothing can flip, so the trunk-only
         # agreement (cos 0.9999) must hold; a masked dx gave cos ~0.7 on embed_coords here
         assert cos > (0.999 if head_type != "simple_conv" else 0.99), (k, cos, rms)
+
+
+@pytest.mark.parametrize("up", ["bilinear", "lift", "loftup"])
+def test_train_step_vs_reference_fixture(golden, up):
+    """One train-mode forward + NFL loss + backward on the HIP path against what the REFERENCE's own model produced in
+    .train() (tests/golden/train_step.npz): train-mode logits (batch-statistics BatchNorm in the
+    frozen LiFT / LoftUp), per-sample losses, gradients of every trainable tensor, the running statistics left behind,
+    and the eval-mode logits of the same batch (which differ from the train-mode ones by up to 0.9)."""
+    from conftest import weights_from
+    from isegprobe_amd.core.training.losses import NormalizedFocalLossSigmoid
+    g, tiny = golden("train_step"), golden("model_tiny")
+    model = build_model(up, upsampler_params=UP_PARAMS.get(up))
+    missing, unexpected = model.load_state_dict({**weights_from(tiny, "common_w"), **weights_from(tiny, up + "_w")}, strict=False)
+    assert not unexpected and all(("mask_token" in k or "num_batches_tracked" in k) for k in missing), missing
+    model = model.cuda()
+    image, points, gt = (torch.from_numpy(g[k]).cuda() for k in ("image", "points", "gt"))
+    with torch.no_grad():
+        ev = model.eval()(image, points)["instances"].cpu().numpy()
+    assert np.abs(ev - g[up + "_eval_logits"]).max() < 2e-2
+    model.train()
+    logits = model(image, points)["instances"]
+    err = np.abs(logits.detach().cpu().numpy() - g[up + "_train_logits"]).max()
+    per_sample = NormalizedFocalLossSigmoid(alpha=0.5, gamma=2)(logits, gt)
+    per_sample.mean().backward()
+    print(f"{up}: train-mode logits max err {err:.3g} (train vs eval logits differ by {np.abs(g[up + '_train_logits'] - g[up + '_eval_logits']).max():.3g}); "
+          f"loss {per_sample.mean().item():.5f} vs {g[up + '_loss_per_sample'].mean():.5f}")
+    assert err < 2e-2
+    np.testing.assert_allclose(per_sample.detach().cpu().numpy(), g[up + "_loss_per_sample"], rtol=2e-2, atol=1e-3)
+    named = dict(model.named_parameters())
+    for k in [k[len(up) + 7:] for k in g if k.startswith(up + "_grad::")]:
+        got, ref = named[k].grad.cpu(), torch.from_numpy(g[f"{up}_grad::{k}"])
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item()
+        rms = (got - ref).pow(2).mean().sqrt().item() / (ref.pow(2).mean().sqrt().item() + 1e-12)
+        print(f"{up} {k:32s} rms-rel {rms:.3e}  cos {cos:.6f}")
+        assert cos > 0.99 and rms < 0.15, (k, cos, rms)
+    for k in [k for k in g if k.startswith(up + "_after_fwd::")]:  # running statistics after ONE train-mode forward
+        name = k.split("::", 1)[1]
+        got = dict(model.named_buffers())[name].cpu().numpy()
+        np.testing.assert_allclose(got, g[k], rtol=2e-2, atol=2e-3, err_msg=name)
+
+
+def test_bn_train_kernels_vs_torch():
+    """isp_bn_train_{stats,apply,bwd} against torch's BatchNorm2d in training mode (+ReLU): output, running statistics,
+    input gradient; padded channels (gamma = beta = 0 on zero data) stay zero."""
+    from isegprobe_amd import hip_ops as ops
+    torch.manual_seed(0)
+    B, H, W, C, Cp = 3, 17, 23, 40, 64
+    x = torch.zeros(B, H, W, Cp, device="cuda")
+    x[..., :C] = torch.randn(B, H, W, C, device="cuda") * 1.5 + 0.7
+    xb = x.to(torch.bfloat16)
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C) * 0.3 + 1)
+        bn.bias.copy_(torch.randn(C) * 0.2)
+        bn.running_mean.copy_(torch.randn(C) * 0.1)
+        bn.running_var.copy_(torch.rand(C) + 0.5)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    xr = xb[..., :C].float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = torch.relu(bn(xr))
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    gamma, beta = torch.zeros(Cp, device="cuda"), torch.zeros(Cp, device="cuda")
+    gamma[:C], beta[:C] = bn.weight.detach(), bn.bias.detach()
+    y, sums, (nm, nv) = ops.bn_train(xb, gamma, beta, bn.eps, True, (rm0, rv0), bn.momentum)
+    assert (y[..., :C].float().permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-2
+    assert y[..., C:].abs().max().item() == 0
+    assert (nm - bn.running_mean).abs().max().item() < 1e-4 and (nv - bn.running_var).abs().max().item() < 1e-3
+    gyp = torch.zeros(B, H, W, Cp, device="cuda", dtype=torch.bfloat16)
+    gyp[..., :C] = gy.permute(0, 2, 3, 1).to(torch.bfloat16)
+    dx = ops.bn_train_bwd(gyp, xb, y, sums, gamma, bn.eps)
+    gref = xr.grad.permute(0, 2, 3, 1)
+    rel = (dx[..., :C].float() - gref).pow(2).mean().sqrt().item() / gref.pow(2).mean().sqrt().item()
+    assert rel < 2e-2, rel
+    assert dx[..., C:].abs().max().item() == 0
 
 
 # ------------------------------------------------------------------ device click simulation (SURVEY.md 8(f) rank 3)
