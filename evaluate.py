@@ -5,6 +5,9 @@ NoC table).
 
     python evaluate.py --dataset /path/to/GrabCut --checkpoint ckpt.pth --eval-mode fixed224
     python evaluate.py --synthetic 50                 # GrabCut-layout fixture of seeded ellipses
+    python evaluate.py +checkpoint=/path/to/ckpt +datasets=GrabCut,Berkeley eval_mode=fixed224 n_clicks=20
+                                                      # the reference's Hydra form (README.md:97-103; keys of
+                                                      # configs/eval_cfg.yaml; dataset roots from main_cfg_path's DATASETS)
 """
 import argparse
 import os
@@ -37,7 +40,32 @@ def main():
                     help="robot user + IoU on the host (numpy/scipy) as in the reference, instead of the device clicker")
     ap.add_argument("--fp32", action="store_true",
                     help="checking mode: fp32-accurate arithmetic (model.forward_fp32, three bf16 products; 3-4x slower)")
-    args = ap.parse_args()
+    from isegprobe_amd.core.utils.overrides import DATASET_PATH_KEYS, EVAL_DEFAULTS, apply_overrides, split_overrides
+    overrides, rest = split_overrides(sys.argv[1:])
+    args = ap.parse_args(rest)
+    jobs = None  # [(dataset name, root)]
+    print_ious = True
+    if overrides:
+        cfg = apply_overrides(EVAL_DEFAULTS, overrides)
+        given = {k for k, _, _ in overrides}
+        if cfg["mode"] != "NoBRS":
+            raise SystemExit("only mode=NoBRS is built (every experiment of the reference used it, eval_cfg.yaml:13-14)")
+        if cfg["eval_ritm"]:
+            raise SystemExit("eval_ritm=true is outside the probed path")
+        args.checkpoint = cfg["checkpoint"] if "checkpoint" in given else args.checkpoint
+        args.eval_mode, args.n_clicks, args.thresh = str(cfg["eval_mode"]), int(cfg["n_clicks"]), float(cfg["thresh"])
+        args.target_iou, print_ious = float(cfg["target_iou"]), bool(cfg["print_ious"])
+        if cfg["logs_path"]:
+            args.logs = str(cfg["logs_path"])
+        if "datasets" in given and not args.dataset and not args.synthetic:
+            import yaml
+            if not os.path.exists(str(cfg["main_cfg_path"])):
+                raise SystemExit(f"datasets={cfg['datasets']}: dataset roots come from {cfg['main_cfg_path']} (DATASETS.<NAME>_PATH), "
+                                 "which does not exist; give --dataset ROOT --dataset-name NAME instead")
+            roots = (yaml.safe_load(open(str(cfg["main_cfg_path"]))) or {}).get("DATASETS", {})
+            jobs = [(n, roots[DATASET_PATH_KEYS[n]]) for n in str(cfg["datasets"]).split(",")]
+    # inference/utils.py:254-257: printing the per-click IoUs forces every click to run; otherwise stop at target_iou >= 0.8
+    max_iou_thr = 1.01 if print_ious else max(0.8, args.target_iou)
 
     import isegprobe_amd
     from isegprobe_amd.core.inference.datasets import get_dataset, write_synthetic_grabcut
@@ -71,23 +99,25 @@ def main():
     if args.synthetic:
         tmp = tempfile.TemporaryDirectory()
         args.dataset = str(write_synthetic_grabcut(tmp.name, args.synthetic))
-    if not args.dataset:
-        raise SystemExit("give --dataset or --synthetic N")
-    dataset = get_dataset(args.dataset_name, args.dataset)
+    if jobs is None:
+        if not args.dataset:
+            raise SystemExit("give --dataset, --synthetic N or +datasets=...")
+        jobs = [(args.dataset_name, args.dataset)]
     predictor = get_predictor(model, "NoBRS", device, prob_thresh=args.thresh,
                               zoom_in_params={"skip_clicks": -1, "target_size": crop})
-    # print_ious=True in the reference forces all n_clicks to run (inference/utils.py:254-255)
-    all_ious, elapsed = evaluate_dataset(dataset, predictor, pred_thr=args.thresh, max_iou_thr=1.01,
-                                         min_clicks=1, max_clicks=args.n_clicks,
-                                         device_clicker=False if args.host_clicker else None)
-    # the reference's table / log files (inference/utils.py:174-246,365-543); SPC printed with 4 digits as well
     from isegprobe_amd.core.inference.utils import save_iou_analysis_data, save_results
     logs = args.logs or tempfile.mkdtemp(prefix="isegprobe_eval_")
-    results = save_results(model.upsampler.__class__.__name__, args.dataset_name, logs, (all_ious, elapsed),
-                           eval_mode=args.eval_mode, n_clicks=args.n_clicks, target_iou=1.01, print_ious=True,
-                           save_ious=True)
-    save_iou_analysis_data(args.dataset_name, logs, (all_ious, elapsed), eval_mode=args.eval_mode, n_clicks=args.n_clicks)
-    print(f"SPC {elapsed / max(sum(len(x) for x in all_ious), 1):.4f} s; logs, IoU pickles: {logs}")
+    for i, (name, root) in enumerate(jobs):
+        dataset = get_dataset(name, root)
+        all_ious, elapsed = evaluate_dataset(dataset, predictor, pred_thr=args.thresh, max_iou_thr=max_iou_thr,
+                                             min_clicks=1, max_clicks=args.n_clicks,
+                                             device_clicker=False if args.host_clicker else None)
+        # the reference's table / log files (inference/utils.py:174-246,365-543); NoC thresholds up to target_iou
+        save_results(model.upsampler.__class__.__name__, name, logs, (all_ious, elapsed), eval_mode=args.eval_mode,
+                     n_clicks=args.n_clicks, target_iou=max_iou_thr if print_ious else args.target_iou, print_ious=print_ious,
+                     save_ious=True, print_header=i == 0)
+        save_iou_analysis_data(name, logs, (all_ious, elapsed), eval_mode=args.eval_mode, n_clicks=args.n_clicks)
+        print(f"{name}: SPC {elapsed / max(sum(len(x) for x in all_ious), 1):.4f} s; logs, IoU pickles: {logs}")
     if tmp:
         tmp.cleanup()
 

@@ -125,11 +125,12 @@ def save_iou_analysis_data(dataset_name, logs_path, dataset_results, eval_mode="
     return path
 
 
-def load_single_is_model(state_dict, device, **kwargs):
+def load_single_is_model(state_dict, device, eval_ritm=False, **kwargs):
     """core/inference/utils.py:60-83: rebuild the model from the checkpoint's config, load the saved (trainable) weights
-    over the freshly constructed ones, freeze, move, eval."""
+    over the freshly constructed ones, freeze, move, eval.  ``eval_ritm`` keeps the reference's positional slot
+    (RITM-style evaluation is outside the probed path: True raises)."""
     from ..utils.serialization import load_model
-    model = load_model(state_dict["config"], **kwargs)
+    model = load_model(state_dict["config"], eval_ritm, **kwargs)
     current = model.state_dict()
     current.update(state_dict["state_dict"])
     model.load_state_dict(current, strict=False)
@@ -138,13 +139,15 @@ def load_single_is_model(state_dict, device, **kwargs):
     return model.to(device).eval()
 
 
-def load_is_model(checkpoint, device, **kwargs):
-    """core/inference/utils.py:37-57: a checkpoint path / dict, or a list of them (per-click models)."""
+def load_is_model(checkpoint, device, eval_ritm=False, **kwargs):
+    """core/inference/utils.py:37-57: a checkpoint path / dict, or a list of them (per-click models); same positional
+    signature as the reference (``load_is_model(ckpt, device, cfg.eval_ritm)``, evaluate.py:80)."""
     import torch
     from pathlib import Path
     import isegprobe_amd
     isegprobe_amd.install_as_core()  # checkpoints name core.* classes and pickle core.utils.model_builder.ModelBuilder
     sd = torch.load(checkpoint, map_location="cpu", weights_only=False) if isinstance(checkpoint, (str, Path)) else checkpoint
     if isinstance(sd, list):
-        return load_single_is_model(sd[0], device, **kwargs), [load_single_is_model(x, device, **kwargs) for x in sd]
-    return load_single_is_model(sd, device, **kwargs)
+        return (load_single_is_model(sd[0], device, eval_ritm, **kwargs),
+                [load_single_is_model(x, device, eval_ritm, **kwargs) for x in sd])
+    return load_single_is_model(sd, device, eval_ritm, **kwargs)

@@ -59,8 +59,11 @@ def get_class_from_str(path):
         raise
 
 
-def load_model(config, **overrides):
-    """Rebuild a model from a checkpoint's config (serialization.py:61-91)."""
+def load_model(config, eval_ritm=False, **overrides):
+    """Rebuild a model from a checkpoint's config (serialization.py:61-91; ``eval_ritm`` is the reference's second
+    positional parameter -- RITM-style evaluation is outside the probed path)."""
+    if eval_ritm:
+        raise NotImplementedError("eval_ritm=True (RITM-style evaluation) is outside the dense-feature path")
     cls = get_class_from_str(config["class"])
     defaults = _default_params(cls)
     kwargs = {}

@@ -4,6 +4,9 @@ Hydra config + a model script; this one keeps the same roles with plain argument
 
     python train.py --steps 20                                   # single GPU
     python -m torch.distributed.run --nproc-per-node 8 train.py  # data parallel, RCCL over xGMI
+    python train.py +exp.name=my_name +exp.model_path=models/sbd/dinov2/patch-embed_loftup.py dataloader.batch_size=8
+                                                                 # the reference's Hydra form (README.md:85-90), parsed
+                                                                 # without hydra (core/utils/overrides.py)
 
 `--model` names one of the reference's model scripts (models/sbd/<family>/<script>.py: backbone, click-injection
 mode, click encoder, upsampler and head exactly as configured there).  Each rank builds the same model (frozen
@@ -72,6 +75,10 @@ def model_configs(name, size, arch="dinov2_vits14", upsampler=None, injection=No
     return cfg
 
 
+def D_rank0():
+    return int(os.environ.get("RANK", "0")) == 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
@@ -85,7 +92,25 @@ def main():
     ap.add_argument("--injection", default=None, help="override feats_injection_mode (before_backbone | after_backbone)")
     ap.add_argument("--lr", type=float, default=5e-5)
     ap.add_argument("--save", default=None, help="directory for a reference-format last_checkpoint.pth (rank 0)")
-    args = ap.parse_args()
+    ap.add_argument("--eval-frozen-bn", action="store_true",
+                    help="keep the frozen upsampler's BatchNorm in eval mode (the reference's net.train() uses batch statistics)")
+    from isegprobe_amd.core.utils.overrides import TRAIN_DEFAULTS, apply_overrides, split_overrides
+    overrides, rest = split_overrides(sys.argv[1:])
+    args = ap.parse_args(rest)
+    if overrides:  # Hydra-style tokens over configs/train_cfg.yaml's keys
+        cfg = apply_overrides(TRAIN_DEFAULTS, overrides)
+        given = {k for k, _, _ in overrides}
+        if "exp.model_path" in given:
+            args.model = str(cfg["exp"]["model_path"])
+        if "dataloader.batch_size" in given:  # global batch, split over the GPUs (trainer.py:67-68)
+            args.batch = max(1, int(cfg["dataloader"]["batch_size"]) // int(os.environ.get("WORLD_SIZE", "1")))
+        if "training_params.crop_size" in given:
+            cs = cfg["training_params"]["crop_size"]
+            args.size = int(cs[0] if isinstance(cs, (list, tuple)) else cs)
+        if "training.local_rank" in given:  # the reference reads the rank's device from YAML only (train_cfg.yaml:36)
+            os.environ.setdefault("LOCAL_RANK", str(cfg["training"]["local_rank"]))
+        if D_rank0():
+            print(f"experiment '{cfg['exp']['name']}', model script {args.model}")
 
     from isegprobe_amd.core.model import iSegProbeModel
     from isegprobe_amd.core.training.trainer import DataParallelTrainer
@@ -96,7 +121,7 @@ def main():
     torch.manual_seed(0)  # identical initial weights on every rank
     model = iSegProbeModel(**model_configs(args.model, args.size, args.arch, args.upsampler, args.injection),
                            use_disks=True, norm_radius=5, with_prev_mask=True).cuda()
-    trainer = DataParallelTrainer(model, lr=args.lr)
+    trainer = DataParallelTrainer(model, lr=args.lr, frozen_bn_batch_stats=not args.eval_frozen_bn)
     rng = np.random.default_rng(100 + D.get_rank())
     if D.get_rank() == 0:
         print(f"model {args.model}  world {D.get_world_size()}  trainable bucket {trainer.bucket.nbytes() / 1e6:.1f} MB  "
