@@ -488,6 +488,8 @@ def test_cfg4_vitb14_loftup_forward_and_gradients_vs_oracle():
     assert err.max().item() <= 1.5e-2, err.max().item()  # absolute, centred logits; see test_s14_learned_upsamplers_vs_oracle
     assert _mask_agreement(y, ref) == 1.0
     model.train()
+    model.upsampler.eval()  # same BatchNorm mode as the oracle pass above (DataParallelTrainer(frozen_bn_batch_stats=False)); the
+    # batch-statistics mode of the reference's net.train() is pinned by test_train_step_vs_reference_fixture
     out = model(image.cuda(), points.cuda())["instances"]
     (out * coef.cuda()).sum().backward()
     named = dict(model.named_parameters())
