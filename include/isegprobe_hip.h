@@ -229,6 +229,17 @@ int isp_loftup_fourier_cn_f32(const float* image, const float* minmax_c2, const 
                               const float* bias_cos, const float* gamma, const float* beta, float* out_f32, int B, int H, int W,
                               int n_freqs, int ldo, float eps, void* stream);
 
+/* ---- fused ViT MLP branch, in place on the fp32 residual stream x [M][D]:
+ *   x += ls2 * (fc2(GELU(fc1(LayerNorm(x)))))      reference dinov2/layers/block.py:92-117 (second branch), mlp.py:34-40,
+ *   layer_scale.py:25-26, nn.LayerNorm(eps=1e-6) DINOv2.py:98.  Token-stationary: a workgroup owns 128 rows, their
+ *   normalised values stay in registers as MFMA operands, only weights stream through LDS, the [M][HID] hidden map never
+ *   exists.  w1 [HID][D] bf16 = fc1.weight * diag(norm2.weight), b1 [HID] f32 = fc1.bias + fc1.weight @ norm2.bias,
+ *   w2p [D][HID] bf16 = diag(ls2) * fc2.weight with the hidden axis permuted inside every group of 16 (physical 8g+e holds
+ *   logical 4g+e for e < 4, 8+4g+e-4 otherwise, g in {0,1}: the 32x32 accumulator layout of the first product), b2 [D] f32 = ls2 * fc2.bias.
+ *   (D, HID) = (384, 1536) (DINOv2-S/14). */
+int isp_vit_mlp_fused(float* x, const void* w1, const float* b1, const void* w2p, const float* b2, long M, int D, int HID,
+                      float eps, void* stream);
+
 /* ---- LiFT image pyramid (LiFT.py:70-91,106-112): 3x3 / stride 2 / pad 1 conv to 32 channels (input NCHW f32 with
  * 3 channels, or NHWC bf16 with 32), weights w [32][3][3][cin] f32; relu != 0: eval-BatchNorm folded into w/bias
  * by the caller + ReLU; relu == 0: the raw conv, ahead of isp_bn_train_*.  And F.adaptive_max_pool2d on NHWC bf16. */

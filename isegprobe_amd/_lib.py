@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "libisegprobe_hip.so")  # env override: kernel A/B experiments
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ISP_F32, ISP_BF16 = 0, 1
 EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16, EP_BIAS_QGELU_SAVE_BF16, EP_MUL_DQGELU_BF16 = range(14)
@@ -89,6 +89,7 @@ SIGNATURES = {
     "isp_loftup_fourier_cn": [_vp] * 8 + [_i, _i, _i, _i, _i, _f, _vp],
     "isp_loftup_fourier_cn_f32": [_vp] * 8 + [_i, _i, _i, _i, _i, _f, _vp],
     "isp_conv3x3_s2_c32": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "isp_vit_mlp_fused": [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _vp],
     "isp_bn_train_stats": [_vp, _vp, _l, _i, _vp],
     "isp_bn_train_apply": [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _f, _vp],
     "isp_bn_train_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp],

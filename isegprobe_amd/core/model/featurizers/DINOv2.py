@@ -70,6 +70,15 @@ class _Block(nn.Module):
         self.ls2 = _Gamma(dim, init_values) if init_values else nn.Identity()
 
 
+def _use_fused_mlp(rows):
+    """ISEGPROBE_FUSED_MLP=1 routes the MLP branch of every block through the token-stationary fused kernel
+    (csrc/vit_fused.hip).  Off by default: measured at 32 768 rows it takes 133-135 us against 142-150 us for
+    LayerNorm + fc1 + fc2, but one workgroup owns 128 rows and streams every weight byte itself, so the batch-32
+    headline shape (32 x 1025 = 256 x 128 + 32 rows) needs a second round of workgroups and loses (199-210 us).
+    DESIGN.md section 4 has the ablation of where its time goes."""
+    return os.environ.get("ISEGPROBE_FUSED_MLP", "0") == "1" and rows >= 128
+
+
 class _PatchProj(nn.Module):
     def __init__(self, patch, dim):
         super().__init__()
@@ -157,6 +166,11 @@ class DINOv2Featurizer(nn.Module):
                     fc1_w=b16(blk.mlp.fc1.weight), fc1_b=f32(blk.mlp.fc1.bias),
                     fc2_w=b16(blk.mlp.fc2.weight), fc2_b=f32(blk.mlp.fc2.bias),
                     ls2=f32(blk.ls2.gamma) if isinstance(blk.ls2, _Gamma) else None))
+                if ops.vit_mlp_fused_supported(m.embed_dim, blk.mlp.fc1.weight.shape[0]):
+                    blocks[-1]["mlp_fused"] = ops.vit_mlp_pack(blk.norm2.weight.detach(), blk.norm2.bias.detach(),
+                                                               blk.mlp.fc1.weight.detach(), blk.mlp.fc1.bias.detach(),
+                                                               blk.mlp.fc2.weight.detach(), blk.mlp.fc2.bias.detach(),
+                                                               blk.ls2.gamma.detach() if isinstance(blk.ls2, _Gamma) else None)
             self._pos_cache.clear()
             return dict(blocks=blocks, nw=f32(m.norm.weight), nb=f32(m.norm.bias),
                         patch_w=m.patch_embed.proj.weight.detach().flatten(1).float(),
@@ -210,6 +224,10 @@ class DINOv2Featurizer(nn.Module):
                 return qkv  # packed [B*L, 3, heads, 64]: the caller extracts K; the rest of the block is unused
             att = ops.attention_packed_qkv(qkv, B, L, heads, 64 ** -0.5)
             ops.linear_residual_(x, att, blk["proj_w"], blk["proj_b"], blk["ls1"])
+            if "mlp_fused" in blk and _use_fused_mlp(x.shape[0]):
+                # LayerNorm + fc1 + GELU + fc2 + LayerScale + residual in one token-stationary kernel (csrc/vit_fused.hip)
+                ops.vit_mlp_fused_(x, *blk["mlp_fused"], LN_EPS)
+                continue
             hbuf = ops.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS)
             hid = ops.linear(hbuf, blk["fc1_w"], blk["fc1_b"], "gelu")
             ops.linear_residual_(x, hid, blk["fc2_w"], blk["fc2_b"], blk["ls2"])

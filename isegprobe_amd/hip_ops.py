@@ -147,6 +147,35 @@ def linear_residual_(x, A, Wt, bias=None, gamma=None):
     return x
 
 
+def vit_mlp_pack(norm_w, norm_b, fc1_w, fc1_b, fc2_w, fc2_b, ls=None):
+    """Weights of isp_vit_mlp_fused from a block's fp32 parameters: LayerNorm affine folded into fc1, LayerScale into
+    fc2, fc2's hidden axis permuted inside every group of 16 to the 32x32 accumulator order of the first product
+    (physical 8g+e <- logical 4g+e for e < 4, 8+4g+(e-4) otherwise, g in {0,1})."""
+    w1 = fc1_w.float() * norm_w.float()[None, :]
+    b1 = fc1_b.float() + fc1_w.float() @ norm_b.float()
+    w2, b2 = fc2_w.float(), fc2_b.float()
+    if ls is not None:
+        w2, b2 = w2 * ls.float()[:, None], b2 * ls.float()
+    hid = w2.shape[1]
+    perm = torch.tensor([(4 * (p // 8) + p % 8) if p % 8 < 4 else (8 + 4 * (p // 8) + p % 8 - 4) for p in range(16)],
+                        device=w2.device)
+    idx = (torch.arange(0, hid, 16, device=w2.device)[:, None] + perm[None, :]).reshape(-1)
+    return (w1.to(BF16).contiguous(), b1.contiguous(), w2[:, idx].to(BF16).contiguous(), b2.contiguous())
+
+
+def vit_mlp_fused_(x, w1, b1, w2p, b2, eps):
+    """In place on the fp32 residual stream x [M, D]:  x += ls * fc2(GELU(fc1(LayerNorm(x))))  (weights from vit_mlp_pack)."""
+    _need(x, torch.float32, "x")
+    M, D = x.shape
+    check(_lib.lib().isp_vit_mlp_fused(_p(x), _p(w1), _p(b1), _p(w2p), _p(b2), M, D, w1.shape[0], float(eps), _stream()),
+          "isp_vit_mlp_fused")
+    return x
+
+
+def vit_mlp_fused_supported(D, hid):
+    return (D, hid) == (384, 1536)
+
+
 def conv3x3(x, Wt, bias=None, act="relu", out_dtype=BF16):
     """x [B,H,W,C] bf16 NHWC, Wt [N, 9*C] bf16 (ky,kx,c order) -> [B,H,W,N]."""
     _need(x, BF16, "x")

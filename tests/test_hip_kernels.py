@@ -277,3 +277,25 @@ def test_classifier_and_layout(ops):
     view = f.reshape(2, 3, 3, 384).permute(0, 3, 1, 2)
     back = ops.nchw_f32_to_nhwc_bf16(view)
     assert torch.equal(back, f.reshape(2, 3, 3, 384).to(BF))
+
+
+@pytest.mark.parametrize("M,D,HID", [(128, 384, 1536), (128 * 5 + 37, 384, 1536), (4100, 384, 1536), (128 * 300, 384, 1536)])
+def test_vit_mlp_fused(ops, M, D, HID):
+    """x += ls * fc2(GELU(fc1(LayerNorm(x)))) (dinov2/layers/block.py:92-117, mlp.py:34-40): the token-stationary fused
+    kernel against torch fp32 and against the three-kernel route it replaces; partial last tile, several tiles per
+    workgroup (M > 256 * 128), asymmetric weights (a permuted or transposed operand cannot cancel)."""
+    torch.manual_seed(M + D)
+    x = torch.randn(M, D, device="cuda") * 2 + 0.3
+    nw, nb = torch.randn(D, device="cuda") * 0.3 + 1, torch.randn(D, device="cuda") * 0.2
+    w1, b1 = torch.randn(HID, D, device="cuda") / math.sqrt(D), torch.randn(HID, device="cuda") * 0.3
+    w2, b2 = torch.randn(D, HID, device="cuda") / math.sqrt(HID), torch.randn(D, device="cuda") * 0.3
+    ls = torch.randn(D, device="cuda") * 0.5 + 1
+    ref = x + ls * (F.gelu(F.layer_norm(x, (D,), nw, nb, 1e-6) @ w1.t() + b1) @ w2.t() + b2)
+    y = ops.vit_mlp_fused_(x.clone(), *ops.vit_mlp_pack(nw, nb, w1, b1, w2, b2, ls), 1e-6)
+    h = ops.layernorm(x, nw, nb, 1e-6)
+    hid = ops.linear(h, bf(w1), b1, "gelu")
+    y3 = x.clone()
+    ops.linear_residual_(y3, hid, bf(w2), b2, ls)
+    e, e3 = (y - ref).abs().max().item(), (y3 - ref).abs().max().item()
+    print(f"fused MLP M={M} D={D}: max err {e:.3g} (three-kernel route {e3:.3g}), ref rms {ref.pow(2).mean().sqrt():.3f}")
+    assert e < 3e-2 and e < 2 * e3 + 1e-3
