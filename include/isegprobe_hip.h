@@ -196,7 +196,7 @@ int isp_jbu_range_proj(const float* guidance, float* proj, const float* w0, cons
 int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const void* fix0_w, const float* fix0_b,
                     const void* fix3_w, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
                     float sigma_spatial, int B, int GH, int GW, void* stream);
-int isp_jbu_apply(const void* src_nhwc_bf16, const void* kc_bf16, void* out_nhwc_bf16, int B, int h, int w, int C,
+int isp_jbu_apply(const void* src_nhwc_f16, const void* kc_f16, void* out_nhwc, int B, int h, int w, int C, int out_bf16,
                   void* stream);
 /* Last JBU stage fused with the model's bilinear (align_corners) resize to the image size
  * (core/model/iseg_probe_model.py:120-129; FeatUp's x16 map is 16/14 of the image): isp_jbu_blend turns the stage's
@@ -208,8 +208,12 @@ int isp_jbu_blend(const void* kc_bf16, void* kc9_bf16, int B, int GH, int GW, in
 int isp_jbu_kernels_resized(const float* proj, const float* guidance, void* kc9_bf16, const void* fix0_w, const float* fix0_b,
                             const void* fix3_w, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
                             float sigma_spatial, int B, int GH, int GW, int OH, int OW, void* stream);
-int isp_jbu_apply_resized(const void* src_nhwc_bf16, const void* kc9_bf16, void* out_nhwc_bf16, int B, int h, int w, int OH,
-                          int OW, int C, void* stream);
+int isp_jbu_apply_resized(const void* src_nhwc_f16, const void* kc9_f16, void* out_nhwc, int B, int h, int w, int OH, int OW,
+                          int C, int out_bf16, void* stream);
+/* Inside the stack everything is IEEE half: kernel records (kc, kc9), the fix-up MLP weights handed to isp_jbu_kernels*,
+ * and the feature maps between stages (src / out of isp_jbu_apply*); the stack's bf16 input is converted exactly by
+ * isp_bf16_to_f16 and the stage that feeds the seg head writes bf16 (out_bf16 != 0).  n % 8 == 0. */
+int isp_bf16_to_f16(const void* in_bf16, void* out_f16, long n, void* stream);
 
 /* Adjoint of isp_jbu_apply w.r.t. the source: gsrc [B,h,w,C] = A(kc)^T gout [B,2h,2w,C] (kc depends on the guidance only).
  * What autograd does for FeatUp's JBU stage when the probe trains through it (models/sbd/dinov2/patch-embed_jbu.py). */

@@ -41,12 +41,12 @@ class JBULearnedRange(nn.Module):
         def build():
             f = lambda t: t.detach().float().contiguous()
 
-            def pad64(w, b):  # fix-up MLP layer -> zero-padded [64,64] bf16 + [64] f32 (MFMA operands)
+            def pad64(w, b):  # fix-up MLP layer -> zero-padded [64,64] f16 + [64] f32 (MFMA operands)
                 wp = torch.zeros(64, 64, device=w.device)
                 wp[:w.shape[0], :w.shape[1]] = w.detach().float().flatten(1)
                 bp = torch.zeros(64, device=w.device)
                 bp[:b.shape[0]] = b.detach().float()
-                return wp.to(BF16).contiguous(), bp
+                return wp.to(ops.F16).contiguous(), bp
             f0w, f0b = pad64(self.fixup_proj[0].weight, self.fixup_proj[0].bias)
             f3w, f3b = pad64(self.fixup_proj[3].weight, self.fixup_proj[3].bias)
             return dict(w0=f(self.range_proj[0].weight.flatten(1)), b0=f(self.range_proj[0].bias),
@@ -67,11 +67,12 @@ class JBULearnedRange(nn.Module):
         proj = ops.jbu_range_proj(small, P["w0"], P["b0"], P["w3"], P["b3"])
         return ops.jbu_kernels(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"])
 
-    def run(self, source_nhwc, guidance, kc=None):
+    def run(self, source_nhwc, guidance, kc=None, out_dtype=None):
+        """One x2 stage.  Maps inside the stack are f16 (``out_dtype`` default); the stage that leaves it writes bf16."""
         # composite kernels on the low-res grid, applied by MFMA: no x2 map in HBM
         if kc is None:
             kc = self.kernels(guidance, source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2)
-        return ops.jbu_apply(source_nhwc, kc)
+        return ops.jbu_apply(source_nhwc, kc, out_dtype or ops.F16)
 
     @staticmethod
     def resize_fusable(GH, GW, OH, OW):
@@ -119,7 +120,7 @@ class JBUStack(nn.Module):
             x = up.run(x, None, kc)
         if records[3].shape[3] == 9:  # records of the resized grid
             return nchw_view(self.up4.run_resized(x, None, records[3].shape[1], records[3].shape[2], records[3]))
-        return nchw_view(self.up4.run(x, None, records[3]))
+        return nchw_view(self.up4.run(x, None, records[3], out_dtype=BF16))
 
     def stage_records(self, guidance, h, w, out_size=None):
         """The kernel records of the four stages for an h x w source: functions of the guidance only, so they can be
@@ -143,8 +144,9 @@ class JBUStack(nn.Module):
         # net.train() would switch them on, trainer.py:214 -- a stochastic quirk we do not mirror)
         x = to_nhwc_bf16(source)
         guidance = guidance.float().contiguous()
-        for up in (self.up1, self.up2, self.up3, self.up4):
+        for up in (self.up1, self.up2, self.up3):
             x = up.run(x, guidance)
+        x = self.up4.run(x, guidance, out_dtype=BF16)
         conv = self.fixup_proj[1]
         w, b = self._packed.get((conv.weight, conv.bias),
                                 lambda: (conv.weight.detach().flatten(1).to(BF16).contiguous(),
@@ -188,10 +190,10 @@ class _JBUFn(torch.autograd.Function):
         x = src.detach()
         g = guidance.detach().float().contiguous()
         kcs = []
-        for up in (stack.up1, stack.up2, stack.up3, stack.up4):
+        for i, up in enumerate((stack.up1, stack.up2, stack.up3, stack.up4)):
             kc = up.kernels(g, x.shape[1] * 2, x.shape[2] * 2)
             kcs.append(kc)
-            x = ops.jbu_apply(x, kc)
+            x = ops.jbu_apply(x, kc, BF16 if i == 3 else ops.F16)
         conv = stack.fixup_proj[1]
         w = conv.weight.detach().flatten(1).to(BF16).contiguous()
         B, H, W, C = x.shape

@@ -18,6 +18,28 @@
 #include "isp_common.h"
 
 namespace {
+// ---- fp16 inside the stack.  The composite-kernel records, the fix-up MLP operands and the feature maps between the
+// stages are IEEE half (11 significant bits) rather than bf16 (8): every stage re-rounds its input, its kernel weights and
+// its output, and with bf16 those roundings (1.3e-3 / 1.3e-3 / 1.7e-3 relative each, measured per stage by
+// tools/diag_jbu_precision.py) made the four stages the largest contributor to the bench workload's logit error.  All
+// values here are bounded -- kernel weights sum to 1 per pixel, features are convex-ish combinations of LayerNorm-ed
+// tokens -- so half's range is ample; the MFMA rate of the f16 forms is that of the bf16 ones.  The stack's input is
+// converted bf16 -> f16 (exact) and its last stage writes bf16 for the head's convolution.
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2h(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v_t{lo, hi}, f16x2_t));
+}
+__device__ __forceinline__ float h_lo(unsigned q) { return (float)__builtin_bit_cast(f16x2_t, q).x; }
+__device__ __forceinline__ float h_hi(unsigned q) { return (float)__builtin_bit_cast(f16x2_t, q).y; }
+template <bool OUT_BF16>
+__device__ __forceinline__ unsigned pack2o(float lo, float hi) {
+    if constexpr (OUT_BF16) return pack2bf(lo, hi);
+    else return pack2h(lo, hi);
+}
+
 
 constexpr int R = 3, DIA = 7, TAPS = 49, KEY = 32;
 
@@ -186,7 +208,7 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
                 e[q] = i < TAPS ? k[i < TAPS ? i : 0] : (i == TAPS ? g0 : (i == TAPS + 1 ? g1 : (i == TAPS + 2 ? g2 : 0.f)));
             }
             *reinterpret_cast<uint4*>(s_x + mlp_off(row, c)) =
-                make_uint4(pack2bf(e[0], e[1]), pack2bf(e[2], e[3]), pack2bf(e[4], e[5]), pack2bf(e[6], e[7]));
+                make_uint4(pack2h(e[0], e[1]), pack2h(e[2], e[3]), pack2h(e[4], e[5]), pack2h(e[6], e[7]));
         }
     }
     {
@@ -198,28 +220,28 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
             const float* bsrc = layer == 0 ? f0b : f3b;
             const char* src = layer == 0 ? s_x : s_h;
             char* dst = layer == 0 ? s_h : s_x;
-            bf16x8 wf[4][2];  // A operand: W[unit = 16*ot + fr][k = 32*ks + 8*fq + j]
+            f16x8_t wf[4][2];  // A operand: W[unit = 16*ot + fr][k = 32*ks + 8*fq + j]
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    wf[ot][ks] = *reinterpret_cast<const bf16x8*>(wsrc + (ot * 16 + fr) * 64 + ks * 32 + fq * 8);
+                    wf[ot][ks] = *reinterpret_cast<const f16x8_t*>(wsrc + (ot * 16 + fr) * 64 + ks * 32 + fq * 8);
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 const int row = wv * 64 + pt * 16 + fr;  // B operand: X[pixel = row][k..k+7]
-                const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(src + mlp_off(row, fq));
-                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(src + mlp_off(row, 4 + fq));
+                const f16x8_t x0 = *reinterpret_cast<const f16x8_t*>(src + mlp_off(row, fq));
+                const f16x8_t x1 = *reinterpret_cast<const f16x8_t*>(src + mlp_off(row, 4 + fq));
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ot][0], x0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ot][1], x1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ot][0], x0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ot][1], x1, acc, 0, 0, 0);
                     // D[unit = 16*ot + 4*fq + j][pixel = row]
                     const float4 bb = *reinterpret_cast<const float4*>(bsrc + ot * 16 + fq * 4);
                     float r0 = acc[0] + bb.x, r1 = acc[1] + bb.y, r2 = acc[2] + bb.z, r3 = acc[3] + bb.w;
                     if (layer == 0) r0 = gelu_erf(r0), r1 = gelu_erf(r1), r2 = gelu_erf(r2), r3 = gelu_erf(r3);
                     *reinterpret_cast<uint2*>(dst + mlp_off(row, ot * 2 + (fq >> 1)) + (fq & 1) * 8) =
-                        make_uint2(pack2bf(r0, r1), pack2bf(r2, r3));
+                        make_uint2(pack2h(r0, r1), pack2h(r2, r3));
                 }
             }
         }
@@ -233,8 +255,8 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = c * 8 + 2 * e;
-                if (i < TAPS) k[i] += 0.1f * __uint_as_float(q[e] << 16);
-                if (i + 1 < TAPS) k[i + 1] += 0.1f * __uint_as_float(q[e] & 0xffff0000u);
+                if (i < TAPS) k[i] += 0.1f * h_lo(q[e]);
+                if (i + 1 < TAPS) k[i + 1] += 0.1f * h_hi(q[e]);
             }
         }
     }
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
                 for (int s4 = 0; s4 < 4; ++s4) r[s4] = __builtin_elementwise_fma(f32x2{hv, hv}, bx[tx][s4], r[s4]);
             }
             *reinterpret_cast<uint4*>(stg + sl * 256 + (((ry * 2 + half) ^ (sl & 15)) << 4)) =
-                make_uint4(pack2bf(r[0].x, r[0].y), pack2bf(r[1].x, r[1].y), pack2bf(r[2].x, r[2].y), pack2bf(r[3].x, r[3].y));
+                make_uint4(pack2h(r[0].x, r[0].y), pack2h(r[1].x, r[1].y), pack2h(r[2].x, r[2].y), pack2h(r[3].x, r[3].y));
         }
     }
     if constexpr (!BLEND) {
@@ -335,13 +357,13 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
                     const unsigned* q = &v.x;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        acc[2 * e] = fmaf(wgt, __uint_as_float(q[e] << 16), acc[2 * e]);
-                        acc[2 * e + 1] = fmaf(wgt, __uint_as_float(q[e] & 0xffff0000u), acc[2 * e + 1]);
+                        acc[2 * e] = fmaf(wgt, h_lo(q[e]), acc[2 * e]);
+                        acc[2 * e + 1] = fmaf(wgt, h_hi(q[e]), acc[2 * e + 1]);
                     }
                 }
             }
             *reinterpret_cast<uint4*>(kout + (((size_t)b * OH + Y) * OW + X) * 144 + r * 16 + half * 8) =
-                make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+                make_uint4(pack2h(acc[0], acc[1]), pack2h(acc[2], acc[3]), pack2h(acc[4], acc[5]), pack2h(acc[6], acc[7]));
         }
     }
 }
@@ -376,6 +398,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ int src_swz(int col, int chunk) { return chunk ^ (((col >> 1) & 3) << 1); }
 constexpr int SROWB = 24 * 128;  // bytes per source-tile row
 
+template <bool OUT_BF16>
 __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ kc,
                                                            bf16_t* __restrict__ out, int h, int w, int C, int tiles_x,
                                                            int tiles_y, int nwg) {
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restr
     // ---- band fragments: lane (px = lane&15, g = lane>>4) holds, per (row si, strip cs, window row ry), the 4 slots
     // of src cols o'(cs) + 4g .. +3, i.e. the 8-byte chunk ((o' >> 2) + g) & 3 of the record's 32-byte row ry
     const int px = lane & 15, g = lane >> 4;
-    bf16x4 band[2][2][8];
+    f16x4_t band[2][2][8];
 #pragma unroll
     for (int si = 0; si < 2; ++si)
 #pragma unroll
@@ -404,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restr
             const int chunk = ((tile_x0 >> 2) + 2 * cs + g) & 3;
             const bf16_t* kp = kc + (((size_t)b * GH + gy) * GW + gx) * 128 + chunk * 4;
 #pragma unroll
-            for (int ry = 0; ry < 8; ++ry) band[si][cs][ry] = *reinterpret_cast<const bf16x4*>(kp + ry * 16);
+            for (int ry = 0; ry < 8; ++ry) band[si][cs][ry] = *reinterpret_cast<const f16x4_t*>(kp + ry * 16);
         }
     // ---- per-lane transposed-read geometry: a 16-lane group reads 4 src cols x 16 channels; fb = byte offset of the
     // lane's fragment piece inside a tile row, per (strip, 16-channel block)
@@ -449,8 +472,9 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restr
                 for (int cb = 0; cb < 4; ++cb) {
                     const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (ISP_LDS s16x4_t*)(rbase + fb[cs][cb] + ry * SROWB));
-                    acc[0][cs][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, band[0][cs][ry], acc[0][cs][cb], 0, 0, 0);
-                    acc[1][cs][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, band[1][cs][ry], acc[1][cs][cb], 0, 0, 0);
+                    const f16x4_t ah = __builtin_bit_cast(f16x4_t, a);
+                    acc[0][cs][cb] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, band[0][cs][ry], acc[0][cs][cb], 0, 0, 0);
+                    acc[1][cs][cb] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, band[1][cs][ry], acc[1][cs][cb], 0, 0, 0);
                 }
             }
         }
@@ -462,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
                     *reinterpret_cast<uint2*>(stg + ((si * 2 + cs) * 16 + px) * STG_PITCH + cb * 32 + g * 8) = make_uint2(
-                        pack2bf(acc[si][cs][cb][0], acc[si][cs][cb][1]), pack2bf(acc[si][cs][cb][2], acc[si][cs][cb][3]));
+                        pack2o<OUT_BF16>(acc[si][cs][cb][0], acc[si][cs][cb][1]), pack2o<OUT_BF16>(acc[si][cs][cb][2], acc[si][cs][cb][3]));
         // (written and read by the same wave: ordered by the compiler's lgkmcnt wait)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -515,13 +539,13 @@ __global__ __launch_bounds__(256) void jbu_blend_kernel(const bf16_t* __restrict
             const unsigned* q = &v.x;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[2 * e] = fmaf(wgt, __uint_as_float(q[e] << 16), acc[2 * e]);
-                acc[2 * e + 1] = fmaf(wgt, __uint_as_float(q[e] & 0xffff0000u), acc[2 * e + 1]);
+                acc[2 * e] = fmaf(wgt, h_lo(q[e]), acc[2 * e]);
+                acc[2 * e + 1] = fmaf(wgt, h_hi(q[e]), acc[2 * e + 1]);
             }
         }
     }
     *reinterpret_cast<uint4*>(kout + (((size_t)b * OH + Y) * OW + X) * 144 + r * 16 + half * 8) =
-        make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+        make_uint4(pack2h(acc[0], acc[1]), pack2h(acc[2], acc[3]), pack2h(acc[4], acc[5]), pack2h(acc[6], acc[7]));
 }
 
 // Block = 7 rows x 28 cols of OUTPUT pixels (the 8 x 32 stage tile of jbu_apply_kernel), 4 waves x 2 rows x 2 strips
@@ -532,6 +556,7 @@ constexpr int RTH = 7, RTW = 28, RSTRIP = 14;
 constexpr int RSROWS = 12, RSPIX = RSROWS * SCOLS, RSRC_BYTES = ((RSPIX + 7) / 8) * 8 * ACC * 2;
 constexpr int RAPPLY_LDS = RSRC_BYTES + 4 * 64 * STG_PITCH;
 
+template <bool OUT_BF16>
 __global__ __launch_bounds__(256, 2) void jbu_apply_resized_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ kc9,
                                                                    bf16_t* __restrict__ out, int h, int w, int OH, int OW,
                                                                    int C, float sy, int tiles_x, int tiles_y, int nwg) {
@@ -547,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_resized_kernel(const bf16_t*
     const int tile_x0 = tx * 16 - 4;              // o' of the first strip
 
     const int px = lane & 15, g = lane >> 4;
-    bf16x4 band[2][2][9];
+    f16x4_t band[2][2][9];
     int r0[2];
 #pragma unroll
     for (int si = 0; si < 2; ++si) {
@@ -562,8 +587,8 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_resized_kernel(const bf16_t*
             const bf16_t* kp = kc9 + (((size_t)b * OH + oy) * OW + ox) * 144 + chunk * 4;
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
-                bf16x4 v = *reinterpret_cast<const bf16x4*>(kp + r * 16);
-                if (!live) v = bf16x4{0, 0, 0, 0};
+                f16x4_t v = *reinterpret_cast<const f16x4_t*>(kp + r * 16);
+                if (!live) v = f16x4_t{0, 0, 0, 0};
                 band[si][cs][r] = v;
             }
         }
@@ -608,8 +633,8 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_resized_kernel(const bf16_t*
                     for (int cb = 0; cb < 4; ++cb) {
                         const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (ISP_LDS s16x4_t*)(rbase + fb[cs][cb] + r * SROWB));
-                        acc[si][cs][cb] =
-                            __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, band[si][cs][r], acc[si][cs][cb], 0, 0, 0);
+                        acc[si][cs][cb] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a), band[si][cs][r],
+                                                                                acc[si][cs][cb], 0, 0, 0);
                     }
                 }
             }
@@ -621,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_resized_kernel(const bf16_t*
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
                     *reinterpret_cast<uint2*>(stg + ((si * 2 + cs) * 16 + px) * STG_PITCH + cb * 32 + g * 8) = make_uint2(
-                        pack2bf(acc[si][cs][cb][0], acc[si][cs][cb][1]), pack2bf(acc[si][cs][cb][2], acc[si][cs][cb][3]));
+                        pack2o<OUT_BF16>(acc[si][cs][cb][0], acc[si][cs][cb][1]), pack2o<OUT_BF16>(acc[si][cs][cb][2], acc[si][cs][cb][3]));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int id = j * 64 + lane, sp = id >> 3, ck = id & 7;  // sp = (si*2 + cs)*16 + px
@@ -634,7 +659,26 @@ __global__ __launch_bounds__(256, 2) void jbu_apply_resized_kernel(const bf16_t*
     }
 }
 
+// bf16 -> f16 (exact for |v| in half's range; LayerNorm-ed ViT tokens are): the stack's input conversion
+__global__ __launch_bounds__(256) void bf16_to_f16_kernel(const bf16_t* __restrict__ in, unsigned short* __restrict__ out, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 u = reinterpret_cast<const uint4*>(in)[i];
+    const unsigned* q = &u.x;
+    unsigned o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2h(__uint_as_float(q[e] << 16), __uint_as_float(q[e] & 0xffff0000u));
+    reinterpret_cast<uint4*>(out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 }  // namespace
+
+extern "C" int isp_bf16_to_f16(const void* in_bf16, void* out_f16, long n, void* stream) {
+    ISP_CHECK_ARG(in_bf16 && out_f16 && n > 0 && n % 8 == 0);
+    bf16_to_f16_kernel<<<(unsigned)((n / 8 + 255) / 256), 256, 0, (hipStream_t)stream>>>((const bf16_t*)in_bf16,
+                                                                                       (unsigned short*)out_f16, n / 8);
+    return isp_launch_status();
+}
 
 extern "C" int isp_adaptive_avg_pool_nchw_f32(const float* in, float* out, long planes, int H, int W, int OH, int OW,
                                               void* stream) {
@@ -714,8 +758,10 @@ extern "C" int isp_jbu_blend(const void* kc_bf16, void* kc9_bf16, int B, int GH,
     return isp_launch_status();
 }
 
-extern "C" int isp_jbu_apply_resized(const void* src_nhwc_bf16, const void* kc9_bf16, void* out_nhwc_bf16, int B, int h, int w,
-                                     int OH, int OW, int C, void* stream) {
+extern "C" int isp_jbu_apply_resized(const void* src_nhwc_f16, const void* kc9_f16, void* out_nhwc, int B, int h, int w,
+                                     int OH, int OW, int C, int out_bf16, void* stream) {
+    const void *src_nhwc_bf16 = src_nhwc_f16, *kc9_bf16 = kc9_f16;
+    void* out_nhwc_bf16 = out_nhwc;
     ISP_CHECK_ARG(src_nhwc_bf16 && kc9_bf16 && out_nhwc_bf16 && B > 0 && h >= 4 && w >= 4 && C > 0 && C % ACC == 0);
     ISP_CHECK_ARG((2 * h) % 8 == 0 && (2 * w) % 8 == 0 && (long)OH * 8 == (long)(2 * h) * 7 && (long)OW * 8 == (long)(2 * w) * 7);
     const int tiles_x = (OW + RTW - 1) / RTW, tiles_y = (OH + RTH - 1) / RTH;
@@ -723,15 +769,22 @@ extern "C" int isp_jbu_apply_resized(const void* src_nhwc_bf16, const void* kc9_
     ISP_CHECK_ARG(nwg <= 0x7fffffffL);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)jbu_apply_resized_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RAPPLY_LDS) !=
-            hipSuccess)
+        if (hipFuncSetAttribute((const void*)jbu_apply_resized_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                RAPPLY_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)jbu_apply_resized_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                RAPPLY_LDS) != hipSuccess)
             return ISP_ERR_LAUNCH;
         attr_done = true;
     }
     const float sy = (float)(2 * h - 1) / (float)(OH - 1);
-    jbu_apply_resized_kernel<<<(unsigned)nwg, 256, RAPPLY_LDS, (hipStream_t)stream>>>(
-        (const bf16_t*)src_nhwc_bf16, (const bf16_t*)kc9_bf16, (bf16_t*)out_nhwc_bf16, h, w, OH, OW, C, sy, tiles_x, tiles_y,
-        (int)nwg);
+    if (out_bf16)
+        jbu_apply_resized_kernel<true><<<(unsigned)nwg, 256, RAPPLY_LDS, (hipStream_t)stream>>>(
+            (const bf16_t*)src_nhwc_bf16, (const bf16_t*)kc9_bf16, (bf16_t*)out_nhwc_bf16, h, w, OH, OW, C, sy, tiles_x, tiles_y,
+            (int)nwg);
+    else
+        jbu_apply_resized_kernel<false><<<(unsigned)nwg, 256, RAPPLY_LDS, (hipStream_t)stream>>>(
+            (const bf16_t*)src_nhwc_bf16, (const bf16_t*)kc9_bf16, (bf16_t*)out_nhwc_bf16, h, w, OH, OW, C, sy, tiles_x, tiles_y,
+            (int)nwg);
     return isp_launch_status();
 }
 
@@ -771,7 +824,7 @@ __global__ __launch_bounds__(256) void jbu_apply_bwd_kernel(const bf16_t* __rest
                 const bf16_t* kp = kc + (((size_t)b * GH + y) * GW + x) * 128;
                 float wgt = 0.f;
                 for (int ry = ry0; ry <= ry1; ++ry)
-                    for (int rx = rx0; rx <= rx1; ++rx) wgt += bf2f(kp[ry * 16 + ((bx + rx) & 15)]);
+                    for (int rx = rx0; rx <= rx1; ++rx) wgt += (float)reinterpret_cast<const _Float16*>(kp)[ry * 16 + ((bx + rx) & 15)];
                 const uint4 g = *reinterpret_cast<const uint4*>(gout + (((size_t)b * GH + y) * GW + x) * C + c0);
                 const unsigned* q = &g.x;
 #pragma unroll
@@ -796,20 +849,28 @@ extern "C" int isp_jbu_apply_bwd(const void* gout_nhwc_bf16, const void* kc_bf16
     return isp_launch_status();
 }
 
-extern "C" int isp_jbu_apply(const void* src_nhwc_bf16, const void* kc_bf16, void* out_nhwc_bf16, int B, int h, int w,
-                             int C, void* stream) {
+extern "C" int isp_jbu_apply(const void* src_nhwc_f16, const void* kc_f16, void* out_nhwc, int B, int h, int w, int C,
+                             int out_bf16, void* stream) {
+    const void *src_nhwc_bf16 = src_nhwc_f16, *kc_bf16 = kc_f16;
+    void* out_nhwc_bf16 = out_nhwc;
     ISP_CHECK_ARG(src_nhwc_bf16 && kc_bf16 && out_nhwc_bf16 && B > 0 && h >= 2 && w >= 2 && C > 0 && C % ACC == 0);
     const int tiles_x = (2 * w + ATW - 1) / ATW, tiles_y = (2 * h + ATH - 1) / ATH;
     const long nwg = (long)tiles_x * tiles_y * B;
     ISP_CHECK_ARG(nwg <= 0x7fffffffL);
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)jbu_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, APPLY_LDS) !=
-            hipSuccess)
+        if (hipFuncSetAttribute((const void*)jbu_apply_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, APPLY_LDS) !=
+                hipSuccess ||
+            hipFuncSetAttribute((const void*)jbu_apply_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, APPLY_LDS) !=
+                hipSuccess)
             return ISP_ERR_LAUNCH;
         attr_done = true;
     }
-    jbu_apply_kernel<<<(unsigned)nwg, 256, APPLY_LDS, (hipStream_t)stream>>>(
-        (const bf16_t*)src_nhwc_bf16, (const bf16_t*)kc_bf16, (bf16_t*)out_nhwc_bf16, h, w, C, tiles_x, tiles_y, (int)nwg);
+    if (out_bf16)
+        jbu_apply_kernel<true><<<(unsigned)nwg, 256, APPLY_LDS, (hipStream_t)stream>>>(
+            (const bf16_t*)src_nhwc_bf16, (const bf16_t*)kc_bf16, (bf16_t*)out_nhwc_bf16, h, w, C, tiles_x, tiles_y, (int)nwg);
+    else
+        jbu_apply_kernel<false><<<(unsigned)nwg, 256, APPLY_LDS, (hipStream_t)stream>>>(
+            (const bf16_t*)src_nhwc_bf16, (const bf16_t*)kc_bf16, (bf16_t*)out_nhwc_bf16, h, w, C, tiles_x, tiles_y, (int)nwg);
     return isp_launch_status();
 }

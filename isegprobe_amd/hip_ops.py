@@ -562,63 +562,83 @@ def jbu_tables(G, device):
     return _JBU_TABLES[key]
 
 
+F16 = torch.float16  # the dtype inside the FeatUp-JBU stack (records, fix-up MLP weights, maps between stages)
+
+
+def to_f16(x):
+    """bf16 -> f16 (exact within half's range): the stack's input conversion."""
+    if x.dtype == F16:
+        return x
+    _need(x, BF16, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=F16)
+    check(_lib.lib().isp_bf16_to_f16(_p(x), _p(out), x.numel(), _stream()), "isp_bf16_to_f16")
+    return out
+
+
 def jbu_kernels(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial):
-    """-> composite kernels kc [B,GH,GW,8,16] bf16 (see include/isegprobe_hip.h)."""
+    """-> composite kernels kc [B,GH,GW,8,16] f16 (see include/isegprobe_hip.h); f0w / f3w: f16 [64,64]."""
+    _need(f0w, F16, "f0w")
+    _need(f3w, F16, "f3w")
     B, GH, GW, _ = proj.shape
     bys = jbu_tables(GH, proj.device)[0]
     bxs = jbu_tables(GW, proj.device)[1]
-    kc = torch.empty(B, GH, GW, 8, 16, device=proj.device, dtype=BF16)
+    kc = torch.empty(B, GH, GW, 8, 16, device=proj.device, dtype=F16)
     check(_lib.lib().isp_jbu_kernels(_p(proj), _p(g), _p(kc), _p(f0w), _p(f0b), _p(f3w), _p(f3b), _p(bys), _p(bxs),
                                      float(range_temp), float(sigma_spatial), B, GH, GW, _stream()), "isp_jbu_kernels")
     return kc
 
 
 def jbu_kernels_resized(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial, OH, OW):
-    """jbu_blend(jbu_kernels(...), OH, OW) in one launch -> kc9 [B,OH,OW,9,16] bf16."""
+    """jbu_blend(jbu_kernels(...), OH, OW) in one launch -> kc9 [B,OH,OW,9,16] f16."""
+    _need(f0w, F16, "f0w")
+    _need(f3w, F16, "f3w")
     B, GH, GW, _ = proj.shape
     bys = jbu_tables(GH, proj.device)[0]
     bxs = jbu_tables(GW, proj.device)[1]
-    kc9 = torch.empty(B, OH, OW, 9, 16, device=proj.device, dtype=BF16)
+    kc9 = torch.empty(B, OH, OW, 9, 16, device=proj.device, dtype=F16)
     check(_lib.lib().isp_jbu_kernels_resized(_p(proj), _p(g), _p(kc9), _p(f0w), _p(f0b), _p(f3w), _p(f3b), _p(bys), _p(bxs),
                                              float(range_temp), float(sigma_spatial), B, GH, GW, OH, OW, _stream()),
           "isp_jbu_kernels_resized")
     return kc9
 
 
-def jbu_apply(src, kc):
-    """src [B,h,w,C] bf16 NHWC, kc [B,2h,2w,8,16] bf16 -> [B,2h,2w,C] bf16."""
-    _need(src, BF16, "src")
-    _need(kc, BF16, "kc")
+def jbu_apply(src, kc, out_dtype=F16):
+    """src [B,h,w,C] f16 NHWC (bf16 is converted, exactly), kc [B,2h,2w,8,16] f16 -> [B,2h,2w,C]; ``out_dtype``: f16 for a
+    map that feeds the next stage, bf16 for the one that leaves the stack."""
+    src = to_f16(src)
+    _need(kc, F16, "kc")
     B, h, w, C = src.shape
-    out = torch.empty(B, 2 * h, 2 * w, C, device=src.device, dtype=BF16)
-    check(_lib.lib().isp_jbu_apply(_p(src), _p(kc), _p(out), B, h, w, C, _stream()), "isp_jbu_apply")
+    out = torch.empty(B, 2 * h, 2 * w, C, device=src.device, dtype=out_dtype)
+    check(_lib.lib().isp_jbu_apply(_p(src), _p(kc), _p(out), B, h, w, C, int(out_dtype == BF16), _stream()), "isp_jbu_apply")
     return out
 
 
 def jbu_blend(kc, OH, OW):
     """Stage records [B,GH,GW,8,16] -> records of the bilinearly resized grid [B,OH,OW,9,16] (OH*8 == GH*7)."""
-    _need(kc, BF16, "kc")
+    _need(kc, F16, "kc")
     B, GH, GW = kc.shape[:3]
-    out = torch.empty(B, OH, OW, 9, 16, device=kc.device, dtype=BF16)
+    out = torch.empty(B, OH, OW, 9, 16, device=kc.device, dtype=F16)
     check(_lib.lib().isp_jbu_blend(_p(kc), _p(out), B, GH, GW, OH, OW, _stream()), "isp_jbu_blend")
     return out
 
 
-def jbu_apply_resized(src, kc9):
-    """src [B,h,w,C] bf16 NHWC, kc9 [B,OH,OW,9,16] bf16 (jbu_blend) -> [B,OH,OW,C] bf16 = resize(jbu_apply(src, kc))."""
-    _need(src, BF16, "src")
-    _need(kc9, BF16, "kc9")
+def jbu_apply_resized(src, kc9, out_dtype=BF16):
+    """src [B,h,w,C] f16 NHWC (bf16 is converted), kc9 [B,OH,OW,9,16] f16 (jbu_blend) -> [B,OH,OW,C] = resize(jbu_apply(src, kc));
+    this is the stage that leaves the stack, hence bf16 by default."""
+    src = to_f16(src)
+    _need(kc9, F16, "kc9")
     B, h, w, C = src.shape
     OH, OW = kc9.shape[1:3]
-    out = torch.empty(B, OH, OW, C, device=src.device, dtype=BF16)
-    check(_lib.lib().isp_jbu_apply_resized(_p(src), _p(kc9), _p(out), B, h, w, OH, OW, C, _stream()), "isp_jbu_apply_resized")
+    out = torch.empty(B, OH, OW, C, device=src.device, dtype=out_dtype)
+    check(_lib.lib().isp_jbu_apply_resized(_p(src), _p(kc9), _p(out), B, h, w, OH, OW, C, int(out_dtype == BF16), _stream()),
+          "isp_jbu_apply_resized")
     return out
 
 
 def jbu_apply_bwd(gout, kc):
-    """Adjoint of jbu_apply w.r.t. src: gout [B,2h,2w,C] bf16, kc [B,2h,2w,8,16] bf16 -> [B,h,w,C] bf16."""
+    """Adjoint of jbu_apply w.r.t. src: gout [B,2h,2w,C] bf16, kc [B,2h,2w,8,16] f16 -> [B,h,w,C] bf16."""
     _need(gout, BF16, "gout")
-    _need(kc, BF16, "kc")
+    _need(kc, F16, "kc")
     B, GH, GW, C = gout.shape
     if kc.shape != (B, GH, GW, 8, 16) or GH % 2 or GW % 2:
         raise IspError("jbu_apply_bwd: shape mismatch")

@@ -286,7 +286,7 @@ def test_jbu_apply_adjoint(ops, B, h, w, C):
     live = torch.zeros(2 * w, 16, device="cuda")
     for rx in range(8):
         live[xs, (bx + rx) & 15] = 1
-    kc = (kc * live[None, None, :, None, :]).to(BF)
+    kc = (kc * live[None, None, :, None, :]).to(torch.float16)  # records are IEEE half inside the JBU stack
     x = torch.randn(B, h, w, C, device="cuda").to(BF)
     g = torch.randn(B, 2 * h, 2 * w, C, device="cuda").to(BF)
     Ax = ops.jbu_apply(x, kc).float()

@@ -15,7 +15,7 @@ for (B, h, C) in ((2, 37, 192), (32, 256, 384), (32, 128, 384)):
     bx = ((xs - 4) >> 1) - 1
     slot = torch.arange(16, device="cuda")
     inwin = ((slot[None, :] - bx[:, None]) & 15) < 8          # the format's precondition: zero outside the window slots
-    kc = (kc * inwin[None, None, :, None, :]).to(torch.bfloat16)
+    kc = (kc * inwin[None, None, :, None, :]).to(torch.float16)
     y = ops.jbu_apply(x, kc); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()

@@ -25,7 +25,7 @@ def rel(a, b):
 
 
 xe = x.clone()            # exact chain (fp32)
-xb = x.to(torch.bfloat16)  # product chain
+xb = x.to(torch.bfloat16)  # product chain (bf16 in, converted exactly to f16 by the first stage)
 for i, st in enumerate((stack.up1, stack.up2, stack.up3, stack.up4)):
     Bn, hh, ww, _ = xe.shape
     small = ops.adaptive_avg_pool(g, 2 * hh, 2 * ww)
@@ -34,9 +34,9 @@ for i, st in enumerate((stack.up1, stack.up2, stack.up3, stack.up4)):
     args = (f32(st.fixup_proj[0].weight.flatten(1)), f32(st.fixup_proj[0].bias), f32(st.fixup_proj[3].weight.flatten(1)),
             f32(st.fixup_proj[3].bias), float(st.range_temp.item()), float(st.sigma_spatial.item()))
     ye = ops.jbu_stage_f32(xe, proj, small, *args)
-    y_in = ops.jbu_stage_f32(xe.to(torch.bfloat16).float(), proj, small, *args)   # input rounding only
-    y1 = st.run(xe.to(torch.bfloat16), g)                                           # product stage on the exact input
+    y_in = ops.jbu_stage_f32(xe.to(torch.float16).float(), proj, small, *args)    # input rounding only
+    y1 = st.run(xe.to(torch.float16), g)                                            # product stage on the exact input (f16 inside the stack)
     yb = st.run(xb, g)                                                              # product chain
     print(f"stage {i + 1} ({2 * hh}x{2 * ww}): input-rounding only {rel(y_in, ye)} | product stage on exact input {rel(y1, ye)}"
-          f" | floor bf16(out) {rel(ye.to(torch.bfloat16), ye)} | chain {rel(yb, ye)}", flush=True)
+          f" | floor f16(out) {rel(ye.to(torch.float16), ye)} | chain {rel(yb, ye)}", flush=True)
     xe, xb = ye, yb

@@ -11,7 +11,7 @@ for (B, h, C) in ((2, 32, 128), (2, 16, 64), (32, 256, 384)):
     xs = torch.arange(GH, device="cuda")
     bx = ((xs - 4) >> 1) - 1
     inwin = ((torch.arange(16, device="cuda")[None, :] - bx[:, None]) & 15) < 8
-    kc = (kc * inwin[None, None, :, None, :]).to(torch.bfloat16)
+    kc = (kc * inwin[None, None, :, None, :]).to(torch.float16)
     def ref():
         return ops.resize_nhwc(ops.jbu_apply(x, kc), OH, OH, "bilinear")
     kc9 = ops.jbu_blend(kc, OH, OH)
