@@ -2,7 +2,8 @@
 sbd,pascalvoc}.py, core/data/data_sample.py, core/inference/utils.py:86-104).  Host-side I/O around the
 per-click path: what `evaluate.py` iterates over.
 
-* GrabCut / Berkeley: ``data_GT/<name>.*`` images, ``boundary_GT/<name>.*`` masks with {0, 128 = ignore, 255 = object}.
+* GrabCut:            ``data_GT/<name>.*`` images, ``boundary_GT/<name>.*`` masks with {0, 128 = ignore, > 128 = object};
+                      Berkeley: the same reader on ``images/`` + ``masks/``.
 * DAVIS / COCO_MVal:  ``img/<name>.*``, ``gt/<name>.*`` (any non-zero channel = object).
 * SBD:                ``img/<name>.jpg``, ``inst/<name>.mat`` (MATLAB struct ``GTinst.Segmentation``), ``{split}.txt``;
                       the evaluation variant enumerates (image, instance id) pairs and caches the list in
@@ -103,7 +104,14 @@ class GrabCutLayoutDataset(_Base):
         return DSample(image, m, objects_ids=[1], ignore_ids=[-1], sample_id=index)
 
 
-GrabCutDataset = BerkeleyDataset = GrabCutLayoutDataset
+GrabCutDataset = GrabCutLayoutDataset
+
+
+class BerkeleyDataset(GrabCutLayoutDataset):
+    """berkeley.py:6-10: the GrabCut reader on ``images/`` + ``masks/`` directories."""
+
+    def __init__(self, dataset_path, **kwargs):
+        super().__init__(dataset_path, images_dir_name="images", masks_dir_name="masks", **kwargs)
 
 
 class DavisDataset(_Base):

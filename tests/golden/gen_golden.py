@@ -686,12 +686,122 @@ def gen_train_step():
     save("train_step", **out)
 
 
+def _write_dataset_tree(root):
+    """A tiny tree in every on-disk layout the reference's evaluation readers understand (lossless image files + SBD's
+    .mat + PascalVOC's test pickle).  Committed under tests/golden/datasets/ as data; the arrays the reference's readers
+    return for it are the fixture proper."""
+    import pickle
+    import shutil
+    from PIL import Image
+    from scipy.io import savemat
+    rng = np.random.default_rng(8)
+    shutil.rmtree(root, ignore_errors=True)
+    img = lambda h, w: rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    # GrabCut / Berkeley layout (grabcut.py:25-38): boundary 0 / 128 (ignore) / 255 (object); mask file of another type
+    g = os.path.join(root, "grabcut")
+    os.makedirs(os.path.join(g, "data_GT")), os.makedirs(os.path.join(g, "boundary_GT"))
+    for k, (h, w, ext_i, ext_m) in enumerate(((18, 24, "png", "bmp"), (20, 16, "bmp", "png"))):
+        Image.fromarray(img(h, w)).save(os.path.join(g, "data_GT", f"s{k}.{ext_i}"))
+        m = np.zeros((h, w), np.uint8)
+        m[3:h - 4, 4:w - 5] = 255
+        m[2, 4:w - 5] = m[h - 4, 4:w - 5] = 128
+        m[5, 6] = 129 if k else 200  # any value > 128 is object (grabcut.py:38)
+        Image.fromarray(np.stack([m, m, m], -1) if k else m).save(os.path.join(g, "boundary_GT", f"s{k}.{ext_m}"))
+    # Berkeley (berkeley.py:6-10): the same reader on images/ + masks/
+    bk = os.path.join(root, "berkeley")
+    shutil.copytree(os.path.join(g, "data_GT"), os.path.join(bk, "images"))
+    shutil.copytree(os.path.join(g, "boundary_GT"), os.path.join(bk, "masks"))
+    # DAVIS / COCO_MVal layout (davis.py:25-38): any non-zero channel is the object
+    d = os.path.join(root, "davis")
+    os.makedirs(os.path.join(d, "img")), os.makedirs(os.path.join(d, "gt"))
+    Image.fromarray(img(15, 21)).save(os.path.join(d, "img", "f0.png"))
+    gm = np.zeros((15, 21, 3), np.uint8)
+    gm[2:9, 3:12, 1], gm[10:13, 14:20, 2], gm[0, 0, 0] = 7, 200, 1
+    Image.fromarray(gm).save(os.path.join(d, "gt", "f0.png"))
+    # SBD (sbd.py:15-131): img/<name>.jpg, inst/<name>.mat with GTinst.Segmentation, <split>.txt
+    sbd = os.path.join(root, "sbd")
+    os.makedirs(os.path.join(sbd, "img")), os.makedirs(os.path.join(sbd, "inst"))
+    names = ["2008_000001", "2008_000002"]
+    for k, name in enumerate(names):
+        flat = np.full((16, 18, 3), 30 + 60 * k, np.uint8)  # constant colour: every JPEG decoder returns the same pixels
+        Image.fromarray(flat).save(os.path.join(sbd, "img", name + ".jpg"), quality=95)
+        seg = np.zeros((16, 18), np.uint8)
+        seg[1:6, 1:7] = 1
+        seg[8:15, 4:17] = 3 + k
+        if k == 0:  # a thin L-shaped "buggy" instance: area / bbox area < 0.08 (sbd.py:58-75)
+            seg[7, :] = 9
+            seg[15, 0] = 9
+        savemat(os.path.join(sbd, "inst", name + ".mat"), {"GTinst": {"Segmentation": seg, "Categories": np.array([[1]])}})
+    open(os.path.join(sbd, "val.txt"), "w").write("\n".join(names) + "\n")
+    open(os.path.join(sbd, "train.txt"), "w").write(names[0] + "\n")
+    # PascalVOC test split (pascalvoc.py:22-60): ImageSets/Segmentation/test.pickle = (names, instance ids)
+    voc = os.path.join(root, "voc")
+    os.makedirs(os.path.join(voc, "JPEGImages")), os.makedirs(os.path.join(voc, "SegmentationObject"))
+    os.makedirs(os.path.join(voc, "ImageSets", "Segmentation"))
+    Image.fromarray(np.full((12, 14, 3), 120, np.uint8)).save(os.path.join(voc, "JPEGImages", "a.jpg"), quality=95)
+    so = np.zeros((12, 14, 3), np.uint8)
+    so[1:5, 1:6] = 38       # grey 38 and 75 as instance ids, 220 the void border
+    so[6:11, 5:13] = 75
+    so[5, 1:6] = 220
+    Image.fromarray(so).save(os.path.join(voc, "SegmentationObject", "a.png"))
+    with open(os.path.join(voc, "ImageSets", "Segmentation", "test.pickle"), "wb") as f:
+        pickle.dump((["a", "a"], [38, 75]), f)
+
+
+def gen_datasets():
+    """The reference's OWN evaluation readers (core/data/datasets/{grabcut,berkeley,davis,sbd,pascalvoc}.py + DSample) on a
+    tiny tree written in their on-disk formats.  cv2 is absent: imread / cvtColor are stood in with PIL (same decoders the
+    product uses; BGR2GRAY = OpenCV's documented 8-bit fixed-point weights) -- the readers' logic (ignore labels, channel
+    max, GTinst indexing, instance enumeration, buggy-mask filter, pickle cache, DSample.gt_mask) is the reference's."""
+    import cv2  # noqa: stub
+    from PIL import Image
+
+    def imread(path, flags=None):
+        return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+
+    cv2.COLOR_BGR2RGB, cv2.COLOR_BGR2GRAY = 4, 6
+
+    def cvtColor(a, code):
+        if code == 4:
+            return np.ascontiguousarray(a[:, :, ::-1])
+        b, g, r = (a[..., i].astype(np.int32) for i in range(3))
+        return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+
+    cv2.imread, cv2.cvtColor = imread, cvtColor
+    from core.data.datasets.berkeley import BerkeleyDataset
+    from core.data.datasets.davis import DavisDataset
+    from core.data.datasets.grabcut import GrabCutDataset
+    from core.data.datasets.pascalvoc import PascalVocDataset
+    from core.data.datasets.sbd import SBDDataset, SBDEvaluationDataset
+    root = os.path.join(OUT, "datasets")
+    _write_dataset_tree(root)
+    out = {}
+    # keys = the names core/inference/utils.py:86-104 (get_dataset) accepts, built as it builds them; plus the training reader
+    readers = {"GrabCut": GrabCutDataset(os.path.join(root, "grabcut")), "Berkeley": BerkeleyDataset(os.path.join(root, "berkeley")),
+               "DAVIS": DavisDataset(os.path.join(root, "davis")), "COCO_MVal": DavisDataset(os.path.join(root, "davis")),
+               "SBD": SBDEvaluationDataset(os.path.join(root, "sbd")),
+               "SBD_Train": SBDEvaluationDataset(os.path.join(root, "sbd"), split="train"),
+               "PascalVOC": PascalVocDataset(os.path.join(root, "voc"), split="test"),
+               "SBDDataset_train": SBDDataset(os.path.join(root, "sbd"), split="train")}
+    for name, ds in readers.items():
+        out[name + "_len"] = np.array(len(ds.dataset_samples))
+        for i in range(len(ds.dataset_samples)):
+            smp = ds.get_sample(i)
+            out[f"{name}_{i}_image"] = smp.image
+            out[f"{name}_{i}_objects"] = np.array(smp.objects_ids, dtype=np.int64)
+            for j in range(len(smp.objects_ids)):
+                out[f"{name}_{i}_gt{j}"] = smp.gt_mask(j).astype(np.int32)
+    for split in ("val", "train"):  # the caches the reader wrote: tests exercise both paths
+        os.remove(os.path.join(root, "sbd", f"{split}_images_and_ids_list.pkl"))
+    save("datasets", **out)
+
+
 def main():
     torch.set_num_threads(4)
     install_standins()
-    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "train_step"]
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "train_step", "datasets"]
     fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino, "simple_vit": gen_simple_vit, "maskclip": gen_maskclip,
-           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "train_step": gen_train_step}
+           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "train_step": gen_train_step, "datasets": gen_datasets}
     for w in which:
         fns[w]()
 

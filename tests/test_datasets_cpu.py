@@ -130,3 +130,31 @@ def test_results_table_and_log_files(tmp_path, capsys):
     d = pickle.load(open(p, "rb"))
     assert p.name == "GrabCut_fixed224_NoBRS_4.pickle" and set(d) == {"dataset_name", "model_name", "all_ious"}
     assert d["model_name"].endswith("_NoBRS")
+
+
+# ------------------------------------------------------------------ against the REFERENCE's own readers
+@pytest.mark.parametrize("name,sub", [("GrabCut", "grabcut"), ("Berkeley", "berkeley"), ("DAVIS", "davis"), ("COCO_MVal", "davis"),
+                                      ("SBD", "sbd"), ("SBD_Train", "sbd"), ("PascalVOC", "voc"), ("SBDDataset_train", "sbd")])
+def test_readers_vs_reference_readers(golden, tmp_path, name, sub):
+    """tests/golden/datasets/ holds a tiny tree in each on-disk layout; tests/golden/datasets.npz holds what the REFERENCE's
+    readers (core/data/datasets/*.py + DSample, run by gen_golden.py::gen_datasets) returned for it: sample count, images,
+    object ids and every gt_mask -- ours must return the same, first without and (SBD) then with the pickle cache."""
+    import os
+    import shutil
+    g = golden("datasets")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "datasets", sub)
+    root = tmp_path / sub
+    shutil.copytree(src, root)  # SBD's reader writes its cache next to the data
+    for attempt in range(2 if name == "SBD" else 1):
+        ds = D.SBDDataset(root, split="train") if name == "SBDDataset_train" else D.get_dataset(name, root)
+        assert len(ds) == int(g[name + "_len"])
+        for i in range(len(ds)):
+            s = ds.get_sample(i)
+            assert np.array_equal(s.image, g[f"{name}_{i}_image"]), (name, i)
+            assert [int(v) for v in s.objects_ids] == g[f"{name}_{i}_objects"].tolist()
+            for j in range(len(s.objects_ids)):
+                ref = g[f"{name}_{i}_gt{j}"]
+                got = s.gt_mask(j)
+                assert got.shape == ref.shape and np.array_equal(got.astype(np.int32), ref), (name, i, j)
+    if name == "SBD":
+        assert (root / "val_images_and_ids_list.pkl").exists()
