@@ -421,11 +421,20 @@ def run_forward(args):
         if by is not None and (up_ms_seq or up_ms_in):
             ms = up_ms_seq or up_ms_in
             gbs = B * by / (ms * 1e-3) / 1e9
+            up_traffic = None
+            allpmc = _pmc_traffic("r02_bench_pmc.json")
+            if allpmc is not None and args.upsampler == "jbu_featup" and B == 32 and S == 448 and args.arch == "dinov2_vits14":
+                # fabric bytes per step of the stage's kernels (4 profiled forwards: 1 warm-up + 3 steps)
+                up_traffic = sum(v["traffic_bytes_per_launch"] * v["FETCH_SIZE"]["launches"] / 4.0
+                                 for k, v in allpmc["kernels"].items()
+                                 if k.startswith(("jbu_", "adaptive_avg_pool", "bf16_to_f16")) and "traffic_bytes_per_launch" in v)
             line["roofline_upsampler"] = {"kernel": f"{args.upsampler} stage incl. the resize to the image size "
                                                     "(jbu_kernels / jbu_apply / jbu_apply_resized, range proj, pooling)",
                                           "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": gbs / HBM_PEAK_GBS, "ms_per_step": ms, "bytes_per_step": B * by,
-                                          "traffic": None,
+                                          "traffic": up_traffic,
+                                          "traffic_note": "fabric bytes per step summed over the stage's kernels, rocprofv3 --pmc "
+                                                          "passes of this program (profiles/r02_bench_pmc.json)",
                                           "note": "time = the stage run on its own (stages.*): inside the step its guidance-only half "
                                                   f"overlaps the ViT on a second stream (main-stream share {up_ms_in:.2f} ms)"
                                           if up_ms_seq and up_ms_in else "HIP events inside the timed steps"}
