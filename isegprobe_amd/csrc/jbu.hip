@@ -105,7 +105,17 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
 // 32 wide so that each 16-lane group of a ds_read_b128 stays inside one tile row -- a 16x16 block mixed two rows per
 // group and 47 % of its LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-constexpr int TSX = 32, TSY = 8, HALOX = TSX + 2 * R, HALOY = TSY + 2 * R, PSTRIDE = 36;
+constexpr int TSX = 32, TSY = 8, HALOX = TSX + 2 * R, HALOY = TSY + 2 * R;
+constexpr int PLANE = ((HALOY * HALOX * 16 + 255) / 256) * 256;  // one k-chunk plane of the half proj tile, 256-B multiple
+constexpr int LOG_PITCH = 53;  // floats per pixel of the logit staging: odd (column reads by pixel are conflict-free) and
+                              // 4 * (pitch - 1) = 16 mod 32, so the four centre groups of a band store hit every bank twice
+constexpr int LOG_STAGE = 32 * LOG_PITCH * 4 + 128;             // per-wave logit staging [32 px][53] f32 + dump slots
+constexpr int KERNELS_LDS_MAIN = 65536;                         // the later phases reuse the first 64 KiB (MLP / record staging)
+// behind it: the spatial Gaussian (49 f32) and the block's slice of the composite-kernel tables -- bys rows of its 8 pixel
+// rows, bxs rows of its 32 columns -- staged once (the per-pixel float4 table loads from L2, ~70 per pixel at 2 waves per
+// SIMD, were half of the kernel's s_waitcnt time)
+constexpr int TAB_GAUSS = 0, TAB_BY = 256, TAB_BX = TAB_BY + TSY * DIA * 8 * 4, KERNELS_LDS_TABLES = TAB_BX + TSX * DIA * 16 * 4;
+static_assert(4 * PLANE + 4 * LOG_STAGE <= KERNELS_LDS_MAIN, "logit phase fits the later phases' LDS");
 
 // Composite-kernel tables (host-built, depend only on the output size):
 //   bys[y][ty][ry]  : weight of window row ry (src row base_y(y)+ry) in hr row reflect(y+ty-3)
@@ -122,26 +132,48 @@ __device__ __forceinline__ int mlp_off(int row, int chunk) { return row * 128 + 
 // them (and on them only, see jbu_blend_kernel below) are blended from the staged records and stored instead
 // ([B, OH, OW, 9, 16]): the stage's own 256-byte records (2.1 GB at 512^2 x 32) never reach HBM.
 template <bool BLEND>
-__global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restrict__ proj, const float* __restrict__ G,
+__global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const float* __restrict__ proj, const float* __restrict__ G,
                                                            bf16_t* __restrict__ kout, const bf16_t* __restrict__ f0w,
                                                            const float* __restrict__ f0b, const bf16_t* __restrict__ f3w,
                                                            const float* __restrict__ f3b, const float* __restrict__ bys,
                                                            const float* __restrict__ bxs, float temp, float inv2s2,
                                                            int GH, int GW, int OH, int OW, float rsy, float rsx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* tile = reinterpret_cast<float*>(smem);
     const int b = blockIdx.z, ty0 = blockIdx.y * TSY, tx0 = blockIdx.x * TSX;
     const long HW = (long)GH * GW;
-    // stage proj tile (+halo, reflect) : HALOY*HALOX pixels x 8 float4
-    for (int i = threadIdx.x; i < HALOY * HALOX * (KEY / 4); i += 256) {
-        const int c4 = i % (KEY / 4), pix = i / (KEY / 4);
+    // ---- range logits <proj(p), proj(p + t)> for the 49 taps, on MFMA.  (The first version formed them on the VALU: 784
+    // packed FMAs and 392 ds_read_b128 per pixel -- every pixel re-read its 48 neighbours' 128-byte vectors -- which made
+    // the kernel LDS- and VALU-bound.)  The 38 x 14 reflect-padded proj tile is staged as IEEE half in four chunk planes
+    // [k/8][pixel][8 halfs]: 16 consecutive pixels of a tile row x one k-chunk are 256 contiguous bytes, so both MFMA
+    // operands (16 centres, 16 neighbours; lane = (pixel, k-chunk)) are conflict-free ds_read_b128.  Per pixel row and
+    // 16-pixel strip, D[centre c][neighbour n] = one v_mfma_f32_16x16x32_f16 per (dy, neighbour group): 14 MFMAs cover the
+    // 16 x 49 logits (the band n - c in [0, 6] of two 16 x 16 tiles); the band entries go through a wave-private LDS
+    // staging [32 px][49] (odd pitch: conflict-free column reads) to the thread that owns the pixel.
+    char* const planes = smem;                              // 4 x PLANE bytes
+    char* const s_log = smem + 4 * PLANE;                   // 4 waves x [32][49] f32
+    for (int i = threadIdx.x; i < HALOY * HALOX * (KEY / 8); i += 256) {
+        const int c8 = i % (KEY / 8), pix = i / (KEY / 8);
         const int py = pix / HALOX, px = pix % HALOX;
         const int gy = reflect(min(ty0 + py - R, GH - 1 + R), GH), gx = reflect(min(tx0 + px - R, GW - 1 + R), GW);
-        *reinterpret_cast<float4*>(tile + pix * PSTRIDE + c4 * 4) =
-            *reinterpret_cast<const float4*>(proj + ((size_t)b * HW + (size_t)gy * GW + gx) * KEY + c4 * 4);
+        const float* src = proj + ((size_t)b * HW + (size_t)gy * GW + gx) * KEY + c8 * 8;
+        const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+        *reinterpret_cast<uint4*>(planes + c8 * PLANE + pix * 16) =
+            make_uint4(pack2h(v0.x, v0.y), pack2h(v0.z, v0.w), pack2h(v1.x, v1.y), pack2h(v1.z, v1.w));
     }
     // spatial Gaussian of the 49 taps (pixel-independent): computed once per block, read back as LDS broadcasts
-    float* const s_gauss = reinterpret_cast<float*>(smem + HALOY * HALOX * PSTRIDE * 4);
+    float* const s_gauss = reinterpret_cast<float*>(smem + KERNELS_LDS_MAIN + TAB_GAUSS);
+    float* const s_by = reinterpret_cast<float*>(smem + KERNELS_LDS_MAIN + TAB_BY);  // [8 rows][7][8]
+    float* const s_bx = reinterpret_cast<float*>(smem + KERNELS_LDS_MAIN + TAB_BX);  // [32 cols][7][16]
+    for (int i = threadIdx.x; i < TSY * DIA * 8 / 4; i += 256) {
+        const int r = i / (DIA * 8 / 4);
+        reinterpret_cast<float4*>(s_by)[i] =
+            reinterpret_cast<const float4*>(bys + (size_t)min(ty0 + r, GH - 1) * (DIA * 8))[i - r * (DIA * 8 / 4)];
+    }
+    for (int i = threadIdx.x; i < TSX * DIA * 16 / 4; i += 256) {
+        const int c = i / (DIA * 16 / 4);
+        reinterpret_cast<float4*>(s_bx)[i] =
+            reinterpret_cast<const float4*>(bxs + (size_t)min(tx0 + c, GW - 1) * (DIA * 16))[i - c * (DIA * 16 / 4)];
+    }
     if (threadIdx.x < TAPS) {
         const int t = threadIdx.x;
         const float dy = -1.f + (float)(t / DIA) * (2.f / (DIA - 1)), dx = -1.f + (float)(t % DIA) * (2.f / (DIA - 1));
@@ -151,27 +183,60 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
     const int lx = threadIdx.x & (TSX - 1), ly = threadIdx.x / TSX;
     const int y = min(ty0 + ly, GH - 1), x = min(tx0 + lx, GW - 1);  // out-of-image lanes compute a clamped pixel
 
-    float4 ctr[KEY / 4];
-    const float* cp = tile + ((ly + R) * HALOX + lx + R) * PSTRIDE;
-#pragma unroll
-    for (int c = 0; c < KEY / 4; ++c) ctr[c] = *reinterpret_cast<const float4*>(cp + c * 4);
-
     float k[TAPS];
     float mx = -INFINITY;
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int li = lane & 15, lq = lane >> 4;
+        float* const stg = reinterpret_cast<float*>(s_log + wv * LOG_STAGE);
+        const char* const pl = planes + lq * PLANE;  // the lane's k-chunk plane
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {  // the wave's two pixel rows
+            const int row = 2 * wv + rr;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-        const int i = t / DIA, j = t % DIA;
-        const float* np = tile + ((ly + i) * HALOX + lx + j) * PSTRIDE;
-        f32x2 s2 = {0.f, 0.f};  // two running sums -> v_pk_fma_f32 (2 FMAs per instruction)
+            for (int st = 0; st < 2; ++st) {  // two 16-pixel strips
+                const f16x8_t ctr = *reinterpret_cast<const f16x8_t*>(pl + ((row + R) * HALOX + 16 * st + R + li) * 16);
+                // all 14 products of the strip first (independent: no MFMA waits on another), then the band entries.  The
+                // stores are unconditional -- entries outside the band go to a dump slot -- because 56 predicated stores per
+                // strip became 56 exec-mask branches.
 #pragma unroll
-        for (int c = 0; c < KEY / 4; ++c) {
-            const float4 v = *reinterpret_cast<const float4*>(np + c * 4);
-            s2 = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{ctr[c].x, ctr[c].y}, s2);
-            s2 = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{ctr[c].z, ctr[c].w}, s2);
+                for (int d0 = 0; d0 < DIA; d0 += 4) {  // tap rows in two groups (4 + 3): 8 independent MFMAs, 32 result registers
+                    f32x4 d[4][2];
+#pragma unroll
+                    for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            if (d0 + dd >= DIA) continue;
+                            // neighbour n = 16q + li of this strip = halo column 16 st + n (columns past the tile: clamped,
+                            // their products fall outside the band)
+                            const int ncol = min(16 * st + 16 * q + li, HALOX - 1);
+                            const f16x8_t nb = *reinterpret_cast<const f16x8_t*>(pl + ((row + d0 + dd) * HALOX + ncol) * 16);
+                            d[dd][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ctr, nb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        }
+                    // lane: neighbour n = 16q + li, centres c = 4 lq + e  ->  tap tx = n - c
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int c = 4 * lq + e, tx = 16 * q + li - c;
+                            const bool in_band = tx >= 0 && tx < DIA;
+                            const int base = in_band ? (16 * st + c) * LOG_PITCH + tx : 32 * LOG_PITCH + (lane & 31);
+#pragma unroll
+                            for (int dd = 0; dd < 4; ++dd)
+                                if (d0 + dd < DIA) stg[base + (in_band ? (d0 + dd) * DIA : 0)] = d[dd][q][e];
+                        }
+                }
+            }
+            // (written and read by the same wave: ordered by the compiler's lgkmcnt wait)
+            if ((lane >> 5) == rr) {
+                const float* mine = stg + (lane & 31) * LOG_PITCH;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    k[t] = mine[t] * temp;
+                    mx = fmaxf(mx, k[t]);
+                }
+            }
         }
-        const float s = s2.x + s2.y;
-        k[t] = s * temp;
-        mx = fmaxf(mx, k[t]);
     }
     float sum = 0.f;
 #pragma unroll
@@ -239,7 +304,7 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
                     // D[unit = 16*ot + 4*fq + j][pixel = row]
                     const float4 bb = *reinterpret_cast<const float4*>(bsrc + ot * 16 + fq * 4);
                     float r0 = acc[0] + bb.x, r1 = acc[1] + bb.y, r2 = acc[2] + bb.z, r3 = acc[3] + bb.w;
-                    if (layer == 0) r0 = gelu_erf(r0), r1 = gelu_erf(r1), r2 = gelu_erf(r2), r3 = gelu_erf(r3);
+                    if (layer == 0) r0 = gelu_sig5(r0), r1 = gelu_sig5(r1), r2 = gelu_sig5(r2), r3 = gelu_sig5(r3);
                     *reinterpret_cast<uint2*>(dst + mlp_off(row, ot * 2 + (fq >> 1)) + (fq & 1) * 8) =
                         make_uint2(pack2h(r0, r1), pack2h(r2, r3));
                 }
@@ -262,8 +327,8 @@ __global__ __launch_bounds__(256) void jbu_kernels_kernel(const float* __restric
     }
     // composite 8x8 kernel on the source grid: rows first (hrow[ry][tx] = sum_ty by[ty][ry] k[ty][tx],
     // k is dead afterwards), then the two halves of the 16 circular column slots
-    const float* byp = bys + (size_t)y * (DIA * 8);
-    const float* bxp = bxs + (size_t)x * (DIA * 16);
+    const float* byp = s_by + ly * (DIA * 8);    // = bys[y], bxs[x] (clamped like y, x), from the block's LDS copy
+    const float* bxp = s_bx + lx * (DIA * 16);
     // The 256-byte record of a pixel is staged in LDS and leaves as 16 bytes per lane with 16 lanes per record: a
     // thread storing its own record directly issues 64 separate 16-byte segments per instruction (partial lines).
     // Wave-private staging [64 px][16 chunks], chunk slot XORed with the pixel index (conflict-free both ways).
@@ -705,7 +770,8 @@ static int launch_jbu_kernels(const float* proj, const float* guidance, void* kc
     ISP_CHECK_ARG(B > 0 && GH >= 4 && GW >= 4 && GH % 2 == 0 && GW % 2 == 0 && B <= 65535 && sigma_spatial != 0.f);
     const float temp = fminf(fmaxf(expf(range_temp), 1e-4f), 1e4f);
     const float inv2s2 = 1.0f / (2.f * sigma_spatial * sigma_spatial);
-    const int lds = HALOY * HALOX * PSTRIDE * 4 + 256;  // 76.8 KB (>= the 64 KB the MLP staging reuses): 2 blocks per CU
+    const int lds = KERNELS_LDS_MAIN + KERNELS_LDS_TABLES;  // 64 KiB (MLP / record staging; the half proj tile + logit staging
+                                                              // fit inside) + Gaussian + table slices = 80.2 KiB: 2 blocks per CU
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)jbu_kernels_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
