@@ -192,7 +192,8 @@ int isp_token_add_fwd(void* x, int x_dtype, const void* add, int add_dtype, long
  * isp_jbu_apply: out [B,2h,2w,C] = composite kernels applied to src [B,h,w,C] (C % 64 == 0). */
 int isp_adaptive_avg_pool_nchw_f32(const float* in, float* out, long planes, int H, int W, int OH, int OW, void* stream);
 int isp_jbu_range_proj(const float* guidance, float* proj, const float* w0, const float* b0, const float* w3,
-                       const float* b3, int B, int GH, int GW, void* stream);
+                       const float* b3, int B, int GH, int GW, int exact_f32, void* stream);
+/* exact_f32 != 0: both layers in fp32 on the VALU with the erf GELU (checking mode); 0: second layer on f16 MFMA. */
 int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const void* fix0_w, const float* fix0_b,
                     const void* fix3_w, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
                     float sigma_spatial, int B, int GH, int GW, void* stream);

@@ -356,7 +356,7 @@ def _jbu(up, cache, feats_nhwc, image):
         B, h, w, C = x.shape
         small = ops.adaptive_avg_pool(g, 2 * h, 2 * w)
         proj = ops.jbu_range_proj(small, f32(st.range_proj[0].weight.flatten(1)), f32(st.range_proj[0].bias),
-                                  f32(st.range_proj[3].weight.flatten(1)), f32(st.range_proj[3].bias))
+                                  f32(st.range_proj[3].weight.flatten(1)), f32(st.range_proj[3].bias), exact=True)
         x = ops.jbu_stage_f32(x, proj, small, f32(st.fixup_proj[0].weight.flatten(1)), f32(st.fixup_proj[0].bias),
                               f32(st.fixup_proj[3].weight.flatten(1)), f32(st.fixup_proj[3].bias),
                               float(st.range_temp.item()), float(st.sigma_spatial.item()))

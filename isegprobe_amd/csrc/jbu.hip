@@ -68,19 +68,18 @@ __global__ __launch_bounds__(256) void adaptive_avg_pool_kernel(const float* __r
 }
 
 // --------------------------------------------------------------------------------------
-// range_proj: 1x1 (3 -> 32), GELU, 1x1 (32 -> 32).  One thread per pixel; output NHWC f32.
-__global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __restrict__ G, float* __restrict__ proj,
-                                                              const float* __restrict__ w0, const float* __restrict__ b0,
-                                                              const float* __restrict__ w3, const float* __restrict__ b3,
-                                                              long HW, long total) {
+// range_proj, exact form: everything in fp32 on the VALU, erf GELU -- for the fp32 checking mode (core/model/precise.py) and
+// the stage-by-stage fp32 derivation (jbu_f32.hip).  One thread per pixel.
+__global__ __launch_bounds__(256) void jbu_range_proj_f32_kernel(const float* __restrict__ G, float* __restrict__ proj,
+                                                                  const float* __restrict__ w0, const float* __restrict__ b0,
+                                                                  const float* __restrict__ w3, const float* __restrict__ b3,
+                                                                  long HW, long total) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const long b = idx / HW, p = idx - b * HW;
     const float g0 = G[(b * 3 + 0) * HW + p], g1 = G[(b * 3 + 1) * HW + p], g2 = G[(b * 3 + 2) * HW + p];
     float hid[KEY];
 #pragma unroll
-    // explicit fmaf: the library is built with -ffp-contract=off (bit-exact click maps), which would otherwise split
-    // every multiply-add of these VALU-bound loops into two instructions
     for (int j = 0; j < KEY; ++j)
         hid[j] = gelu_erf(fmaf(w0[j * 3 + 2], g2, fmaf(w0[j * 3 + 1], g1, fmaf(w0[j * 3 + 0], g0, b0[j]))));
     float4* o = reinterpret_cast<float4*>(proj + idx * KEY);
@@ -96,6 +95,58 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
             r[q] = s;
         }
         o[m4] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// range_proj: 1x1 (3 -> 32), GELU, 1x1 (32 -> 32); output NHWC f32.  Block = 256 pixels.  Layer 1 (96 FMAs + 32 GELUs) is
+// computed by the pixel's own thread; layer 2 (1024 FMAs per pixel on the VALU in the first version: 0.55 ms at 512^2 x 32)
+// is one f16 MFMA pair per 16 pixels: hidden rows go through LDS as half [pixel][32] (80-byte pitch: the operand reads
+// of 16 consecutive pixels x one k-chunk touch every bank once), D[out][pixel] = W3 . H^T leaves as float4 per lane.
+__global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __restrict__ G, float* __restrict__ proj,
+                                                              const float* __restrict__ w0, const float* __restrict__ b0,
+                                                              const float* __restrict__ w3, const float* __restrict__ b3,
+                                                              long HW, long total) {
+    __shared__ __attribute__((aligned(16))) char s_hid[256 * 80];
+    __shared__ __attribute__((aligned(16))) _Float16 s_w3[KEY * KEY];
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = threadIdx.x; i < KEY * KEY; i += 256) s_w3[i] = (_Float16)w3[i];
+    {
+        const long ic = idx < total ? idx : total - 1;
+        const long b = ic / HW, p = ic - b * HW;
+        const float g0 = G[(b * 3 + 0) * HW + p], g1 = G[(b * 3 + 1) * HW + p], g2 = G[(b * 3 + 2) * HW + p];
+#pragma unroll
+        for (int c = 0; c < KEY / 8; ++c) {
+            float h[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int j = c * 8 + e;
+                h[e] = gelu_sig5(fmaf(w0[j * 3 + 2], g2, fmaf(w0[j * 3 + 1], g1, fmaf(w0[j * 3 + 0], g0, b0[j]))));
+            }
+            *reinterpret_cast<uint4*>(s_hid + threadIdx.x * 80 + c * 16) =
+                make_uint4(pack2h(h[0], h[1]), pack2h(h[2], h[3]), pack2h(h[4], h[5]), pack2h(h[6], h[7]));
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    f16x8_t wf[2];  // A operand: W3[out = 16 ot + li][k = 8 lq ..]
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) wf[ot] = *reinterpret_cast<const f16x8_t*>(s_w3 + (ot * 16 + li) * KEY + lq * 8);
+    float4 bias[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) bias[ot] = *reinterpret_cast<const float4*>(b3 + ot * 16 + lq * 4);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {  // the wave's 64 pixels in 4 tiles of 16
+        const int px = wv * 64 + pt * 16 + li;
+        const f16x8_t hb = *reinterpret_cast<const f16x8_t*>(s_hid + px * 80 + lq * 16);
+        const long gi = (long)blockIdx.x * 256 + px;
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ot], hb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            // D[out = 16 ot + 4 lq + j][pixel = px]
+            if (gi < total)
+                *reinterpret_cast<float4*>(proj + gi * KEY + ot * 16 + lq * 4) =
+                    make_float4(d[0] + bias[ot].x, d[1] + bias[ot].y, d[2] + bias[ot].z, d[3] + bias[ot].w);
+        }
     }
 }
 
@@ -755,11 +806,15 @@ extern "C" int isp_adaptive_avg_pool_nchw_f32(const float* in, float* out, long 
 }
 
 extern "C" int isp_jbu_range_proj(const float* guidance, float* proj, const float* w0, const float* b0,
-                                  const float* w3, const float* b3, int B, int GH, int GW, void* stream) {
+                                  const float* w3, const float* b3, int B, int GH, int GW, int exact_f32, void* stream) {
     ISP_CHECK_ARG(guidance && proj && w0 && b0 && w3 && b3 && B > 0 && GH > 0 && GW > 0);
     const long HW = (long)GH * GW, total = HW * B;
-    jbu_range_proj_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(guidance, proj, w0, b0, w3,
-                                                                                            b3, HW, total);
+    if (exact_f32)
+        jbu_range_proj_f32_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(guidance, proj, w0, b0, w3,
+                                                                                                    b3, HW, total);
+    else
+        jbu_range_proj_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(guidance, proj, w0, b0, w3,
+                                                                                                b3, HW, total);
     return isp_launch_status();
 }
 

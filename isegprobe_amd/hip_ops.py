@@ -520,12 +520,13 @@ def adaptive_avg_pool(x, OH, OW):
     return out
 
 
-def jbu_range_proj(g, w0, b0, w3, b3):
-    """g [B,3,GH,GW] f32 -> proj [B,GH,GW,32] f32."""
+def jbu_range_proj(g, w0, b0, w3, b3, exact=False):
+    """g [B,3,GH,GW] f32 -> proj [B,GH,GW,32] f32.  ``exact``: both layers in fp32 with the erf GELU (the fp32 checking
+    mode); default: second layer on f16 MFMA."""
     _need(g, torch.float32, "guidance")
     B, _, GH, GW = g.shape
     proj = torch.empty(B, GH, GW, 32, device=g.device, dtype=torch.float32)
-    check(_lib.lib().isp_jbu_range_proj(_p(g), _p(proj), _p(w0), _p(b0), _p(w3), _p(b3), B, GH, GW, _stream()),
+    check(_lib.lib().isp_jbu_range_proj(_p(g), _p(proj), _p(w0), _p(b0), _p(w3), _p(b3), B, GH, GW, int(bool(exact)), _stream()),
           "isp_jbu_range_proj")
     return proj
 

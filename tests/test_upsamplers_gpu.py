@@ -130,7 +130,7 @@ def test_jbu_composite_stage_vs_plain_fp32_stage():
     f32 = lambda t: t.detach().float().contiguous()
     small = ops.adaptive_avg_pool(g, 24, 40)
     proj = ops.jbu_range_proj(small, f32(st.range_proj[0].weight.flatten(1)), f32(st.range_proj[0].bias),
-                              f32(st.range_proj[3].weight.flatten(1)), f32(st.range_proj[3].bias))
+                              f32(st.range_proj[3].weight.flatten(1)), f32(st.range_proj[3].bias), exact=True)
     ref = ops.jbu_stage_f32(src.to(torch.bfloat16).float(), proj, small, f32(st.fixup_proj[0].weight.flatten(1)),
                             f32(st.fixup_proj[0].bias), f32(st.fixup_proj[3].weight.flatten(1)), f32(st.fixup_proj[3].bias),
                             0.7, 0.9)

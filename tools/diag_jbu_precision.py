@@ -30,7 +30,7 @@ for i, st in enumerate((stack.up1, stack.up2, stack.up3, stack.up4)):
     Bn, hh, ww, _ = xe.shape
     small = ops.adaptive_avg_pool(g, 2 * hh, 2 * ww)
     proj = ops.jbu_range_proj(small, f32(st.range_proj[0].weight.flatten(1)), f32(st.range_proj[0].bias),
-                              f32(st.range_proj[3].weight.flatten(1)), f32(st.range_proj[3].bias))
+                              f32(st.range_proj[3].weight.flatten(1)), f32(st.range_proj[3].bias), exact=True)
     args = (f32(st.fixup_proj[0].weight.flatten(1)), f32(st.fixup_proj[0].bias), f32(st.fixup_proj[3].weight.flatten(1)),
             f32(st.fixup_proj[3].bias), float(st.range_temp.item()), float(st.sigma_spatial.item()))
     ye = ops.jbu_stage_f32(xe, proj, small, *args)
