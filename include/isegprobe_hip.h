@@ -123,6 +123,14 @@ int isp_attention_fwd(const void* Q, const void* K, const void* V, void* O, int 
                       long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
                       long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
 
+/* head_dim 64 only (else ISP_ERR_UNSUPPORTED): Q already carries scale * log2(e), i.e. Q K^T are base-2 logits and the
+ * kernel's exponentials take the MFMA output as it is.  The ViT trunk folds the factor into the Q rows of its packed qkv
+ * weights and bias (attention.py:62 multiplies q by the scale after the projection: same product, rounded once). */
+int isp_attention_fwd_logit2(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
+                             int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
+                             long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
+                             void* stream);
+
 /* Training variant: also writes lse[b*H+h][q] (row stride lse_ld >= Lq, fp32) = log2 sum_k exp2(s_qk * scale * log2 e),
  * the statistic isp_attention_bwd needs to recompute the probabilities. */
 int isp_attention_fwd_lse(const void* Q, const void* K, const void* V, void* O, float* lse, long lse_ld, int B, int H, int Lq,

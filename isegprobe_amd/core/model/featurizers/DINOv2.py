@@ -156,8 +156,16 @@ class DINOv2Featurizer(nn.Module):
             f32 = lambda t: t.detach().float().contiguous()
             b16 = lambda t: t.detach().to(BF16).contiguous()
             blocks = []
+            heads, D = m.num_heads, m.embed_dim
             for blk in m.blocks:
+                # inference copy of the qkv projection whose Q rows carry softmax scale x log2(e) (attention.py:62 scales
+                # q after the projection): the attention kernel's exponentials then take the score MFMAs' output as is
+                qw, qb = blk.attn.qkv.weight.detach().float().clone(), blk.attn.qkv.bias.detach().float().clone()
+                if D // heads == 64:
+                    qw[:D] *= ops.ATTENTION_LOGIT2_SCALE
+                    qb[:D] *= ops.ATTENTION_LOGIT2_SCALE
                 blocks.append(dict(
+                    qkv_w2=qw.to(BF16).contiguous(), qkv_b2=qb.contiguous(),
                     n1w=f32(blk.norm1.weight), n1b=f32(blk.norm1.bias),
                     qkv_w=b16(blk.attn.qkv.weight), qkv_b=f32(blk.attn.qkv.bias),
                     proj_w=b16(blk.attn.proj.weight), proj_b=f32(blk.attn.proj.bias),
@@ -219,10 +227,10 @@ class DINOv2Featurizer(nn.Module):
         nblk = len(P["blocks"])
         for i, blk in enumerate(P["blocks"]):
             hbuf = ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS)
-            qkv = ops.linear(hbuf, blk["qkv_w"], blk["qkv_b"])
+            qkv = ops.linear(hbuf, blk["qkv_w2"], blk["qkv_b2"])
             if want_last_keys and i == nblk - 1:
                 return qkv  # packed [B*L, 3, heads, 64]: the caller extracts K; the rest of the block is unused
-            att = ops.attention_packed_qkv(qkv, B, L, heads, 64 ** -0.5)
+            att = ops.attention_packed_qkv(qkv, B, L, heads, 64 ** -0.5, q_logit2=True)
             ops.linear_residual_(x, att, blk["proj_w"], blk["proj_b"], blk["ls1"])
             if "mlp_fused" in blk and _use_fused_mlp(x.shape[0]):
                 # LayerNorm + fc1 + GELU + fc2 + LayerScale + residual in one token-stationary kernel (csrc/vit_fused.hip)

@@ -243,13 +243,302 @@ int launch_attention(const void* Q, const void* K, const void* V, void* O, int B
     return isp_launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// head_dim 64 (the ViT's self-attention): the generic kernel above spends 3x its MFMA time in VALU work at this head
+// size (per 64-key tile and wave: 16 MFMAs = 512 cycles, against ~280 vector instructions + 32 v_exp), so this variant
+// removes vector instructions instead of re-tiling:
+//   * the MFMA chain's initial accumulator is -m (the row's reference maximum, a 16-register constant per lane): no
+//     accumulator zeroing and no per-element subtraction; with PRESCALED (isp_attention_fwd_logit2: Q already carries
+//     scale*log2(e), the ViT folds it into the Q rows of its qkv weights) the chain's output goes straight into v_exp,
+//     otherwise one v_mul per element remains (re-rounding Q*c to bf16 inside the kernel would avoid it but changes the
+//     scores by up to 2^-9 of their largest term: visible when |score| >> 1);
+//   * m is only moved when some row's tile maximum exceeds it by more than ATT_THR (base-2 units): the O / l rescale,
+//     the refresh of the -m registers and the correction of the tile in flight then sit behind a wave-uniform branch
+//     that is taken for the first tile and rarely afterwards (P <= 2^ATT_THR in between; the decision precedes the
+//     tile's exponentials, so nothing at the old reference is left unscaled);
+//   * the row sums come out of the PV product: a third A operand of ones accumulates l = sum_k bf16(P) in 16 more
+//     accumulator registers (4 MFMAs per tile instead of 32 adds; the normaliser then matches the rounded numerator);
+//   * 256 registers per wave at most (two blocks per CU), so the accumulators live in VGPRs and the rescale needs no
+//     AGPR copies; K/V tiles by buffer_load ... lds against SGPR resources whose range ends at the last key (rows
+//     past it read zeros): no per-tile address arithmetic; the cross-half maximum by v_permlane32_swap.
+// Waves whose 32 queries are all past Lq only stage tiles; when the last tile holds <= 32 keys its second key block
+// is skipped (L = 1025: one block row and one tile per (batch, head) exist for the class token alone).
+// Measured at B 32 x 6 heads x L 1025 (51.6 GFLOP): 86 us against 101-111 us for the generic kernel.  The PMC passes
+// (tools/att_pmc.sh) put the VALU at 44 % and the MFMA pipe at 37 % of the kernel's cycles with no LDS bank conflicts:
+// what is left is latency, and three waves per SIMD hide it best -- a software-pipelined variant at two waves per SIMD
+// (K fragments and V reads a phase ahead, three LDS slots; 96 us), the same with register-staged tiles (108 us) and
+// this kernel squeezed to four waves per SIMD (101 us) all lost.  Removing the exponentials, the PV product, the V
+// reads or the barrier from the loop moves the time by < 12 % each.
+#ifndef ISP_ATT_THR
+#define ISP_ATT_THR 6.0f
+#endif
+#ifndef ISP_ATT_ONES
+#define ISP_ATT_ONES 1
+#endif
+
+__device__ __forceinline__ float xhalf_max(float x) {  // max(x of lane, x of lane ^ 32)
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+
+template <bool PRESCALED>
+__global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                             const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H,
+                                                             int Lq, int Lk, long qsb, long qsl, long qsh, long ksb,
+                                                             long ksl, long ksh, long osb, long osl, long osh,
+                                                             float c_arg /* scale*log2e */, float* __restrict__ lse,
+                                                             long lse_ld, int nbh, int nqb) {
+    using G = Geo<64>;
+    const float c = PRESCALED ? 1.f : c_arg;  // scores, m_run and the threshold are in units of 1/c base-2 logits
+    const float thr = PRESCALED ? ISP_ATT_THR : ISP_ATT_THR / c_arg;
+    constexpr int NW = 4, KK = 4, DB = 2, QB = 32 * NW, PPW = G::PIECES / NW;  // 2 K + 2 V pieces per wave and tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2: with the q-blocks of one
+    // (batch, head) on consecutive ids, its K and V (262 KB at L = 1025) are pulled over the fabric into all 8 L2s --
+    // 400 MB per launch at B = 32, which alone takes the ~90 us the kernel ran in.  Remapped so that the q-blocks of a
+    // (batch, head) share id % 8 (same XCD, dispatched back to back) whenever the number of (batch, head) pairs allows.
+    int bh, qblk;
+    if (nbh % 8 == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bh = (slot / nqb) * 8 + xcd, qblk = slot % nqb;
+    } else {
+        bh = blockIdx.x / nqb, qblk = blockIdx.x % nqb;
+    }
+    const int b = bh / H, h = bh % H;
+    const int r = lane & 31, hh = lane >> 5;
+    const bool active = qblk * QB + wid * 32 < Lq;  // wave-uniform
+
+    // ---- Q fragments (B operand of S^T = K Q^T): element j <-> d = 16kk + 8hh + j
+    const long qrow = (long)qblk * QB + wid * 32 + r;
+    const bf16_t* qp = Q + (size_t)b * qsb + (size_t)(qrow < Lq ? qrow : Lq - 1) * qsl + (size_t)h * qsh + 8 * hh;
+    bf16x8 qf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + 16 * kk);
+
+    // ---- DMA: lane-constant offsets, the tile advances through the scalar offset
+    const int kbytes = (int)(((long)(Lk - 1) * ksl + 64) * 2);  // (checked by the launcher: < 2^31)
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(K + (size_t)b * ksb + (size_t)h * ksh), 0, kbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(V + (size_t)b * ksb + (size_t)h * ksh), 0, kbytes, 0x00020000);
+    unsigned koff[PPW], voff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int row = (wid + NW * i) * G::ROWS_PER_PIECE + lane / G::CHUNKS, pch = lane % G::CHUNKS;
+        koff[i] = (unsigned)(row * ksl + G::kswz(row, pch) * 8) * 2u;
+        voff[i] = (unsigned)(row * ksl + G::vswz(row, pch) * 8) * 2u;
+    }
+    const int tile_stride = (int)(KB * ksl * 2);
+    auto stage = [&](int tile, char* buf) {
+        const int so = tile * tile_stride;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (ISP_LDS void*)(buf + (wid + NW * i) * 1024), 16, koff[i], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (ISP_LDS void*)(buf + G::TILE + (wid + NW * i) * 1024), 16, voff[i],
+                                                     so, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses (as in the generic kernel)
+    int k_off[2][KK];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int row = kb * 32 + r;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) k_off[kb][kk] = row * G::ROW + (G::kswz(row, 2 * kk + hh) << 4);
+    }
+    const int gi = lane & 15, gq = gi >> 2, gp = gi & 3, g1 = (lane >> 4) & 1;
+    int v_off[DB][2][2][2];  // [db][kb][s][jj]
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int key = kb * 32 + 16 * s + 8 * jj + 4 * hh + gq;
+                    const int col = db * 32 + 16 * g1 + 4 * gp;
+                    v_off[db][kb][s][jj] = G::TILE + key * G::ROW + G::vswz(key, col >> 3) * 16 + (col & 7) * 2;
+                }
+
+    f32x16 o[DB], negm;
+#if ISP_ATT_ONES
+    f32x16 lacc;
+    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+#else
+    float l_run = 0.f;
+#endif
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        o[0][i] = 0.f, o[1][i] = 0.f, negm[i] = 0.f;
+#if ISP_ATT_ONES
+        lacc[i] = 0.f;
+#endif
+    }
+    float m_run = 0.f;
+
+    // one key block (32 keys) of a tile: S^T chain from -m, optional mask of keys >= Lk
+    auto scores = [&](f32x16& s, const char* buf, int kb, int key0, bool mask) {
+        s = negm;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf + k_off[kb][kk]);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+        }
+        if (mask) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (key0 + (i & 3) + 8 * (i >> 2) + 4 * hh >= Lk) s[i] = -INFINITY;
+        }
+    };
+    auto max16 = [](const f32x16& s) {
+        float a = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) a = fmaxf(fmaxf(a, s[i]), s[i + 1]);
+        return fmaxf(a, s[15]);
+    };
+    // P = exp2(S') in place, then O^T += V^T P^T (and l += 1^T P^T) for one key block
+    auto exp_pv = [&](f32x16& s, const char* buf, int kb) {
+#if !ISP_ATT_ONES
+        float psum = 0.f;
+#endif
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s[i] = __builtin_amdgcn_exp2f(PRESCALED ? s[i] : s[i] * c);
+#if !ISP_ATT_ONES
+            psum += s[i];
+#endif
+        }
+#if !ISP_ATT_ONES
+        l_run += psum;
+#endif
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s[8 * ss + j]);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const s16x4 lo = tr_read(buf + v_off[db][kb][ss][0]);
+                const s16x4 hi = tr_read(buf + v_off[db][kb][ss][1]);
+                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+            }
+#if ISP_ATT_ONES
+            lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+#endif
+        }
+    };
+    // move the reference maximum by d (per row; the same in both halves of a row) before the tile's exponentials
+    auto rebase = [&](f32x16& s0, f32x16& s1, float d, bool first) {
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-d * c);  // (first tile: O = l = 0, and d may be < 0)
+        m_run += d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s0[i] -= d, s1[i] -= d;
+            o[0][i] *= alpha, o[1][i] *= alpha;
+#if ISP_ATT_ONES
+            lacc[i] *= alpha;
+#endif
+            negm[i] = -m_run;
+        }
+#if !ISP_ATT_ONES
+        l_run *= alpha;
+#endif
+    };
+
+    const int nt = (Lk + KB - 1) / KB;
+    // FIRST: the reference maximum is set from the tile (whatever its sign); LAST: keys >= Lk are masked and the
+    // second key block may be empty.  (Separate instantiations: as run-time flags the masks become 120 selects per tile.)
+    auto tile = [&]<bool FIRST, bool LAST>(int t) {
+        const char* buf = (t & 1) ? smem + 2 * G::TILE : smem;
+        if (!LAST) stage(t + 1, (t & 1) ? smem : smem + 2 * G::TILE);
+        if (active) {
+            const int key0 = t * KB;
+            const bool two = !LAST || key0 + 32 < Lk;  // the second key block holds a key (wave-uniform)
+            f32x16 s0, s1;
+            scores(s0, buf, 0, key0, LAST);
+            if (two) {
+                scores(s1, buf, 1, key0 + 32, LAST);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s1[i] = -INFINITY;
+            }
+            const float mx = xhalf_max(fmaxf(max16(s0), max16(s1)));  // tile maximum of the row, relative to m_run
+            if (FIRST) {
+                rebase(s0, s1, mx, true);
+            } else if (__builtin_amdgcn_ballot_w64(mx > thr) != 0) {
+                rebase(s0, s1, fmaxf(mx, 0.f), false);
+            }
+            exp_pv(s0, buf, 0);
+            if (two) exp_pv(s1, buf, 1);
+        }
+        __syncthreads();
+    };
+    stage(0, smem);
+    __syncthreads();
+    if (nt == 1) {
+        tile.template operator()<true, true>(0);
+    } else {
+        tile.template operator()<true, false>(0);
+        for (int t = 1; t + 1 < nt; ++t) tile.template operator()<false, false>(t);
+        tile.template operator()<false, true>(nt - 1);
+    }
+    if (!active) return;
+
+    // ---- epilogue: O[b, q, h, d] = o / l
+#if ISP_ATT_ONES
+    const float l_tot = lacc[0];
+#else
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+#endif
+    const float inv = 1.0f / l_tot;
+    if (lse && hh == 0 && qrow < Lq) lse[(size_t)bh * lse_ld + qrow] = m_run * c + log2f(l_tot);
+    if (qrow < Lq) {
+        bf16_t* op = O + (size_t)b * osb + (size_t)qrow * osl + (size_t)h * osh;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = db * 32 + 8 * g4 + 4 * hh;
+                *reinterpret_cast<uint2*>(op + d) =
+                    make_uint2(pack2bf(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv),
+                               pack2bf(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
+            }
+    }
+}
+
+constexpr int kAtt64Lds = Geo<64>::LDS;  // (K + V) x 2 buffers
+
+template <bool PRESCALED>
+int launch_attention64(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, long qsb,
+                       long qsl, long qsh, long ksb, long ksl, long ksh, long osb, long osl, long osh, float scale,
+                       float* lse, long lse_ld, hipStream_t s) {
+    static bool attr_done = false;
+    auto kern = attention64_kernel<PRESCALED>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kAtt64Lds) != hipSuccess)
+            return ISP_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const int nqb = (Lq + 127) / 128;
+    kern<<<(unsigned)(nqb * B * H), 256, kAtt64Lds, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, H, Lq,
+                                                            Lk, qsb, qsl, qsh, ksb, ksl, ksh, osb, osl, osh,
+                                                            scale * 1.4426950408889634f, lse, lse_ld, B * H, nqb);
+    return isp_launch_status();
+}
+
 }  // namespace
 
 static int attention_fwd_impl(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
                               int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
                               long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
-                              float scale, float* lse, long lse_ld, void* stream) {
-    ISP_CHECK_ARG(Q && K && V && O && B > 0 && H > 0 && Lq > 0 && Lk > 0 && scale > 0.f);
+                              float scale, float* lse, long lse_ld, void* stream, bool logit2 = false) {
+    ISP_CHECK_ARG(Q && K && V && O && B > 0 && H > 0 && Lq > 0 && Lk > 0 && (logit2 || scale > 0.f));
     ISP_CHECK_ARG((long)B * H <= 65535);
     // 16-byte vector loads / 8-byte stores need aligned strides
     ISP_CHECK_ARG(q_stride_b % 8 == 0 && q_stride_l % 8 == 0 && q_stride_h % 8 == 0);
@@ -257,9 +546,22 @@ static int attention_fwd_impl(const void* Q, const void* K, const void* V, void*
     ISP_CHECK_ARG(o_stride_b % 4 == 0 && o_stride_l % 4 == 0 && o_stride_h % 4 == 0);
     ISP_CHECK_ARG(!lse || lse_ld >= Lq);
     hipStream_t s = (hipStream_t)stream;
-    if (head_dim == 64)
-        return launch_attention<64>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
-                                    kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
+    if (logit2 && head_dim != 64) return ISP_ERR_UNSUPPORTED;
+    if (head_dim == 64) {
+        // the 64-wide variant addresses keys through a 32-bit buffer range and assumes a key row >= its head slice
+        static const bool generic64 = [] { const char* e = getenv("ISEGPROBE_ATT64"); return e && e[0] == '0'; }();
+        if (!generic64 && kv_stride_l >= 64 && ((long)(Lk - 1) * kv_stride_l + 64) * 2 < (1L << 31) &&
+            (long)KB * kv_stride_l * 2 * ((Lk + KB - 1) / KB) < (1L << 31))
+            return logit2 ? launch_attention64<true>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                                                     kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, lse,
+                                                     lse_ld, s)
+                          : launch_attention64<false>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                                      kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
+        // (generic kernel: its scale argument times log2(e) multiplies the scores; base-2 logits need 1 / log2(e))
+        return launch_attention<64>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l,
+                                    kv_stride_h, o_stride_b, o_stride_l, o_stride_h, logit2 ? 0.6931471805599453f : scale, lse,
+                                    lse_ld, s);
+    }
     if (head_dim == 128) {
         // 256-query blocks once they still fill the chip several times over
         if ((long)((Lq + 255) / 256) * B * H >= 2048)
@@ -293,4 +595,15 @@ extern "C" int isp_attention_fwd_lse(const void* Q, const void* K, const void* V
     ISP_CHECK_ARG(lse);
     return attention_fwd_impl(Q, K, V, O, B, H, Lq, Lk, head_dim, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
                               kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, stream);
+}
+
+// head_dim 64 only: Q already carries softmax scale x log2(e) (Q K^T are base-2 logits) -- what the ViT trunk passes
+// after folding that factor into the Q rows of its qkv weights (reference dinov2/layers/attention.py:62 applies the
+// scale to q after the projection; same product, one rounding).
+extern "C" int isp_attention_fwd_logit2(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
+                                        int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
+                                        long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l,
+                                        long o_stride_h, void* stream) {
+    return attention_fwd_impl(Q, K, V, O, B, H, Lq, Lk, head_dim, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                              kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, stream, true);
 }

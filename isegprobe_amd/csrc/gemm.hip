@@ -905,14 +905,24 @@ __device__ __forceinline__ void conv3x3_patch4_body(const bf16_t* __restrict__ i
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = xcd_remap(blockIdx.x, nwg);
-    const int tn = wg % tiles_n;
-    const int tmi = wg / tiles_n;
-    const int per_img = tiles_x * tiles_y;
-    const int b = tmi / per_img, tt = tmi - b * per_img;
-    const int y0 = (tt / tiles_x) * PT, x0 = (tt % tiles_x) * PT, n0 = tn * PBN;
     const long K = 9L * C;
     const int cblocks = C / BK;
+    const int per_img = tiles_x * tiles_y;
+    // Persistent over output tiles: the grid is one workgroup per CU (ISEGPROBE_CONV_PERSIST=0: one per tile, as before)
+    // and each walks tiles blockIdx, blockIdx + grid, ... -- a tile is ~60 us of MFMA work, and ending a workgroup +
+    // starting the next (wave launch, resource setup, a cold first DMA round trip) cost several us of it.
+#pragma unroll 1
+    for (int wgi = blockIdx.x; wgi < nwg; wgi += gridDim.x) {
+    const int wg = xcd_remap(wgi, nwg);
+    const int tn = wg % tiles_n;
+    const int tmi = wg / tiles_n;
+    const int b = tmi / per_img, tt = tmi - b * per_img;
+    const int y0 = (tt / tiles_x) * PT, x0 = (tt % tiles_x) * PT, n0 = tn * PBN;
+    // Per-tile lane-dependent values (DMA offsets here, the epilogue's addresses below) are derived from an opaque copy
+    // of the lane id: derived from `lane` itself their tile-invariant halves are hoisted out of the tile loop and, with
+    // all 512 registers taken by the main loop, spilled to scratch there and reloaded for every tile (~200 values).
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
 
     // --- DMA slots.  Wave w owns patch pieces w, w+4, ... (a wave whose last slot falls off the patch re-issues
     // its previous piece, so that every wave issues the same number of DMA instructions per step: the vmcnt
@@ -927,11 +937,11 @@ __device__ __forceinline__ void conv3x3_patch4_body(const bf16_t* __restrict__ i
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int piece = wid + NWV * i < P_PIECES ? wid + NWV * i : wid + NWV * (i - 1);
-        const int pix = piece * 8 + (lane >> 3);
+        const int pix = piece * 8 + (lane_t >> 3);
         const int py = pix / PW_, px = pix - py * PW_;
         const int iy = y0 - 1 + py, ix = x0 - 1 + px;
         const bool ok = pix < PPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        poff[i] = ok ? (unsigned)((iy * W + ix) * C + swz(px, lane & 7) * 8) * 2u : 0x80000000u;
+        poff[i] = ok ? (unsigned)((iy * W + ix) * C + swz(px, lane_t & 7) * 8) * 2u : 0x80000000u;
         ppiece[i] = piece;
     }
     auto issue_patch = [&](int i, int cb, char* buf) {
@@ -941,8 +951,8 @@ __device__ __forceinline__ void conv3x3_patch4_body(const bf16_t* __restrict__ i
     unsigned woff[WPW];
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-        const int row = (wid + NWV * i) * 8 + (lane >> 3);
-        woff[i] = (unsigned)((row < wrows ? row : wrows - 1) * K + swz(row, lane & 7) * 8) * 2u;
+        const int row = (wid + NWV * i) * 8 + (lane_t >> 3);
+        woff[i] = (unsigned)((row < wrows ? row : wrows - 1) * K + swz(row, lane_t & 7) * 8) * 2u;
     }
     auto issue_w = [&](int col, char* buf) {
 #pragma unroll
@@ -1070,18 +1080,27 @@ __device__ __forceinline__ void conv3x3_patch4_body(const bf16_t* __restrict__ i
 #ifdef ISP_ABLATE_NO_EPILOGUE
     if (acc[0][0][0] != 12345.678f) return;
 #endif
+    int lane_e = lane;  // (opaque, as lane_t above)
+    asm volatile("" : "+v"(lane_e));
+    const int fr_e = lane_e & 15, fq_e = lane_e >> 4;
     if (y0 + PT <= H && x0 + PT <= W && n0 + PBN <= N) {  // interior tile: no per-lane checks
         auto row_in = [&](int r) -> long { return ((long)b * H + y0 + (r >> 4)) * W + x0 + (r & 15); };
         // the other waves are past every LDS read whose value is used: no barrier before the wave-private staging
         if constexpr (kStagedStore<EP>) {
-            staged_epilogue<TM, TN>(ep, acc, row_in, wm * (TM * 16), fr, fq, lane, n0 + wn * (TN * 16),
+            staged_epilogue<TM, TN>(ep, acc, row_in, wm * (TM * 16), fr_e, fq_e, lane_e, n0 + wn * (TN * 16),
                                     smem + wid * kStageBytes<TM, TN>);
         } else {
-            run_epilogue<TM, TN, true>(ep, acc, row_in, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
+            run_epilogue<TM, TN, true>(ep, acc, row_in, wm * (TM * 16), fr_e, fq_e, n0 + wn * (TN * 16), N, tn * 2 + wn);
         }
     } else {
-        run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * 2 + wn);
+        run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr_e, fq_e, n0 + wn * (TN * 16), N, tn * 2 + wn);
     }
+    if (wgi + (int)gridDim.x < nwg) {
+        // the next tile's prologue DMA overwrites LDS that the waves' epilogue staging may still be reading
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    }  // tiles
 }
 
 // (thin kernels: with the body above written directly as a __global__ template that depends on TN, hipcc 7.2
@@ -1118,8 +1137,17 @@ int launch_conv_patch4(const void* in, const void* Wt, int B, int H, int W, int 
             return ISP_ERR_LAUNCH;
         attr_done = true;
     }
-    kern<<<(unsigned)nwg, 256, P_LDS, s>>>((const bf16_t*)in, (const bf16_t*)Wt, H, W, C, N, tiles_x, tiles_y, tiles_n,
-                                          (int)nwg, ep);
+    static int persist_grid = -1;  // workgroups of the persistent launch = CUs (156 KiB of LDS: one workgroup per CU)
+    if (persist_grid < 0) {
+        const char* e = getenv("ISEGPROBE_CONV_PERSIST");
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (e && e[0] == '0') persist_grid = 0;
+        else if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) persist_grid = p.multiProcessorCount;
+        else persist_grid = 0;
+    }
+    const unsigned grid = persist_grid > 0 && nwg > persist_grid ? (unsigned)persist_grid : (unsigned)nwg;
+    kern<<<grid, 256, P_LDS, s>>>((const bf16_t*)in, (const bf16_t*)Wt, H, W, C, N, tiles_x, tiles_y, tiles_n, (int)nwg, ep);
     return isp_launch_status();
 }
 

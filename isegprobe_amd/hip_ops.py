@@ -250,16 +250,24 @@ def layernorm(x, gamma, beta, eps, out_dtype=BF16, group_out=0, skip=0, rows_out
     return out
 
 
-def attention_packed_qkv(qkv, B, L, heads, scale):
-    """qkv [B*L, 3*heads*64] bf16 laid out (3, heads, 64) per token (attention.py:56-60)."""
+ATTENTION_LOGIT2_SCALE = 64 ** -0.5 * 1.4426950408889634  # what `q_logit2` expects to be folded into q (head_dim 64)
+
+
+def attention_packed_qkv(qkv, B, L, heads, scale, q_logit2=False):
+    """qkv [B*L, 3*heads*64] bf16 laid out (3, heads, 64) per token (attention.py:56-60).  q_logit2: the q third
+    already carries scale * log2(e) (folded into the qkv weights, see DINOv2 featurizer): `scale` is then unused."""
     _need(qkv, BF16, "qkv")
     D = heads * 64
     out = torch.empty(B * L, D, device=qkv.device, dtype=BF16)
     base = qkv.data_ptr()
     q, k, v = (ctypes.c_void_p(base + i * D * 2) for i in range(3))
-    check(_lib.lib().isp_attention_fwd(q, k, v, _p(out), B, heads, L, L, 64,
-                                       L * 3 * D, 3 * D, 64, L * 3 * D, 3 * D, 64, L * D, D, 64,
-                                       float(scale), _stream()), "isp_attention_fwd")
+    strides = (L * 3 * D, 3 * D, 64, L * 3 * D, 3 * D, 64, L * D, D, 64)
+    if q_logit2:
+        check(_lib.lib().isp_attention_fwd_logit2(q, k, v, _p(out), B, heads, L, L, 64, *strides, _stream()),
+              "isp_attention_fwd_logit2")
+    else:
+        check(_lib.lib().isp_attention_fwd(q, k, v, _p(out), B, heads, L, L, 64, *strides, float(scale), _stream()),
+              "isp_attention_fwd")
     return out
 
 

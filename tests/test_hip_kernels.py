@@ -221,7 +221,8 @@ def test_gemm_bf16_store_paths(ops):
             assert torch.equal(out[:, N:], torch.full((M, ldo - N), 7.0, device="cuda", dtype=BF))  # padding untouched
 
 
-@pytest.mark.parametrize("B,L,heads", [(1, 64, 1), (2, 257, 2), (2, 1025, 6), (1, 130, 3)])
+@pytest.mark.parametrize("B,L,heads", [(1, 64, 1), (2, 257, 2), (2, 1025, 6), (1, 130, 3), (1, 33, 2), (1, 96, 1), (1, 97, 1),
+                                       (2, 160, 2), (1, 1, 1)])
 def test_attention_packed(ops, B, L, heads):
     torch.manual_seed(L)
     D = heads * 64
@@ -232,6 +233,15 @@ def test_attention_packed(ops, B, L, heads):
     ref = (p @ v).transpose(1, 2).reshape(B * L, D)
     assert (out.float() - ref).abs().max().item() < 2e-2
     assert rel_err(out, ref) < 2e-2
+    # the ViT's form: q already carries scale * log2(e), the scores are base-2 logits
+    qkv2 = qkv.clone()
+    qkv2[:, :D] = bf(qkv[:, :D].float() * ops.ATTENTION_LOGIT2_SCALE)
+    out2 = ops.attention_packed_qkv(qkv2, B, L, heads, None, q_logit2=True)
+    q2 = qkv2[:, :D].float().view(B, L, heads, 64).permute(0, 2, 1, 3)
+    p2 = (q2 @ k.transpose(-2, -1) * math.log(2.0)).softmax(-1)
+    ref2 = (p2 @ v).transpose(1, 2).reshape(B * L, D)
+    assert (out2.float() - ref2).abs().max().item() < 2e-2
+    assert rel_err(out2, ref2) < 2e-2
 
 
 def test_attention_online_softmax_rescale(ops):
@@ -246,6 +256,31 @@ def test_attention_online_softmax_rescale(ops):
     p = (qf.permute(0, 2, 1, 3) @ kf.permute(0, 2, 3, 1)).softmax(-1)
     ref = (p @ vf.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
     assert (out.float() - ref).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("spike_key,gain", [(3, 400.0), (70, 30.0), (200, 400.0), (200, 9.0), (255, 60.0), (256, 400.0)])
+def test_attention_deferred_max(ops, spike_key, gain):
+    """The head_dim-64 kernel keeps a row's reference maximum until a tile exceeds it by a threshold; spikes below,
+    near and far above the threshold, in the first, a middle and the last (one-key) tile, against an fp64 softmax.
+    Rows whose scores are all very negative (the first tile sets the reference whatever its sign) are in there too."""
+    torch.manual_seed(spike_key)
+    B, L, heads = 1, 257, 1
+    q = torch.randn(B, L, heads, 64, device="cuda") * 0.5
+    k = torch.randn(B, L, heads, 64, device="cuda") * 0.5
+    v = torch.randn(B, L, heads, 64, device="cuda")
+    k[0, spike_key] = q[0, 17] * gain / q[0, 17].square().sum()  # score(17, spike_key) = gain
+    u = torch.zeros(64, device="cuda")
+    u[5] = 1.0
+    k[0, :64, 0] += 3 * u                                         # query 40: scores ~ -90 in the first tile, ~ 0 later
+    q[0, 40, 0] = -30 * u
+    out, lse = ops.attention_lse(bf(q), bf(k), bf(v), 1.0)
+    qd, kd, vd = bf(q).double(), bf(k).double(), bf(v).double()
+    sc = qd.permute(0, 2, 1, 3) @ kd.permute(0, 2, 3, 1)
+    ref = (sc.softmax(-1) @ vd.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+    assert (out.double() - ref).abs().max().item() < 2e-2
+    ref_lse = torch.logsumexp(sc, -1)[0, 0] / math.log(2.0)
+    got = lse.reshape(-1)[:L].double()
+    assert (got - ref_lse).abs().max().item() < 2e-2 + 2e-3 * ref_lse.abs().max().item()
 
 
 @pytest.mark.parametrize("shape", [(2, 4, 5, 56, 70, 64), (1, 32, 32, 448, 448, 384)])
