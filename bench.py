@@ -402,7 +402,7 @@ def run_forward(args):
         if vit_ms:
             fl = B * vit_flops(D, L, h * w)
             line["roofline_vit"] = {"kernel": "DINOv2 forward: patch embed (image + clicks), blocks, final norm "
-                                              "(gemm_tile_kernel, attention_kernel<64>, layernorm)",
+                                              "(gemm_tile_kernel, attention64_kernel, layernorm)",
                                     "bound": "mfma", "achieved": fl / (vit_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                                     "unit": "TFLOP/s", "frac": fl / (vit_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                                     "ms_per_step": vit_ms, "ms_in_step_beside_jbu_records": vit_in, "flops_per_step": fl,
@@ -410,7 +410,7 @@ def run_forward(args):
         att_ms = (st or {}).get("attention_launch_ms") or (float(np.mean(att_in)) if att_in else None)
         if att_ms:
             fl = B * attention_flops(D, L, h * w) / L
-            line["roofline_attention"] = {"kernel": "attention_kernel<64> (fused softmax(QK^T)V, LDS-staged K/V tiles), one launch per block",
+            line["roofline_attention"] = {"kernel": "attention64_kernel<true> (fused softmax(QK^T)V on base-2 logits, LDS-staged K/V tiles), one launch per block",
                                           "bound": "mfma", "achieved": fl / (att_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                                           "unit": "TFLOP/s", "frac": fl / (att_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                                           "launch_ms": att_ms, "launch_ms_in_step_beside_jbu_records": float(np.mean(att_in)) if att_in else None,

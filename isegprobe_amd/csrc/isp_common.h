@@ -67,11 +67,12 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + f
 
 // GELU(x) = x * Phi(x) with Phi(x) ~ sigmoid(x * (c0 + c1 x^2 + c2 x^4)): max |error| 2.5e-5 over the real line (fit
 // against the erf form, tools/fit_gelu.py), 1/160 of a bf16 ulp at 1.0 -- the result is rounded to bf16 right away.
-// One v_exp + one v_rcp + 5 plain VALU per value instead of the erf polynomial's 14: this kernel's GELU has to fit into
-// the issue slots the MFMAs leave free.
+// One v_exp + one v_rcp + 6 plain VALU per value instead of the erf polynomial's 14: this kernel's GELU has to fit into
+// the issue slots the MFMAs leave free.  x^2 is clamped at 36: the quartic (c2 < 0) turns negative at |x| = 11.1, and
+// beyond |x| = 6 the sigmoid is saturated to 2e-9 anyway.
 __device__ __forceinline__ float gelu_sig5(float x) {
     constexpr float L2E = 1.4426950408889634f;
-    const float x2 = x * x;
+    const float x2 = fminf(x * x, 36.0f);
     float p = fmaf(-0.0007030391178699941f * L2E, x2, 0.07401132856622687f * L2E);
     p = fmaf(p, x2, 1.595015725363722f * L2E);
     const float e = __builtin_amdgcn_exp2f(-x * p);  // v_exp_f32

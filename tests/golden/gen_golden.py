@@ -796,12 +796,45 @@ def gen_datasets():
     save("datasets", **out)
 
 
+def gen_crops():
+    """Crops transform (core/inference/transforms/crops.py): window offsets over a sweep of lengths, and one forward /
+    inverse pass (crop batch, shifted clicks, overlap-averaged probabilities) per geometry."""
+    from core.inference.clicker import Click
+    from core.inference.transforms import Crops
+    from core.inference.transforms.crops import get_offsets
+    rng = np.random.default_rng(11)
+    out = {}
+    sweep = [(L, c, ov) for c in (32, 48, 320) for ov in (0.2, 0.35, 0.0) for L in (c, c + 1, c + 7, 2 * c - 1, 2 * c, 2 * c + 5, 3 * c + 11, 1000)]
+    out["offsets_args"] = np.array(sweep, np.float64)
+    flat, ptr = [], [0]
+    for L, c, ov in sweep:
+        flat += get_offsets(L, c, ov)
+        ptr.append(len(flat))
+    out["offsets_flat"], out["offsets_ptr"] = np.array(flat, np.int64), np.array(ptr, np.int64)
+    cases = {"pass": ((40, 70), (48, 64), 0.2), "exact": ((48, 64), (48, 64), 0.2), "two_by_three": ((70, 150), (48, 64), 0.2),
+             "tall": ((131, 64), (48, 64), 0.35)}
+    for tag, ((H, W), crop, ov) in cases.items():
+        image = torch.tensor(rng.standard_normal((1, 4, H, W)), dtype=torch.float32)
+        clicks = [Click(True, (int(rng.integers(H)), int(rng.integers(W))), indx=0), Click(False, (3, W - 2), indx=1),
+                  Click(True, (H - 1, 0), indx=2)]
+        t = Crops(crop_size=crop, min_overlap=ov)
+        crops, cl = t.transform(image, [clicks])
+        probs = torch.tensor(rng.uniform(0, 1, (crops.shape[0], 1, *crops.shape[2:])), dtype=torch.float32)
+        merged = t.inv_transform(probs)
+        out[f"{tag}_args"] = np.array([H, W, crop[0], crop[1], ov], np.float64)
+        out[f"{tag}_image"], out[f"{tag}_crops"] = image.numpy(), crops.numpy()
+        out[f"{tag}_clicks"] = np.array([[c.is_positive, c.coords[0], c.coords[1], c.indx] for c in clicks], np.int64)
+        out[f"{tag}_crop_clicks"] = np.array([[[c.is_positive, c.coords[0], c.coords[1], c.indx] for c in lst] for lst in cl], np.int64)
+        out[f"{tag}_probs"], out[f"{tag}_merged"] = probs.numpy(), merged.numpy()
+    save("crops", **out)
+
+
 def main():
     torch.set_num_threads(4)
     install_standins()
-    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "train_step", "datasets"]
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "train_step", "datasets", "crops"]
     fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino, "simple_vit": gen_simple_vit, "maskclip": gen_maskclip,
-           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "train_step": gen_train_step, "datasets": gen_datasets}
+           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "train_step": gen_train_step, "datasets": gen_datasets, "crops": gen_crops}
     for w in which:
         fns[w]()
 

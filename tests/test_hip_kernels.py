@@ -334,3 +334,32 @@ def test_vit_mlp_fused(ops, M, D, HID):
     e, e3 = (y - ref).abs().max().item(), (y3 - ref).abs().max().item()
     print(f"fused MLP M={M} D={D}: max err {e:.3g} (three-kernel route {e3:.3g}), ref rms {ref.pow(2).mean().sqrt():.3f}")
     assert e < 3e-2 and e < 2 * e3 + 1e-3
+
+
+def test_sigmoid_gelu_far_from_zero(ops):
+    """The kernels' GELU is x * sigmoid(x * quartic(x^2)) with a negative leading coefficient: without the clamp of x^2 it
+    returns 0 for x > 11.1 and x for x < -11.1.  Hidden pre-activations of +-40 through the fused ViT MLP and the
+    FeatUp-JBU range projection (both use it), against the erf form."""
+    torch.manual_seed(3)
+    M, D, HID = 256, 384, 1536
+    x = torch.randn(M, D, device="cuda")
+    nw, nb = torch.ones(D, device="cuda"), torch.zeros(D, device="cuda")
+    w1, b1 = torch.randn(HID, D, device="cuda") / math.sqrt(D), torch.randn(HID, device="cuda") * 0.3
+    b1[::3] += 40.0
+    b1[1::3] -= 40.0
+    w2, b2 = torch.randn(D, HID, device="cuda") / math.sqrt(HID) * 0.05, torch.zeros(D, device="cuda")
+    ls = torch.ones(D, device="cuda")
+    pre = bf(F.layer_norm(x, (D,), nw, nb, 1e-6)).float() @ bf(w1).float().t() + b1
+    ref = x + bf(F.gelu(pre)).float() @ bf(w2).float().t()
+    y = ops.vit_mlp_fused_(x.clone(), *ops.vit_mlp_pack(nw, nb, w1, b1, w2, b2, ls), 1e-6)
+    assert pre.abs().max().item() > 30
+    assert (y - ref).abs().max().item() < 5e-2  # (an unclamped quartic is off by ~40 * |w2| * 512 terms)
+    g = torch.randn(1, 3, 32, 32, device="cuda")
+    w0, b0 = torch.randn(32, 3, device="cuda"), torch.randn(32, device="cuda")
+    b0[::2] += 40.0
+    b0[1::2] -= 40.0
+    w3, b3 = torch.randn(32, 32, device="cuda") * 0.05, torch.randn(32, device="cuda")
+    proj = ops.jbu_range_proj(g, w0, b0, w3, b3)
+    hid = F.gelu(torch.einsum("bchw,nc->bhwn", g, w0) + b0)
+    refp = hid @ w3.t() + b3
+    assert (proj - refp).abs().max().item() < 2e-2 * refp.abs().max().item()
