@@ -182,6 +182,30 @@ def test_conv3x3(ops, B, H, W, C, N):
     assert rel_err(y.permute(0, 3, 1, 2), ref) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,W,C,N", [(3, 200, 200, 192, 192), (2, 150, 170, 64, 384), (2, 130, 130, 128, 256),
+                                       (1, 300, 280, 256, 192)])
+def test_conv3x3_tile_stream(ops, B, H, W, C, N):
+    """More output tiles than CUs: a workgroup of the patch kernel walks several tiles and its K-step stream runs across
+    them (the next tile's first patch / weight tiles are fetched during the last channel block, the epilogue stages through
+    the free patch buffer).  Odd (3) and single channel-block counts flip the patch-buffer parity per tile; border tiles
+    and both channel-block widths (192, 128) are in there.  Also the fused epilogues on such a launch."""
+    torch.manual_seed(C + H)
+    x = bf(torch.randn(B, C, H, W, device="cuda"))
+    w = bf(torch.randn(N, C, 3, 3, device="cuda") / math.sqrt(9 * C))
+    bias = torch.randn(N, device="cuda")
+    conv = F.conv2d(x.float(), w.float(), bias, padding=1)
+    xn, wt = x.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous()
+    y = ops.conv3x3(xn, wt, bias, "relu")
+    assert (y.permute(0, 3, 1, 2).float() - F.relu(conv)).abs().max().item() < 3e-2
+    assert rel_err(y.permute(0, 3, 1, 2), F.relu(conv)) < 1e-2
+    y2 = ops.conv3x3(xn, wt, bias, "relu")
+    assert torch.equal(y, y2)
+    wcls = torch.randn(N, device="cuda") / math.sqrt(N)
+    z = ops.conv3x3_relu_classifier(xn, wt, bias, wcls, 0.25)
+    refz = (F.relu(conv) * wcls.view(1, N, 1, 1)).sum(1) + 0.25
+    assert (z - refz).abs().max().item() < 2e-2 * refz.abs().max().item() + 1e-2
+
+
 @pytest.mark.parametrize("H,W,C,N", [(48, 48, 128, 384), (37, 29, 64, 192), (32, 32, 128, 128)])
 def test_conv3x3_fused_epilogues(ops, H, W, C, N):
     """Folded-affine first conv (border-exact tap table) and classifier-fused last conv on interior + border tiles."""
