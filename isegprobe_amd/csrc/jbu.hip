@@ -49,22 +49,23 @@ __device__ __forceinline__ int reflect(int i, int n) {  // F.pad(mode="reflect")
 }
 
 // --------------------------------------------------------------------------------------
-// F.adaptive_avg_pool2d on NCHW fp32 planes (window = [floor(i*in/out), ceil((i+1)*in/out)) ).
+// F.adaptive_avg_pool2d on NCHW fp32 planes (window = [floor(i*in/out), ceil((i+1)*in/out)) ).  One block per (plane,
+// output row): the row's vertical window is wave-uniform, a thread walks output columns ox, ox + blockDim, ... (neighbouring
+// threads read neighbouring input columns), no 64-bit index arithmetic per element (the first version spent most of
+// its 118 us per launch on four long divisions per output).
 __global__ __launch_bounds__(256) void adaptive_avg_pool_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                 int H, int W, int OH, int OW, long total) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int ox = (int)(idx % OW);
-    const long t = idx / OW;
-    const int oy = (int)(t % OH);
-    const long plane = t / OH;
-    const int y0 = (int)(((long)oy * H) / OH), y1 = (int)((((long)oy + 1) * H + OH - 1) / OH);
-    const int x0 = (int)(((long)ox * W) / OW), x1 = (int)((((long)ox + 1) * W + OW - 1) / OW);
-    const float* p = in + plane * (long)H * W;
-    float s = 0.f;
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) s += p[(size_t)y * W + x];
-    out[idx] = s / (float)((y1 - y0) * (x1 - x0));
+                                                                 int H, int W, int OH, int OW) {
+    const int oy = blockIdx.x, plane = blockIdx.y;
+    const int y0 = (oy * H) / OH, y1 = ((oy + 1) * H + OH - 1) / OH;
+    const float* p = in + (size_t)plane * H * W;
+    float* o = out + ((size_t)plane * OH + oy) * OW;
+    for (int ox = threadIdx.x; ox < OW; ox += blockDim.x) {
+        const int x0 = (ox * W) / OW, x1 = ((ox + 1) * W + OW - 1) / OW;
+        float s = 0.f;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) s += p[(size_t)y * W + x];
+        o[ox] = s / (float)((y1 - y0) * (x1 - x0));
+    }
 }
 
 // --------------------------------------------------------------------------------------
@@ -98,11 +99,12 @@ __global__ __launch_bounds__(256) void jbu_range_proj_f32_kernel(const float* __
     }
 }
 
-// range_proj: 1x1 (3 -> 32), GELU, 1x1 (32 -> 32); output NHWC f32.  Block = 256 pixels.  Layer 1 (96 FMAs + 32 GELUs) is
+// range_proj: 1x1 (3 -> 32), GELU, 1x1 (32 -> 32); output NHWC IEEE half (jbu_kernels stages it as half anyway: 64 instead
+// of 128 bytes per pixel written here and read there, with its halo, 2.1 times).  Block = 256 pixels.  Layer 1 (96 FMAs + 32 GELUs) is
 // computed by the pixel's own thread; layer 2 (1024 FMAs per pixel on the VALU in the first version: 0.55 ms at 512^2 x 32)
 // is one f16 MFMA pair per 16 pixels: hidden rows go through LDS as half [pixel][32] (80-byte pitch: the operand reads
 // of 16 consecutive pixels x one k-chunk touch every bank once), D[out][pixel] = W3 . H^T leaves as float4 per lane.
-__global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __restrict__ G, float* __restrict__ proj,
+__global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __restrict__ G, unsigned short* __restrict__ proj,
                                                               const float* __restrict__ w0, const float* __restrict__ b0,
                                                               const float* __restrict__ w3, const float* __restrict__ b3,
                                                               long HW, long total) {
@@ -144,8 +146,8 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
             const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ot], hb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             // D[out = 16 ot + 4 lq + j][pixel = px]
             if (gi < total)
-                *reinterpret_cast<float4*>(proj + gi * KEY + ot * 16 + lq * 4) =
-                    make_float4(d[0] + bias[ot].x, d[1] + bias[ot].y, d[2] + bias[ot].z, d[3] + bias[ot].w);
+                *reinterpret_cast<uint2*>(proj + gi * KEY + ot * 16 + lq * 4) =
+                    make_uint2(pack2h(d[0] + bias[ot].x, d[1] + bias[ot].y), pack2h(d[2] + bias[ot].z, d[3] + bias[ot].w));
         }
     }
 }
@@ -183,7 +185,8 @@ __device__ __forceinline__ int mlp_off(int row, int chunk) { return row * 128 + 
 // them (and on them only, see jbu_blend_kernel below) are blended from the staged records and stored instead
 // ([B, OH, OW, 9, 16]): the stage's own 256-byte records (2.1 GB at 512^2 x 32) never reach HBM.
 template <bool BLEND>
-__global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const float* __restrict__ proj, const float* __restrict__ G,
+__global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const void* __restrict__ proj_any, int proj_f16,
+                                                           const float* __restrict__ G,
                                                            bf16_t* __restrict__ kout, const bf16_t* __restrict__ f0w,
                                                            const float* __restrict__ f0b, const bf16_t* __restrict__ f3w,
                                                            const float* __restrict__ f3b, const float* __restrict__ bys,
@@ -206,10 +209,16 @@ __global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const float* __rest
         const int c8 = i % (KEY / 8), pix = i / (KEY / 8);
         const int py = pix / HALOX, px = pix % HALOX;
         const int gy = reflect(min(ty0 + py - R, GH - 1 + R), GH), gx = reflect(min(tx0 + px - R, GW - 1 + R), GW);
-        const float* src = proj + ((size_t)b * HW + (size_t)gy * GW + gx) * KEY + c8 * 8;
-        const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-        *reinterpret_cast<uint4*>(planes + c8 * PLANE + pix * 16) =
-            make_uint4(pack2h(v0.x, v0.y), pack2h(v0.z, v0.w), pack2h(v1.x, v1.y), pack2h(v1.z, v1.w));
+        const size_t at = ((size_t)b * HW + (size_t)gy * GW + gx) * KEY + c8 * 8;
+        uint4 h8;
+        if (proj_f16) {  // (block-uniform) the product route: jbu_range_proj already wrote halfs
+            h8 = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(proj_any) + at);
+        } else {
+            const float* src = static_cast<const float*>(proj_any) + at;
+            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+            h8 = make_uint4(pack2h(v0.x, v0.y), pack2h(v0.z, v0.w), pack2h(v1.x, v1.y), pack2h(v1.z, v1.w));
+        }
+        *reinterpret_cast<uint4*>(planes + c8 * PLANE + pix * 16) = h8;
     }
     // spatial Gaussian of the 49 taps (pixel-independent): computed once per block, read back as LDS broadcasts
     float* const s_gauss = reinterpret_cast<float*>(smem + KERNELS_LDS_MAIN + TAB_GAUSS);
@@ -799,26 +808,26 @@ extern "C" int isp_bf16_to_f16(const void* in_bf16, void* out_f16, long n, void*
 extern "C" int isp_adaptive_avg_pool_nchw_f32(const float* in, float* out, long planes, int H, int W, int OH, int OW,
                                               void* stream) {
     ISP_CHECK_ARG(in && out && planes > 0 && H > 0 && W > 0 && OH > 0 && OW > 0);
-    const long total = planes * OH * OW;
-    adaptive_avg_pool_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(in, out, H, W, OH, OW,
-                                                                                               total);
+    ISP_CHECK_ARG(planes <= 65535 && (long)H * OH < (1L << 31) && (long)W * OW < (1L << 31));
+    const unsigned threads = OW >= 256 ? 256u : (unsigned)((OW + 63) / 64 * 64);
+    adaptive_avg_pool_kernel<<<dim3((unsigned)OH, (unsigned)planes), threads, 0, (hipStream_t)stream>>>(in, out, H, W, OH, OW);
     return isp_launch_status();
 }
 
-extern "C" int isp_jbu_range_proj(const float* guidance, float* proj, const float* w0, const float* b0,
+extern "C" int isp_jbu_range_proj(const float* guidance, void* proj, const float* w0, const float* b0,
                                   const float* w3, const float* b3, int B, int GH, int GW, int exact_f32, void* stream) {
     ISP_CHECK_ARG(guidance && proj && w0 && b0 && w3 && b3 && B > 0 && GH > 0 && GW > 0);
     const long HW = (long)GH * GW, total = HW * B;
     if (exact_f32)
-        jbu_range_proj_f32_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(guidance, proj, w0, b0, w3,
-                                                                                                    b3, HW, total);
+        jbu_range_proj_f32_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(guidance, (float*)proj, w0,
+                                                                                                    b0, w3, b3, HW, total);
     else
-        jbu_range_proj_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(guidance, proj, w0, b0, w3,
-                                                                                                b3, HW, total);
+        jbu_range_proj_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(guidance, (unsigned short*)proj,
+                                                                                                w0, b0, w3, b3, HW, total);
     return isp_launch_status();
 }
 
-static int launch_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const void* fix0_w, const float* fix0_b,
+static int launch_jbu_kernels(const void* proj, int proj_f16, const float* guidance, void* kc_bf16, const void* fix0_w, const float* fix0_b,
                               const void* fix3_w, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
                               float sigma_spatial, int B, int GH, int GW, int OH, int OW, void* stream) {
     ISP_CHECK_ARG(proj && guidance && kc_bf16 && fix0_w && fix0_b && fix3_w && fix3_b && bys && bxs);
@@ -839,32 +848,32 @@ static int launch_jbu_kernels(const float* proj, const float* guidance, void* kc
     dim3 grid((GW + TSX - 1) / TSX, (GH + TSY - 1) / TSY, B);
     if (OH > 0) {
         const float rsy = (float)(GH - 1) / (float)(OH - 1), rsx = (float)(GW - 1) / (float)(OW - 1);
-        jbu_kernels_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
+        jbu_kernels_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(proj, proj_f16, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
                                                                           fix0_b, (const bf16_t*)fix3_w, fix3_b, bys, bxs, temp,
                                                                           inv2s2, GH, GW, OH, OW, rsy, rsx);
     } else {
-        jbu_kernels_kernel<false><<<grid, 256, lds, (hipStream_t)stream>>>(proj, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
+        jbu_kernels_kernel<false><<<grid, 256, lds, (hipStream_t)stream>>>(proj, proj_f16, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
                                                                            fix0_b, (const bf16_t*)fix3_w, fix3_b, bys, bxs, temp,
                                                                            inv2s2, GH, GW, 0, 0, 0.f, 0.f);
     }
     return isp_launch_status();
 }
 
-extern "C" int isp_jbu_kernels(const float* proj, const float* guidance, void* kc_bf16, const void* fix0_w,
+extern "C" int isp_jbu_kernels(const void* proj, int proj_f16, const float* guidance, void* kc_bf16, const void* fix0_w,
                                const float* fix0_b, const void* fix3_w, const float* fix3_b, const float* bys,
                                const float* bxs, float range_temp, float sigma_spatial, int B, int GH, int GW,
                                void* stream) {
-    return launch_jbu_kernels(proj, guidance, kc_bf16, fix0_w, fix0_b, fix3_w, fix3_b, bys, bxs, range_temp, sigma_spatial, B,
+    return launch_jbu_kernels(proj, proj_f16, guidance, kc_bf16, fix0_w, fix0_b, fix3_w, fix3_b, bys, bxs, range_temp, sigma_spatial, B,
                               GH, GW, 0, 0, stream);
 }
 
-extern "C" int isp_jbu_kernels_resized(const float* proj, const float* guidance, void* kc9_bf16, const void* fix0_w,
+extern "C" int isp_jbu_kernels_resized(const void* proj, int proj_f16, const float* guidance, void* kc9_bf16, const void* fix0_w,
                                        const float* fix0_b, const void* fix3_w, const float* fix3_b, const float* bys,
                                        const float* bxs, float range_temp, float sigma_spatial, int B, int GH, int GW, int OH,
                                        int OW, void* stream) {
     ISP_CHECK_ARG(GH >= 8 && GW >= 8 && OH > 1 && OW > 1 && GH % 8 == 0 && GW % 8 == 0);
     ISP_CHECK_ARG((long)OH * 8 == (long)GH * 7 && (long)OW * 8 == (long)GW * 7);
-    return launch_jbu_kernels(proj, guidance, kc9_bf16, fix0_w, fix0_b, fix3_w, fix3_b, bys, bxs, range_temp, sigma_spatial, B,
+    return launch_jbu_kernels(proj, proj_f16, guidance, kc9_bf16, fix0_w, fix0_b, fix3_w, fix3_b, bys, bxs, range_temp, sigma_spatial, B,
                               GH, GW, OH, OW, stream);
 }
 

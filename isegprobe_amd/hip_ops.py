@@ -529,11 +529,11 @@ def adaptive_avg_pool(x, OH, OW):
 
 
 def jbu_range_proj(g, w0, b0, w3, b3, exact=False):
-    """g [B,3,GH,GW] f32 -> proj [B,GH,GW,32] f32.  ``exact``: both layers in fp32 with the erf GELU (the fp32 checking
-    mode); default: second layer on f16 MFMA."""
+    """g [B,3,GH,GW] f32 -> proj [B,GH,GW,32].  ``exact``: both layers in fp32 with the erf GELU, f32 output (the fp32
+    checking mode); default: second layer on f16 MFMA, IEEE-half output (what jbu_kernels stages anyway)."""
     _need(g, torch.float32, "guidance")
     B, _, GH, GW = g.shape
-    proj = torch.empty(B, GH, GW, 32, device=g.device, dtype=torch.float32)
+    proj = torch.empty(B, GH, GW, 32, device=g.device, dtype=torch.float32 if exact else F16)
     check(_lib.lib().isp_jbu_range_proj(_p(g), _p(proj), _p(w0), _p(b0), _p(w3), _p(b3), B, GH, GW, int(bool(exact)), _stream()),
           "isp_jbu_range_proj")
     return proj
@@ -584,6 +584,12 @@ def to_f16(x):
     return out
 
 
+def _proj_is_half(proj):
+    if proj.dtype not in (torch.float32, F16) or not proj.is_contiguous() or proj.shape[-1] != 32:
+        raise IspError("proj must be a contiguous [B,GH,GW,32] f32 or f16 tensor")
+    return int(proj.dtype == F16)
+
+
 def jbu_kernels(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial):
     """-> composite kernels kc [B,GH,GW,8,16] f16 (see include/isegprobe_hip.h); f0w / f3w: f16 [64,64]."""
     _need(f0w, F16, "f0w")
@@ -592,7 +598,7 @@ def jbu_kernels(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial):
     bys = jbu_tables(GH, proj.device)[0]
     bxs = jbu_tables(GW, proj.device)[1]
     kc = torch.empty(B, GH, GW, 8, 16, device=proj.device, dtype=F16)
-    check(_lib.lib().isp_jbu_kernels(_p(proj), _p(g), _p(kc), _p(f0w), _p(f0b), _p(f3w), _p(f3b), _p(bys), _p(bxs),
+    check(_lib.lib().isp_jbu_kernels(_p(proj), _proj_is_half(proj), _p(g), _p(kc), _p(f0w), _p(f0b), _p(f3w), _p(f3b), _p(bys), _p(bxs),
                                      float(range_temp), float(sigma_spatial), B, GH, GW, _stream()), "isp_jbu_kernels")
     return kc
 
@@ -605,7 +611,7 @@ def jbu_kernels_resized(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial, 
     bys = jbu_tables(GH, proj.device)[0]
     bxs = jbu_tables(GW, proj.device)[1]
     kc9 = torch.empty(B, OH, OW, 9, 16, device=proj.device, dtype=F16)
-    check(_lib.lib().isp_jbu_kernels_resized(_p(proj), _p(g), _p(kc9), _p(f0w), _p(f0b), _p(f3w), _p(f3b), _p(bys), _p(bxs),
+    check(_lib.lib().isp_jbu_kernels_resized(_p(proj), _proj_is_half(proj), _p(g), _p(kc9), _p(f0w), _p(f0b), _p(f3w), _p(f3b), _p(bys), _p(bxs),
                                              float(range_temp), float(sigma_spatial), B, GH, GW, OH, OW, _stream()),
           "isp_jbu_kernels_resized")
     return kc9
