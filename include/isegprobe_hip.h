@@ -103,6 +103,12 @@ int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, int N, int K,
  * loftup/loftup.py:53-63 and LiFT.py:12-27. */
 int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int H, int W, int C, int N, const isp_epilogue* ep,
                           void* stream);
+/* The same with IEEE-half operands and 16-bit outputs (epilogue kinds ISP_EP_BIAS_BF16, ISP_EP_BIAS_RELU_BF16,
+ * ISP_EP_BIAS_TAPS_RELU_BF16 then write half; ISP_EP_RELU_DOT_PARTIAL_F32 as before): ConvSegHead's convolutions
+ * (heads/conv_heads.py:51-73) behind the FeatUp-JBU stack, whose maps are half.  N % 192 == 0, ldo % 8 == 0, 16-byte
+ * aligned output; anything else returns ISP_ERR_UNSUPPORTED (callers convert to bf16 and use the entry above). */
+int isp_conv3x3_nhwc_f16(const void* in, const void* Wt, int B, int H, int W, int C, int N, const isp_epilogue* ep,
+                         void* stream);
 
 int isp_conv3x3_partial_slots(int N);
 int isp_sum_partials_f32(const float* partial, float* out, long M, int slots, float bias, void* stream);

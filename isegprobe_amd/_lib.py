@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "libisegprobe_hip.so")  # env override: kernel A/B experiments
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 ISP_F32, ISP_BF16 = 0, 1
 EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16, EP_BIAS_QGELU_SAVE_BF16, EP_MUL_DQGELU_BF16 = range(14)
@@ -49,6 +49,7 @@ SIGNATURES = {
     "isp_patchify_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "isp_gemm_bf16": [_vp, _l, _vp, _l, _i, _i, _EP, _vp],
     "isp_conv3x3_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _EP, _vp],
+    "isp_conv3x3_nhwc_f16": [_vp, _vp, _i, _i, _i, _i, _i, _EP, _vp],
     "isp_conv3x3_partial_slots": [_i],
     "isp_sum_partials_f32": [_vp, _vp, _l, _i, _f, _vp],
     "isp_layernorm_fwd": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _l, _l, _vp],

@@ -21,20 +21,28 @@ class ConvModule(nn.Module):
         self.activate = nn.ReLU(inplace=True)
         self._packed = PackedCache()
 
-    def packed(self):
+    def packed(self, dtype=BF16):
+        """Kernel-layout weights in ``dtype``: bf16, or IEEE half for the f16 form of the 3x3 conv (``takes_f16``)."""
         def build():
             w = self.conv.weight.detach()
             n = w.shape[0]
             # [N, C, kh, kw] -> [N, kh*kw*C] (tap-major, channel-minor: the implicit-GEMM K order)
-            return (w.permute(0, 2, 3, 1).reshape(n, -1).to(BF16).contiguous(),
+            return (w.permute(0, 2, 3, 1).reshape(n, -1).to(dtype).contiguous(),
                     self.conv.bias.detach().float().contiguous())
-        return self._packed.get((self.conv.weight, self.conv.bias), build)
+        cache = self._packed if dtype == BF16 else self.__dict__.setdefault("_packed_f16", PackedCache())
+        return cache.get((self.conv.weight, self.conv.bias), build)
+
+    def takes_f16(self):
+        """The f16 conv kernel exists for 3x3 layers whose output channels tile into 192-channel blocks."""
+        return self.conv.kernel_size == (3, 3) and self.conv.out_channels % 192 == 0 and self.conv.in_channels % 64 == 0
 
     def run(self, x_nhwc):
         if grad_mode(self.conv) or (torch.is_grad_enabled() and x_nhwc.requires_grad):
             fn = Conv3x3ReluFn if self.conv.kernel_size == (3, 3) else Conv1x1ReluFn
             return fn.apply(x_nhwc, self.conv.weight, self.conv.bias)
-        w, b = self.packed()
+        if x_nhwc.dtype == ops.F16 and not self.takes_f16():
+            x_nhwc = x_nhwc.to(BF16)
+        w, b = self.packed(x_nhwc.dtype)
         if self.conv.kernel_size == (3, 3):
             return ops.conv3x3(x_nhwc, w, b, "relu")
         B, H, W, C = x_nhwc.shape
@@ -72,10 +80,14 @@ class _StackedHead(BaseClassifierHead):
                 and (y.numel() // y.shape[-1]) % 4 == 0):
             for layer in layers[:-1]:
                 y = layer.run(y)
-            w, b = layers[-1].packed()
+            if y.dtype == ops.F16 and not layers[-1].takes_f16():
+                y = y.to(BF16)
+            w, b = layers[-1].packed(y.dtype)
             wc, bc = self._cls_weights()
             B, H, W, _ = y.shape
             return ops.conv3x3_relu_classifier(y, w, b, wc, bc).view(B, 1, H, W)
+        if y.dtype == ops.F16:  # (the remaining routes are bf16)
+            y = y.to(BF16)
         if training and layers and layers[-1].conv.kernel_size == (3, 3) and self.num_classes == 1:
             for layer in layers[:-1]:
                 y = layer.run(y)
@@ -101,12 +113,16 @@ class _StackedHead(BaseClassifierHead):
             folded = wt + alpha * torch.matmul(wt, Wf.float())           # W1_t (I + a Wf)
             taps = alpha * torch.matmul(wt, bf.float())                  # [N, 9]
             bias_full = first.conv.bias.detach().float() + taps.sum(1)
-            return (folded.reshape(n, 9 * c).to(BF16).contiguous(), bias_full.contiguous(),
+            return (folded.reshape(n, 9 * c).to(dtype).contiguous(), bias_full.contiguous(),
                     taps.t().contiguous())
-        if not hasattr(self, "_fold_packed"):
-            self._fold_packed = PackedCache()
-        wfold, bias_full, taps = self._fold_packed.get((first.conv.weight, first.conv.bias, Wf, bf), build)
-        y = ops.conv3x3_folded_affine(to_nhwc_bf16(x), wfold, bias_full, taps)
+        # an IEEE-half map (the FeatUp-JBU stack's own precision) keeps that precision through the head when the f16
+        # conv exists for this layer; anything else is bf16
+        x = x.permute(0, 2, 3, 1).contiguous() if x.dtype == ops.F16 and first.takes_f16() else to_nhwc_bf16(x)
+        dtype = x.dtype
+        caches = self.__dict__.setdefault("_fold_packed", {})
+        cache = caches.setdefault(dtype, PackedCache())
+        wfold, bias_full, taps = cache.get((first.conv.weight, first.conv.bias, Wf, bf), build)
+        y = ops.conv3x3_folded_affine(x, wfold, bias_full, taps)
         return self._tail(y, list(self.convs)[1:])
 
 

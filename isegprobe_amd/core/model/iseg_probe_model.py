@@ -12,7 +12,7 @@ from ... import hip_ops as ops
 from ..utils.log import logger
 from ..utils.model_builder import ModelBuilder
 from ..utils.serialization import serialize
-from ._tensor import nchw_view, to_nhwc_bf16
+from ._tensor import BF16, nchw_view, to_nhwc_bf16
 from .featurizers import DINOv2Featurizer
 from .featurizers.utils import PatchEmbed
 from .heads import ConvSegHead
@@ -31,6 +31,7 @@ class iSegProbeModel(iSegBaseModel):
         super().__init__(**kwargs)
         self.save_cfg = save_cfg
         self.fold_upsampler_affine = True  # cross-plugin weight folding (JBU fix-up -> head conv1); exact algebra
+        self.head_f16 = os.environ.get("ISEGPROBE_HEAD_F16", "1") != "0"  # f16 head convs behind the JBU stack
         self.architecture = architecture
         assert backbone_cfg is not None and head_cfg is not None and embed_coords_cfg is not None, \
             "backbone, head and embed_coords configurations must be provided"
@@ -121,7 +122,16 @@ class iSegProbeModel(iSegBaseModel):
                 if jbu_records is not None:
                     records, side = jbu_records
                     torch.cuda.current_stream().wait_stream(side)
-                hr = self.upsampler.upsampler.forward_stages(backbone_features, image, out_size=image.shape[2:], records=records)
+                # the stack's maps are IEEE half; the head takes them as they are when its f16 convolutions apply and
+                # the resize is fused into the last stage (the stand-alone resize kernel is bf16): three more mantissa
+                # bits on the head's input, weights and hidden map -- the largest share of the bf16 path's logit error
+                stack = self.upsampler.upsampler
+                p = self.backbone.patch_size
+                half = (self.head_f16 and self.head.convs[0].takes_f16()
+                        and stack.up4.resize_fusable((image.shape[2] // p) << 4, (image.shape[3] // p) << 4,
+                                                     image.shape[2], image.shape[3]))
+                hr = stack.forward_stages(backbone_features, image, out_size=image.shape[2:], records=records,
+                                          out_dtype=ops.F16 if half else BF16)
                 if image.size()[2:] != hr.size()[2:]:
                     hr = nchw_view(ops.resize_nhwc(to_nhwc_bf16(hr), image.shape[2], image.shape[3], "bilinear"))
                 Wf, bf, alpha = self.upsampler.upsampler.fixup_affine()

@@ -91,11 +91,11 @@ class JBULearnedRange(nn.Module):
             return ops.jbu_kernels_resized(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"], OH, OW)
         return self._gcache.get(guidance, id(P), (GH, GW, OH, OW), build)
 
-    def run_resized(self, source_nhwc, guidance, OH, OW, kc9=None):
+    def run_resized(self, source_nhwc, guidance, OH, OW, kc9=None, out_dtype=BF16):
         """resize_bilinear(run(source), OH, OW) as one operator (isp_jbu_apply_resized on the blended records)."""
         if kc9 is None:
             kc9 = self.kernels_resized(guidance, source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2, OH, OW)
-        return ops.jbu_apply_resized(source_nhwc, kc9)
+        return ops.jbu_apply_resized(source_nhwc, kc9, out_dtype=out_dtype)
 
 
 class JBUStack(nn.Module):
@@ -108,19 +108,21 @@ class JBUStack(nn.Module):
         self.fixup_proj = nn.Sequential(nn.Dropout2d(0.2), nn.Conv2d(feat_dim, feat_dim, kernel_size=1))
         self._packed = PackedCache()
 
-    def forward_stages(self, source, guidance, out_size=None, records=None):
+    def forward_stages(self, source, guidance, out_size=None, records=None, out_dtype=BF16):
         """The four x2 stages WITHOUT the final fix-up  x + 0.1*conv1x1(x).  The fix-up is a per-pixel
         affine map; iSegProbeModel folds it (through the linear resize) into the seg head's first conv.
         With ``out_size`` the model's bilinear resize to the image size (iseg_probe_model.py:120-129) is fused into the
-        last stage when the sizes allow it (otherwise the caller resizes as before)."""
+        last stage when the sizes allow it (otherwise the caller resizes as before).  ``out_dtype``: bf16, or IEEE half for
+        a consumer that takes the stack's own precision (the seg head's f16 convolutions)."""
         x = to_nhwc_bf16(source)
         if records is None:
             records = self.stage_records(guidance, x.shape[1], x.shape[2], out_size)
         for up, kc in zip((self.up1, self.up2, self.up3), records[:3]):
             x = up.run(x, None, kc)
         if records[3].shape[3] == 9:  # records of the resized grid
-            return nchw_view(self.up4.run_resized(x, None, records[3].shape[1], records[3].shape[2], records[3]))
-        return nchw_view(self.up4.run(x, None, records[3], out_dtype=BF16))
+            return nchw_view(self.up4.run_resized(x, None, records[3].shape[1], records[3].shape[2], records[3],
+                                                  out_dtype=out_dtype))
+        return nchw_view(self.up4.run(x, None, records[3], out_dtype=out_dtype))
 
     def stage_records(self, guidance, h, w, out_size=None):
         """The kernel records of the four stages for an h x w source: functions of the guidance only, so they can be

@@ -170,7 +170,7 @@ __device__ __forceinline__ ColsBias load_bias(const float* bias, int n) {  // bi
     return ColsBias{bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0)};
 }
 
-template <int ACT>
+template <int ACT, bool F16 = false>  // F16: the 16-bit output is IEEE half (isp_conv3x3_nhwc_f16) instead of bf16
 struct EpBiasActBf16 {  // out[m][n] = bf16(act(v + bias[n]))
     bf16_t* out;
     const float* bias;  // may be null
@@ -186,7 +186,7 @@ struct EpBiasActBf16 {  // out[m][n] = bf16(act(v + bias[n]))
             if (ACT == ACT_GELU) r[j] = gelu_erf(r[j]);
             if (ACT == ACT_QGELU) r[j] = r[j] / (1.0f + __expf(-1.702f * r[j]));
         }
-        return make_uint2(pack2bf(r[0], r[1]), pack2bf(r[2], r[3]));
+        return make_uint2(pack2o<!F16>(r[0], r[1]), pack2o<!F16>(r[2], r[3]));
     }
     __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c) const {
         *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = pack(m, n, v, c);
@@ -309,6 +309,7 @@ struct EpAxpyResBf16 {  // out = res + alpha * (v + bias), bf16 in/out (FeatUp J
 // Used when a per-pixel affine map z = (I + aW)x + a*b in front of a zero-padded 3x3 conv is folded
 // into the conv weights: the constant part a*b only contributes through taps inside the image.
 // `bias` already holds b_conv + sum_t taps[t]; border pixels subtract their missing taps.
+template <bool F16 = false>
 struct EpBiasTapsReluBf16 {
     bf16_t* out;
     const float* bias;
@@ -339,8 +340,8 @@ struct EpBiasTapsReluBf16 {
                 }
             }
         }
-        return make_uint2(pack2bf(fmaxf(v[0] + b.x, 0.f), fmaxf(v[1] + b.y, 0.f)),
-                          pack2bf(fmaxf(v[2] + b.z, 0.f), fmaxf(v[3] + b.w, 0.f)));
+        return make_uint2(pack2o<!F16>(fmaxf(v[0] + b.x, 0.f), fmaxf(v[1] + b.y, 0.f)),
+                          pack2o<!F16>(fmaxf(v[2] + b.z, 0.f), fmaxf(v[3] + b.w, 0.f)));
     }
     __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c, unsigned outside) const {
         *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = pack(m, n, v, c, outside);
@@ -886,7 +887,7 @@ int launch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int C
 // chunks are XOR-swizzled by the pixel's COLUMN in the patch ((px >> 1) & 7): a fragment read's address is then
 // lane constant(dx, k-half) + immediate((t + dy + 1) * row pitch) -- no per-read address arithmetic.
 //   LDS = 2 x 42 KiB patch + 3 x 24 KiB weights = 156 KiB.
-template <class EP, int TN>
+template <class EP, int TN, bool F16 = false>  // F16: operands are IEEE half (same MFMA rate, 3 more mantissa bits)
 __device__ __forceinline__ void conv3x3_patch4_body(const bf16_t* __restrict__ in, const bf16_t* __restrict__ Wt, int H,
                                                     int W, int C, int N, int tiles_x, int tiles_y, int tiles_n, int nwg,
                                                     const EP& ep) {
@@ -992,7 +993,11 @@ __device__ __forceinline__ void conv3x3_patch4_body(const bf16_t* __restrict__ i
         for (int mi = m_lo; mi < m_hi; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+                if constexpr (F16)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fw[ni]),
+                                                                        __builtin_bit_cast(f16x8_t, fa[mi]), acc[mi][ni], 0, 0, 0);
+                else
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][ni], 0, 0, 0);
     };
 
     // --- prologue: patch of channel block 0, weight tiles of steps 0 and 1
@@ -1105,12 +1110,12 @@ __device__ __forceinline__ void conv3x3_patch4_body(const bf16_t* __restrict__ i
 
 // (thin kernels: with the body above written directly as a __global__ template that depends on TN, hipcc 7.2
 // silently leaves the kernel's host-side handle undefined)
-template <class EP>
+template <class EP, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel_192(const bf16_t* __restrict__ in,
                                                                     const bf16_t* __restrict__ Wt, int H, int W, int C,
                                                                     int N, int tiles_x, int tiles_y, int tiles_n,
                                                                     int nwg, EP ep) {
-    conv3x3_patch4_body<EP, 6>(in, Wt, H, W, C, N, tiles_x, tiles_y, tiles_n, nwg, ep);
+    conv3x3_patch4_body<EP, 6, F16>(in, Wt, H, W, C, N, tiles_x, tiles_y, tiles_n, nwg, ep);
 }
 template <class EP>
 __global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel_128(const bf16_t* __restrict__ in,
@@ -1120,7 +1125,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel_128(const bf16_t
     conv3x3_patch4_body<EP, 4>(in, Wt, H, W, C, N, tiles_x, tiles_y, tiles_n, nwg, ep);
 }
 
-template <int TN, class EP>
+template <int TN, class EP, bool F16 = false>
 int launch_conv_patch4(const void* in, const void* Wt, int B, int H, int W, int C, int N, EP ep, hipStream_t s) {
     constexpr int PBN = 2 * TN * 16, P_LDS = 2 * P_BYTES + 3 * PBN * BK * 2;
     const int tiles_x = (W + PT - 1) / PT, tiles_y = (H + PT - 1) / PT, tiles_n = (N + PBN - 1) / PBN;
@@ -1130,7 +1135,8 @@ int launch_conv_patch4(const void* in, const void* Wt, int B, int H, int W, int 
     static bool attr_done = false;
     static_assert(TN == 6 || TN == 4);
     void (*kern)(const bf16_t*, const bf16_t*, int, int, int, int, int, int, int, int, EP);
-    if constexpr (TN == 6) kern = conv3x3_patch4_kernel_192<EP>;
+    static_assert(!F16 || TN == 6, "the f16 form exists for 192-channel blocks only");
+    if constexpr (TN == 6) kern = conv3x3_patch4_kernel_192<EP, F16>;
     else kern = conv3x3_patch4_kernel_128<EP>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess)
@@ -1177,7 +1183,7 @@ int dispatch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int
                 case ISP_EP_BIAS_TAPS_RELU_BF16:
                     if (!e->bias || !e->pos || e->img_h <= 0 || e->img_w <= 0 || ldo != N) return ISP_ERR_INVALID;
                     return launch_conv_patch4<TN>(in, Wt, B, H, W, C, N,
-                                              EpBiasTapsReluBf16{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
+                                              EpBiasTapsReluBf16<>{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
                 case ISP_EP_RELU_DOT_PARTIAL_F32:
                     if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
                     return launch_conv_patch4<TN>(in, Wt, B, H, W, C, N, EpReluDotPartial{(float*)e->out, e->bias, e->gamma, M}, s);
@@ -1193,7 +1199,7 @@ int dispatch_conv_patch(const void* in, const void* Wt, int B, int H, int W, int
         case ISP_EP_BIAS_TAPS_RELU_BF16:
             if (!e->bias || !e->pos || e->img_h <= 0 || e->img_w <= 0 || ldo != N) return ISP_ERR_INVALID;
             return launch_conv_patch<TN>(in, Wt, B, H, W, C, N,
-                                     EpBiasTapsReluBf16{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
+                                     EpBiasTapsReluBf16<>{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
         case ISP_EP_RELU_DOT_PARTIAL_F32:
             if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
             return launch_conv_patch<TN>(in, Wt, B, H, W, C, N, EpReluDotPartial{(float*)e->out, e->bias, e->gamma, M}, s);
@@ -1244,7 +1250,7 @@ int dispatch_epilogue(AL al, const void* Wt, long M, int N, int K, const isp_epi
             if constexpr (!((KINDS >> ISP_EP_BIAS_TAPS_RELU_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
             if (!e->bias || !e->pos || e->img_h <= 0 || e->img_w <= 0 || ldo != N) return ISP_ERR_INVALID;
             return launch_gemm<CFG>(al, Wt, M, N, K,
-                               EpBiasTapsReluBf16{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
+                               EpBiasTapsReluBf16<>{(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
             }
         case ISP_EP_BIAS_QGELU_BF16:
             if constexpr (!((KINDS >> ISP_EP_BIAS_QGELU_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
@@ -1323,6 +1329,35 @@ extern "C" int isp_conv3x3_partial_slots(int N) {
     if (patch128_ok(N) && !ep_forces_tile_engine()) return (N + 127) / 128 * 2;  // patch kernel, 128-channel blocks
     if (N > 64) return ((N + CfgConv128::BN - 1) / CfgConv128::BN) * CfgConv128::WN;
     return ((N + Cfg128::BN - 1) / Cfg128::BN) * Cfg128::WN;
+}
+
+// IEEE-half operands (in, Wt) and 16-bit outputs: the head's convolutions behind the FeatUp-JBU stack, whose maps are
+// half already -- three more mantissa bits than bf16 on the head's inputs, weights and hidden map (the largest
+// contribution to the bf16 path's logit error, tools/diag_precision_full.py) at the same MFMA rate.  192-channel-block
+// patch kernel only: N % 192 == 0, C % 64 == 0, 16-byte aligned output with ldo % 8 == 0.
+extern "C" int isp_conv3x3_nhwc_f16(const void* in, const void* Wt, int B, int H, int W, int C, int N, const isp_epilogue* e,
+                                    void* stream) {
+    ISP_CHECK_ARG(in && Wt && e && e->out && B > 0 && H > 0 && W > 0 && C > 0 && C % BK == 0 && N > 0);
+    const long M = (long)B * H * W;
+    ISP_CHECK_ARG(M <= 0x7fffffffL);
+    const long ldo = e->ldo > 0 ? e->ldo : N;
+    if (N % 192 != 0 || ldo % 8 != 0 || (reinterpret_cast<size_t>(e->out) & 15) != 0) return ISP_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    switch (e->kind) {
+        case ISP_EP_BIAS_BF16:
+            return launch_conv_patch4<6, EpBiasActBf16<ACT_NONE, true>, true>(in, Wt, B, H, W, C, N, {(bf16_t*)e->out, e->bias, ldo}, s);
+        case ISP_EP_BIAS_RELU_BF16:
+            return launch_conv_patch4<6, EpBiasActBf16<ACT_RELU, true>, true>(in, Wt, B, H, W, C, N, {(bf16_t*)e->out, e->bias, ldo}, s);
+        case ISP_EP_BIAS_TAPS_RELU_BF16:
+            if (!e->bias || !e->pos || e->img_h <= 0 || e->img_w <= 0 || ldo != N) return ISP_ERR_INVALID;
+            return launch_conv_patch4<6, EpBiasTapsReluBf16<true>, true>(in, Wt, B, H, W, C, N,
+                                                                         {(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
+        case ISP_EP_RELU_DOT_PARTIAL_F32:
+            if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
+            return launch_conv_patch4<6, EpReluDotPartial, true>(in, Wt, B, H, W, C, N, {(float*)e->out, e->bias, e->gamma, M}, s);
+        default:
+            return ISP_ERR_UNSUPPORTED;
+    }
 }
 
 extern "C" int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int H, int W, int C, int N,

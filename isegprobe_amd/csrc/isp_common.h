@@ -36,6 +36,22 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
 
+// ---- IEEE half helpers (FeatUp-JBU stack, f16 form of the head's convolutions)
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2h(float lo, float hi) {  // round-to-nearest-even
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v_t{lo, hi}, f16x2_t));
+}
+__device__ __forceinline__ float h_lo(unsigned q) { return (float)__builtin_bit_cast(f16x2_t, q).x; }
+__device__ __forceinline__ float h_hi(unsigned q) { return (float)__builtin_bit_cast(f16x2_t, q).y; }
+template <bool OUT_BF16>
+__device__ __forceinline__ unsigned pack2o(float lo, float hi) {
+    if constexpr (OUT_BF16) return pack2bf(lo, hi);
+    else return pack2h(lo, hi);
+}
+
 // 16-byte async global -> LDS copy.  LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const ISP_GLOBAL void*)gsrc, (ISP_LDS void*)lds_wave_base, 16, 0, 0);

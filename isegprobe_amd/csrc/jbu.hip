@@ -25,21 +25,7 @@ namespace {
 // values here are bounded -- kernel weights sum to 1 per pixel, features are convex-ish combinations of LayerNorm-ed
 // tokens -- so half's range is ample; the MFMA rate of the f16 forms is that of the bf16 ones.  The stack's input is
 // converted bf16 -> f16 (exact) and its last stage writes bf16 for the head's convolution.
-typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2v_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pack2h(float lo, float hi) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v_t{lo, hi}, f16x2_t));
-}
-__device__ __forceinline__ float h_lo(unsigned q) { return (float)__builtin_bit_cast(f16x2_t, q).x; }
-__device__ __forceinline__ float h_hi(unsigned q) { return (float)__builtin_bit_cast(f16x2_t, q).y; }
-template <bool OUT_BF16>
-__device__ __forceinline__ unsigned pack2o(float lo, float hi) {
-    if constexpr (OUT_BF16) return pack2bf(lo, hi);
-    else return pack2h(lo, hi);
-}
-
+// (pack2h / h_lo / h_hi / pack2o: isp_common.h)
 
 constexpr int R = 3, DIA = 7, TAPS = 49, KEY = 32;
 

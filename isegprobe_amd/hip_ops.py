@@ -176,47 +176,58 @@ def vit_mlp_fused_supported(D, hid):
     return (D, hid) == (384, 1536)
 
 
-def conv3x3(x, Wt, bias=None, act="relu", out_dtype=BF16):
-    """x [B,H,W,C] bf16 NHWC, Wt [N, 9*C] bf16 (ky,kx,c order) -> [B,H,W,N]."""
+def _conv_entry(x, Wt):
+    """The conv entry point for an operand pair: both bf16, or both IEEE half (the head behind FeatUp JBU)."""
+    if x.dtype == F16:
+        _need(x, F16, "x")
+        _need(Wt, F16, "Wt")
+        if Wt.shape[0] % 192:
+            raise IspError("the f16 conv handles N % 192 == 0 only (convert to bf16 otherwise)")
+        return _lib.lib().isp_conv3x3_nhwc_f16, "isp_conv3x3_nhwc_f16"
     _need(x, BF16, "x")
     _need(Wt, BF16, "Wt")
+    return _lib.lib().isp_conv3x3_nhwc_bf16, "isp_conv3x3_nhwc_bf16"
+
+
+def conv3x3(x, Wt, bias=None, act="relu", out_dtype=None):
+    """x [B,H,W,C] bf16 (or f16) NHWC, Wt [N, 9*C] same dtype (ky,kx,c order) -> [B,H,W,N] (dtype of x, or f32)."""
+    fn, name = _conv_entry(x, Wt)
+    out_dtype = x.dtype if out_dtype is None else out_dtype
     B, H, W, C = x.shape
     N = Wt.shape[0]
     if Wt.shape[1] != 9 * C:
         raise IspError("conv3x3 weight must be [N, 9*C]")
     out = torch.empty(B, H, W, N, device=x.device, dtype=out_dtype)
-    if out_dtype == BF16:
+    if out_dtype == x.dtype:
         kind = {None: _lib.EP_BIAS_BF16, "relu": _lib.EP_BIAS_RELU_BF16, "gelu": _lib.EP_BIAS_GELU_BF16}[act]
-    else:
+    elif out_dtype == torch.float32 and x.dtype == BF16:
         kind = _lib.EP_BIAS_F32
+    else:
+        raise IspError("conv3x3: output must have the operands' dtype (or f32 for bf16 operands)")
     ep = _epilogue(kind, out, N, bias)
-    check(_lib.lib().isp_conv3x3_nhwc_bf16(_p(x), _p(Wt), B, H, W, C, N, ctypes.byref(ep), _stream()),
-          "isp_conv3x3_nhwc_bf16")
+    check(fn(_p(x), _p(Wt), B, H, W, C, N, ctypes.byref(ep), _stream()), name)
     return out
 
 
 def conv3x3_folded_affine(x, Wt, bias_full, taps):
     """conv3x3 + ReLU whose input carries a folded per-pixel affine map: `bias_full` = conv bias +
     sum of the 9 tap constants `taps` [9,N]; border pixels drop the taps outside the image."""
-    _need(x, BF16, "x")
-    _need(Wt, BF16, "Wt")
+    fn, name = _conv_entry(x, Wt)
     _need(bias_full, torch.float32, "bias_full")
     _need(taps, torch.float32, "taps")
     B, H, W, C = x.shape
     N = Wt.shape[0]
-    out = torch.empty(B, H, W, N, device=x.device, dtype=BF16)
+    out = torch.empty(B, H, W, N, device=x.device, dtype=x.dtype)
     ep = _epilogue(_lib.EP_BIAS_TAPS_RELU_BF16, out, N, bias_full, pos=taps)
     ep.img_h, ep.img_w = H, W
-    check(_lib.lib().isp_conv3x3_nhwc_bf16(_p(x), _p(Wt), B, H, W, C, N, ctypes.byref(ep), _stream()),
-          "isp_conv3x3_nhwc_bf16")
+    check(fn(_p(x), _p(Wt), B, H, W, C, N, ctypes.byref(ep), _stream()), name)
     return out
 
 
 def conv3x3_relu_classifier(x, Wt, bias, wcls, bcls):
     """relu(conv3x3(x) + bias) . wcls + bcls without storing the conv output: x [B,H,W,C] bf16 ->
     logits [B,H,W] f32 (second head conv + BaseClassifierHead.classifier fused)."""
-    _need(x, BF16, "x")
-    _need(Wt, BF16, "Wt")
+    fn, name = _conv_entry(x, Wt)
     _need(bias, torch.float32, "bias")
     _need(wcls, torch.float32, "wcls")
     B, H, W, C = x.shape
@@ -225,8 +236,7 @@ def conv3x3_relu_classifier(x, Wt, bias, wcls, bcls):
     slots = _lib.lib().isp_conv3x3_partial_slots(N)
     partial = torch.empty(slots, M, device=x.device, dtype=torch.float32)
     ep = _epilogue(_lib.EP_RELU_DOT_PARTIAL_F32, partial, N, bias, gamma=wcls)
-    check(_lib.lib().isp_conv3x3_nhwc_bf16(_p(x), _p(Wt), B, H, W, C, N, ctypes.byref(ep), _stream()),
-          "isp_conv3x3_nhwc_bf16")
+    check(fn(_p(x), _p(Wt), B, H, W, C, N, ctypes.byref(ep), _stream()), name)
     out = torch.empty(B, H, W, device=x.device, dtype=torch.float32)
     check(_lib.lib().isp_sum_partials_f32(_p(partial), _p(out), M, slots, float(bcls), _stream()), "isp_sum_partials_f32")
     return out

@@ -206,6 +206,36 @@ def test_conv3x3_tile_stream(ops, B, H, W, C, N):
     assert (z - refz).abs().max().item() < 2e-2 * refz.abs().max().item() + 1e-2
 
 
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 56, 56, 384, 384), (1, 37, 45, 128, 192), (3, 200, 200, 192, 192)])
+def test_conv3x3_f16(ops, B, H, W, C, N):
+    """IEEE-half form of the patch conv (isp_conv3x3_nhwc_f16): plain, folded-affine and classifier-fused epilogues
+    against fp32 on the half-rounded operands; its rounding error is ~8x below the bf16 form's on the same data."""
+    torch.manual_seed(C + H)
+    x = torch.randn(B, C, H, W, device="cuda")
+    w = torch.randn(N, C, 3, 3, device="cuda") / math.sqrt(9 * C)
+    bias = torch.randn(N, device="cuda")
+    xh, wh = x.half(), w.half()
+    conv = F.conv2d(xh.float(), wh.float(), bias, padding=1)
+    xn, wt = xh.permute(0, 2, 3, 1).contiguous(), wh.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous()
+    y = ops.conv3x3(xn, wt, bias, "relu")
+    assert y.dtype == torch.float16
+    e16 = (y.permute(0, 3, 1, 2).float() - F.relu(conv)).abs().max().item()
+    yb = ops.conv3x3(bf(x).permute(0, 2, 3, 1).contiguous(), bf(w).permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), bias, "relu")
+    eb = (yb.permute(0, 3, 1, 2).float() - F.relu(F.conv2d(x, w, bias, padding=1))).abs().max().item()
+    e16_full = (y.permute(0, 3, 1, 2).float() - F.relu(F.conv2d(x, w, bias, padding=1))).abs().max().item()
+    print(f"conv3x3 f16: max err {e16:.3g} vs fp32 on half operands, {e16_full:.3g} vs fp32 on fp32 operands (bf16 form: {eb:.3g})")
+    assert e16 < 4e-3 and e16_full < eb / 3
+    taps = torch.randn(9, N, device="cuda") * 0.3
+    yt = ops.conv3x3_folded_affine(xn, wt, bias + taps.sum(0), taps)
+    inside = F.conv2d(torch.ones(1, 1, H, W, device="cuda"), torch.eye(9, device="cuda").view(9, 1, 3, 3), padding=1)
+    ref = F.relu(conv + torch.einsum("tn,thw->nhw", taps, inside[0]))
+    assert (yt.permute(0, 3, 1, 2).float() - ref).abs().max().item() < 4e-3
+    wcls = torch.randn(N, device="cuda") / math.sqrt(N)
+    z = ops.conv3x3_relu_classifier(xn, wt, bias, wcls, 0.25)
+    refz = (F.relu(conv) * wcls.view(1, N, 1, 1)).sum(1) + 0.25
+    assert (z - refz).abs().max().item() < 2e-3 * refz.abs().max().item() + 1e-3
+
+
 @pytest.mark.parametrize("H,W,C,N", [(48, 48, 128, 384), (37, 29, 64, 192), (32, 32, 128, 128)])
 def test_conv3x3_fused_epilogues(ops, H, W, C, N):
     """Folded-affine first conv (border-exact tap table) and classifier-fused last conv on interior + border tiles."""
