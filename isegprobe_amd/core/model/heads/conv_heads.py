@@ -5,6 +5,8 @@ The reference builds its layers from mmcv's ``ConvModule`` (conv + bias -> ReLU 
 state-dict keys (``convs.{i}.conv.{weight,bias}``).  3x3 layers run as bf16 implicit-GEMM
 convolutions with bias+ReLU fused, 1x1 layers as GEMMs; the final C->1 classifier is a
 per-pixel dot product."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -12,6 +14,9 @@ from .... import hip_ops as ops
 from .._autograd import ClassifierFn, Conv1x1ReluFn, Conv3x3ReluClassifierFn, Conv3x3ReluFn, grad_mode
 from .._tensor import BF16, PackedCache, to_nhwc_bf16
 from .base_head import BaseClassifierHead
+
+
+HEAD_F16 = os.environ.get("ISEGPROBE_HEAD_F16", "1") != "0"  # f16 operands for the inference convolutions (see forward)
 
 
 class ConvModule(nn.Module):
@@ -70,7 +75,13 @@ class _StackedHead(BaseClassifierHead):
             for _ in range(num_layers)])
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self._tail(to_nhwc_bf16(x), list(self.convs))
+        y, layers = to_nhwc_bf16(x), list(self.convs)
+        if (HEAD_F16 and layers and all(l.takes_f16() for l in layers) and self.num_classes == 1
+                and not (grad_mode(self) or (torch.is_grad_enabled() and y.requires_grad))):
+            # inference: the convolutions run on IEEE-half operands (weights and the hidden map keep three more
+            # mantissa bits; the bf16 input converts exactly) -- one extra pass over the input map
+            y = ops.to_f16(y)
+        return self._tail(y, layers)
 
     def _tail(self, y, layers):
         """Remaining conv layers + classifier; a trailing 3x3 layer is fused with the 1x1 classifier
