@@ -206,12 +206,15 @@ int isp_token_add_fwd(void* x, int x_dtype, const void* add, int add_dtype, long
  * isp_jbu_apply: out [B,2h,2w,C] = composite kernels applied to src [B,h,w,C] (C % 64 == 0). */
 int isp_adaptive_avg_pool_nchw_f32(const float* in, float* out, long planes, int H, int W, int OH, int OW, void* stream);
 int isp_jbu_range_proj(const float* guidance, void* proj, const float* w0, const float* b0, const float* w3,
-                       const float* b3, int B, int GH, int GW, int exact_f32, void* stream);
+                       const float* b3, int B, int GH, int GW, int exact_f32, const float* drop_hidden, void* stream);
 /* exact_f32 != 0: both layers in fp32 on the VALU with the erf GELU, proj [B,GH,GW,32] f32 (checking mode);
- * 0: second layer on f16 MFMA, proj [B,GH,GW,32] IEEE half.  isp_jbu_kernels* take either (proj_f16 = 1 for half). */
+ * 0: second layer on f16 MFMA, proj [B,GH,GW,32] IEEE half.  isp_jbu_kernels* take either (proj_f16 = 1 for half).
+ * drop_hidden (nullable): train-mode Dropout2d of the frozen stack under the reference's net.train() (trainer.py:214;
+ * FeatUp's range_proj / fixup_proj carry Dropout2d(0.1) behind their GELU): per (image, hidden unit) multipliers, 0 or
+ * 1/(1-p), [B,32] for isp_jbu_range_proj and [B,64] (49 used) for isp_jbu_kernels*; the caller draws them. */
 int isp_jbu_kernels(const void* proj, int proj_f16, const float* guidance, void* kc_bf16, const void* fix0_w, const float* fix0_b,
                     const void* fix3_w, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
-                    float sigma_spatial, int B, int GH, int GW, void* stream);
+                    float sigma_spatial, int B, int GH, int GW, const float* drop_hidden, void* stream);
 int isp_jbu_apply(const void* src_nhwc_f16, const void* kc_f16, void* out_nhwc, int B, int h, int w, int C, int out_bf16,
                   void* stream);
 /* Last JBU stage fused with the model's bilinear (align_corners) resize to the image size
@@ -223,7 +226,7 @@ int isp_jbu_blend(const void* kc_bf16, void* kc9_bf16, int B, int GH, int GW, in
 /* isp_jbu_kernels followed by isp_jbu_blend in one launch: the stage's own records are never stored */
 int isp_jbu_kernels_resized(const void* proj, int proj_f16, const float* guidance, void* kc9_bf16, const void* fix0_w, const float* fix0_b,
                             const void* fix3_w, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
-                            float sigma_spatial, int B, int GH, int GW, int OH, int OW, void* stream);
+                            float sigma_spatial, int B, int GH, int GW, int OH, int OW, const float* drop_hidden, void* stream);
 int isp_jbu_apply_resized(const void* src_nhwc_f16, const void* kc9_f16, void* out_nhwc, int B, int h, int w, int OH, int OW,
                           int C, int out_bf16, void* stream);
 /* Inside the stack everything is IEEE half: kernel records (kc, kc9), the fix-up MLP weights handed to isp_jbu_kernels*,

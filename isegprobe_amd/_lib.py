@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "libisegprobe_hip.so")  # env override: kernel A/B experiments
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 ISP_F32, ISP_BF16 = 0, 1
 EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16, EP_BIAS_QGELU_SAVE_BF16, EP_MUL_DQGELU_BF16 = range(14)
@@ -79,13 +79,13 @@ SIGNATURES = {
     "isp_resize_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "isp_token_add_fwd": [_vp, _i, _vp, _i, _l, _i, _i, _i, _vp],
     "isp_adaptive_avg_pool_nchw_f32": [_vp, _vp, _l, _i, _i, _i, _i, _vp],
-    "isp_jbu_range_proj": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "isp_jbu_kernels": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp],
+    "isp_jbu_range_proj": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "isp_jbu_kernels": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp],
     "isp_jbu_apply": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "isp_bf16_to_f16": [_vp, _vp, _l, _vp],
     "isp_jbu_apply_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "isp_jbu_blend": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "isp_jbu_kernels_resized": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _vp],
+    "isp_jbu_kernels_resized": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _i, _i, _vp, _vp],
     "isp_jbu_apply_resized": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "isp_fuse_flip_sigmoid": [_vp, _vp, _l, _i, _i, _i, _vp],
     "isp_minmax_nchw_f32": [_vp, _vp, _vp, _i, _i, _l, _vp],

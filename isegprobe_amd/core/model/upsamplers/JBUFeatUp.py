@@ -55,23 +55,26 @@ class JBULearnedRange(nn.Module):
                         temp=float(self.range_temp.item()), sigma=float(self.sigma_spatial.item()))
         return self._packed.get(self._packed.tensors_of(self.parameters), build)
 
-    def kernels(self, guidance, GH, GW):
+    def kernels(self, guidance, GH, GW, drops=None):
         """Composite (bicubic-x2 o 7x7) kernels of this stage: a function of the guidance only, so the click loop
         reuses them while the image / zoom-in ROI is unchanged (_guidance_cache)."""
         P = self.packed()
+        if drops is not None:  # train-mode Dropout2d: fresh multipliers per forward, nothing to cache
+            return self._build_kernels(P, guidance, GH, GW, drops)
         return self._gcache.get(guidance, id(P), (GH, GW), lambda: self._build_kernels(P, guidance, GH, GW))
 
     @staticmethod
-    def _build_kernels(P, guidance, GH, GW):
+    def _build_kernels(P, guidance, GH, GW, drops=None):
         small = ops.adaptive_avg_pool(guidance, GH, GW)
-        proj = ops.jbu_range_proj(small, P["w0"], P["b0"], P["w3"], P["b3"])
-        return ops.jbu_kernels(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"])
+        proj = ops.jbu_range_proj(small, P["w0"], P["b0"], P["w3"], P["b3"], drop=None if drops is None else drops[0])
+        return ops.jbu_kernels(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"],
+                               drop=None if drops is None else drops[1])
 
-    def run(self, source_nhwc, guidance, kc=None, out_dtype=None):
+    def run(self, source_nhwc, guidance, kc=None, out_dtype=None, drops=None):
         """One x2 stage.  Maps inside the stack are f16 (``out_dtype`` default); the stage that leaves it writes bf16."""
         # composite kernels on the low-res grid, applied by MFMA: no x2 map in HBM
         if kc is None:
-            kc = self.kernels(guidance, source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2)
+            kc = self.kernels(guidance, source_nhwc.shape[1] * 2, source_nhwc.shape[2] * 2, drops)
         return ops.jbu_apply(source_nhwc, kc, out_dtype or ops.F16)
 
     @staticmethod
@@ -136,25 +139,47 @@ class JBUStack(nn.Module):
             recs.append(self.up4.kernels(guidance, GH, GW))
         return recs
 
+    def dropout_active(self):
+        """The reference trains with net.train() on the whole model (trainer.py:214), which also switches on the frozen
+        stack's Dropout2d layers: 0.1 behind the GELU of every stage's range_proj and fixup_proj, 0.2 in front of the final
+        1x1 conv.  Active for a training forward (module in train mode, autograd recording)."""
+        return self.training and torch.is_grad_enabled()
+
+    def draw_dropout(self, B, device, generator=None):
+        """One forward's Dropout2d multipliers (0 or 1/(1-p) per (image, channel)):
+        {"stages": [(range [B,32], fixup [B,64], units 49.. are padding)] * 4, "fixup": [B,C]}."""
+        def mult(n, p):
+            keep = torch.rand(B, n, device=device, generator=generator) >= p
+            return keep.float() / (1.0 - p)
+        stages = []
+        for _ in range(4):
+            fix = torch.ones(B, 64, device=device)
+            fix[:, :49] = mult(49, 0.1)
+            stages.append((mult(32, 0.1), fix))
+        return {"stages": stages, "fixup": mult(self.fixup_proj[1].in_channels, 0.2)}
+
     def fixup_affine(self):
         """(W [C,C], b [C], alpha): z = x + alpha * (W x + b)."""
         conv = self.fixup_proj[1]
         return conv.weight.detach().flatten(1), conv.bias.detach(), 0.1
 
-    def forward(self, source, guidance):
-        # NB: the frozen upsampler's Dropout2d layers are never applied (the reference's
-        # net.train() would switch them on, trainer.py:214 -- a stochastic quirk we do not mirror)
+    def forward(self, source, guidance, drops=None):
+        """``drops``: train-mode Dropout2d multipliers (``draw_dropout``); drawn here when ``dropout_active()``."""
         x = to_nhwc_bf16(source)
         guidance = guidance.float().contiguous()
-        for up in (self.up1, self.up2, self.up3):
-            x = up.run(x, guidance)
-        x = self.up4.run(x, guidance, out_dtype=BF16)
+        if drops is None and self.dropout_active():
+            drops = getattr(self, "fixed_dropout", None) or self.draw_dropout(x.shape[0], x.device)
+        st = [None] * 4 if drops is None else drops["stages"]
+        for up, d in zip((self.up1, self.up2, self.up3), st):
+            x = up.run(x, guidance, drops=d)
+        x = self.up4.run(x, guidance, out_dtype=BF16, drops=st[3])
         conv = self.fixup_proj[1]
         w, b = self._packed.get((conv.weight, conv.bias),
                                 lambda: (conv.weight.detach().flatten(1).to(BF16).contiguous(),
                                          conv.bias.detach().float().contiguous()))
         B, H, W, C = x.shape
-        y = ops.linear_axpy_res(x.view(-1, C), w, b, x.view(-1, C), 0.1)
+        xin = x if drops is None else (x * drops["fixup"].to(BF16).view(B, 1, 1, C)).contiguous()
+        y = ops.linear_axpy_res(xin.view(-1, C), w, b, x.view(-1, C), 0.1)
         return nchw_view(y.view(B, H, W, C))
 
 
@@ -175,11 +200,16 @@ class JBUFeatUpUpsampler(BaseUpsampler):
             logger.info("JBUFeatUpUpsampler: no weights given, keeping default init (no network for torch.hub)")
         self.eval()
 
-    def forward(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
+    def forward(self, source: torch.Tensor, guidance: torch.Tensor, drops=None) -> torch.Tensor:
+        """``drops``: explicit train-mode Dropout2d multipliers (tests); by default the stack draws its own whenever the
+        module is in train mode and autograd records (``JBUStack.dropout_active``)."""
         x = to_nhwc_bf16(source)
         if torch.is_grad_enabled() and x.requires_grad:  # training with clicks injected before the upsampler
-            return nchw_view(_JBUFn.apply(x, guidance, self.upsampler))
-        return self.upsampler(source, guidance)
+            stack = self.upsampler
+            if drops is None and stack.dropout_active():
+                drops = getattr(stack, "fixed_dropout", None) or stack.draw_dropout(x.shape[0], x.device)  # (tests pin them)
+            return nchw_view(_JBUFn.apply(x, guidance, stack, drops))
+        return self.upsampler(source, guidance, drops=drops)
 
 
 class _JBUFn(torch.autograd.Function):
@@ -188,27 +218,33 @@ class _JBUFn(torch.autograd.Function):
     g <- g + 0.1 W^T g, then four adjoint applies with the saved kernels."""
 
     @staticmethod
-    def forward(ctx, src, guidance, stack):
+    def forward(ctx, src, guidance, stack, drops=None):
         x = src.detach()
         g = guidance.detach().float().contiguous()
-        kcs = []
+        kcs = []  # (drops are drawn by the caller: grad mode is off inside a Function's forward)
         for i, up in enumerate((stack.up1, stack.up2, stack.up3, stack.up4)):
-            kc = up.kernels(g, x.shape[1] * 2, x.shape[2] * 2)
+            kc = up.kernels(g, x.shape[1] * 2, x.shape[2] * 2, None if drops is None else drops["stages"][i])
             kcs.append(kc)
             x = ops.jbu_apply(x, kc, BF16 if i == 3 else ops.F16)
         conv = stack.fixup_proj[1]
         w = conv.weight.detach().flatten(1).to(BF16).contiguous()
         B, H, W, C = x.shape
-        y = ops.linear_axpy_res(x.view(-1, C), w, conv.bias.detach().float().contiguous(), x.view(-1, C), 0.1)
-        ctx.kcs, ctx.wT = kcs, conv.weight.detach().flatten(1).t().contiguous().to(BF16)
+        fix = None if drops is None else drops["fixup"].to(BF16).view(B, 1, 1, C)
+        xin = x if fix is None else (x * fix).contiguous()  # z = x + 0.1 (W (m o x) + b)
+        y = ops.linear_axpy_res(xin.view(-1, C), w, conv.bias.detach().float().contiguous(), x.view(-1, C), 0.1)
+        ctx.kcs, ctx.wT, ctx.fix = kcs, conv.weight.detach().flatten(1).t().contiguous().to(BF16), fix
         return y.view(B, H, W, C)
 
     @staticmethod
     def backward(ctx, g_out):
         B, H, W, C = g_out.shape
         g = g_out.contiguous().view(-1, C)
-        g = ops.linear_axpy_res(g, ctx.wT, None, g, 0.1).view(B, H, W, C)  # (I + 0.1 W)^T
+        if ctx.fix is None:
+            g = ops.linear_axpy_res(g, ctx.wT, None, g, 0.1).view(B, H, W, C)  # (I + 0.1 W)^T
+        else:  # (I + 0.1 W diag(m))^T g = g + 0.1 m o (W^T g)
+            t = ops.linear(g, ctx.wT).view(B, H, W, C)
+            g = (g.view(B, H, W, C).float() + 0.1 * (t * ctx.fix).float()).to(BF16)
         for kc in reversed(ctx.kcs):
             g = ops.jbu_apply_bwd(g, kc)
         ctx.kcs = None
-        return g, None, None
+        return g, None, None, None

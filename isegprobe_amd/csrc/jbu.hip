@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void adaptive_avg_pool_kernel(const float* __r
 __global__ __launch_bounds__(256) void jbu_range_proj_f32_kernel(const float* __restrict__ G, float* __restrict__ proj,
                                                                   const float* __restrict__ w0, const float* __restrict__ b0,
                                                                   const float* __restrict__ w3, const float* __restrict__ b3,
-                                                                  long HW, long total) {
+                                                                  const float* __restrict__ drop, long HW, long total) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const long b = idx / HW, p = idx - b * HW;
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void jbu_range_proj_f32_kernel(const float* __
     float hid[KEY];
 #pragma unroll
     for (int j = 0; j < KEY; ++j)
-        hid[j] = gelu_erf(fmaf(w0[j * 3 + 2], g2, fmaf(w0[j * 3 + 1], g1, fmaf(w0[j * 3 + 0], g0, b0[j]))));
+        hid[j] = gelu_erf(fmaf(w0[j * 3 + 2], g2, fmaf(w0[j * 3 + 1], g1, fmaf(w0[j * 3 + 0], g0, b0[j])))) *
+                 (drop ? drop[b * KEY + j] : 1.0f);
     float4* o = reinterpret_cast<float4*>(proj + idx * KEY);
 #pragma unroll
     for (int m4 = 0; m4 < KEY / 4; ++m4) {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void jbu_range_proj_f32_kernel(const float* __
 __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __restrict__ G, unsigned short* __restrict__ proj,
                                                               const float* __restrict__ w0, const float* __restrict__ b0,
                                                               const float* __restrict__ w3, const float* __restrict__ b3,
-                                                              long HW, long total) {
+                                                              const float* __restrict__ drop, long HW, long total) {
     __shared__ __attribute__((aligned(16))) char s_hid[256 * 80];
     __shared__ __attribute__((aligned(16))) _Float16 s_w3[KEY * KEY];
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
             for (int e = 0; e < 8; ++e) {
                 const int j = c * 8 + e;
                 h[e] = gelu_sig5(fmaf(w0[j * 3 + 2], g2, fmaf(w0[j * 3 + 1], g1, fmaf(w0[j * 3 + 0], g0, b0[j]))));
+                if (drop) h[e] *= drop[b * KEY + j];  // train-mode Dropout2d(0.1) behind the GELU: per (image, channel) 0 or 1/0.9
             }
             *reinterpret_cast<uint4*>(s_hid + threadIdx.x * 80 + c * 16) =
                 make_uint4(pack2h(h[0], h[1]), pack2h(h[2], h[3]), pack2h(h[4], h[5]), pack2h(h[6], h[7]));
@@ -177,7 +179,8 @@ __global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const void* __restr
                                                            const float* __restrict__ f0b, const bf16_t* __restrict__ f3w,
                                                            const float* __restrict__ f3b, const float* __restrict__ bys,
                                                            const float* __restrict__ bxs, float temp, float inv2s2,
-                                                           int GH, int GW, int OH, int OW, float rsy, float rsx) {
+                                                           int GH, int GW, int OH, int OW, float rsy, float rsx,
+                                                           const float* __restrict__ drop) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.z, ty0 = blockIdx.y * TSY, tx0 = blockIdx.x * TSX;
     const long HW = (long)GH * GW;
@@ -350,7 +353,13 @@ __global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const void* __restr
                     // D[unit = 16*ot + 4*fq + j][pixel = row]
                     const float4 bb = *reinterpret_cast<const float4*>(bsrc + ot * 16 + fq * 4);
                     float r0 = acc[0] + bb.x, r1 = acc[1] + bb.y, r2 = acc[2] + bb.z, r3 = acc[3] + bb.w;
-                    if (layer == 0) r0 = gelu_sig5(r0), r1 = gelu_sig5(r1), r2 = gelu_sig5(r2), r3 = gelu_sig5(r3);
+                    if (layer == 0) {
+                        r0 = gelu_sig5(r0), r1 = gelu_sig5(r1), r2 = gelu_sig5(r2), r3 = gelu_sig5(r3);
+                        if (drop) {  // train-mode Dropout2d(0.1) of the fix-up MLP's hidden units: [B][64] multipliers
+                            const float4 dm = *reinterpret_cast<const float4*>(drop + (size_t)b * 64 + ot * 16 + fq * 4);
+                            r0 *= dm.x, r1 *= dm.y, r2 *= dm.z, r3 *= dm.w;
+                        }
+                    }
                     *reinterpret_cast<uint2*>(dst + mlp_off(row, ot * 2 + (fq >> 1)) + (fq & 1) * 8) =
                         make_uint2(pack2h(r0, r1), pack2h(r2, r3));
                 }
@@ -801,21 +810,22 @@ extern "C" int isp_adaptive_avg_pool_nchw_f32(const float* in, float* out, long 
 }
 
 extern "C" int isp_jbu_range_proj(const float* guidance, void* proj, const float* w0, const float* b0,
-                                  const float* w3, const float* b3, int B, int GH, int GW, int exact_f32, void* stream) {
+                                  const float* w3, const float* b3, int B, int GH, int GW, int exact_f32,
+                                  const float* drop_hidden, void* stream) {
     ISP_CHECK_ARG(guidance && proj && w0 && b0 && w3 && b3 && B > 0 && GH > 0 && GW > 0);
     const long HW = (long)GH * GW, total = HW * B;
     if (exact_f32)
         jbu_range_proj_f32_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(guidance, (float*)proj, w0,
-                                                                                                    b0, w3, b3, HW, total);
+                                                                                                    b0, w3, b3, drop_hidden, HW, total);
     else
         jbu_range_proj_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(guidance, (unsigned short*)proj,
-                                                                                                w0, b0, w3, b3, HW, total);
+                                                                                                w0, b0, w3, b3, drop_hidden, HW, total);
     return isp_launch_status();
 }
 
 static int launch_jbu_kernels(const void* proj, int proj_f16, const float* guidance, void* kc_bf16, const void* fix0_w, const float* fix0_b,
                               const void* fix3_w, const float* fix3_b, const float* bys, const float* bxs, float range_temp,
-                              float sigma_spatial, int B, int GH, int GW, int OH, int OW, void* stream) {
+                              float sigma_spatial, int B, int GH, int GW, int OH, int OW, const float* drop, void* stream) {
     ISP_CHECK_ARG(proj && guidance && kc_bf16 && fix0_w && fix0_b && fix3_w && fix3_b && bys && bxs);
     ISP_CHECK_ARG(B > 0 && GH >= 4 && GW >= 4 && GH % 2 == 0 && GW % 2 == 0 && B <= 65535 && sigma_spatial != 0.f);
     const float temp = fminf(fmaxf(expf(range_temp), 1e-4f), 1e4f);
@@ -836,11 +846,11 @@ static int launch_jbu_kernels(const void* proj, int proj_f16, const float* guida
         const float rsy = (float)(GH - 1) / (float)(OH - 1), rsx = (float)(GW - 1) / (float)(OW - 1);
         jbu_kernels_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(proj, proj_f16, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
                                                                           fix0_b, (const bf16_t*)fix3_w, fix3_b, bys, bxs, temp,
-                                                                          inv2s2, GH, GW, OH, OW, rsy, rsx);
+                                                                          inv2s2, GH, GW, OH, OW, rsy, rsx, drop);
     } else {
         jbu_kernels_kernel<false><<<grid, 256, lds, (hipStream_t)stream>>>(proj, proj_f16, guidance, (bf16_t*)kc_bf16, (const bf16_t*)fix0_w,
                                                                            fix0_b, (const bf16_t*)fix3_w, fix3_b, bys, bxs, temp,
-                                                                           inv2s2, GH, GW, 0, 0, 0.f, 0.f);
+                                                                           inv2s2, GH, GW, 0, 0, 0.f, 0.f, drop);
     }
     return isp_launch_status();
 }
@@ -848,19 +858,19 @@ static int launch_jbu_kernels(const void* proj, int proj_f16, const float* guida
 extern "C" int isp_jbu_kernels(const void* proj, int proj_f16, const float* guidance, void* kc_bf16, const void* fix0_w,
                                const float* fix0_b, const void* fix3_w, const float* fix3_b, const float* bys,
                                const float* bxs, float range_temp, float sigma_spatial, int B, int GH, int GW,
-                               void* stream) {
+                               const float* drop_hidden, void* stream) {
     return launch_jbu_kernels(proj, proj_f16, guidance, kc_bf16, fix0_w, fix0_b, fix3_w, fix3_b, bys, bxs, range_temp, sigma_spatial, B,
-                              GH, GW, 0, 0, stream);
+                              GH, GW, 0, 0, drop_hidden, stream);
 }
 
 extern "C" int isp_jbu_kernels_resized(const void* proj, int proj_f16, const float* guidance, void* kc9_bf16, const void* fix0_w,
                                        const float* fix0_b, const void* fix3_w, const float* fix3_b, const float* bys,
                                        const float* bxs, float range_temp, float sigma_spatial, int B, int GH, int GW, int OH,
-                                       int OW, void* stream) {
+                                       int OW, const float* drop_hidden, void* stream) {
     ISP_CHECK_ARG(GH >= 8 && GW >= 8 && OH > 1 && OW > 1 && GH % 8 == 0 && GW % 8 == 0);
     ISP_CHECK_ARG((long)OH * 8 == (long)GH * 7 && (long)OW * 8 == (long)GW * 7);
     return launch_jbu_kernels(proj, proj_f16, guidance, kc9_bf16, fix0_w, fix0_b, fix3_w, fix3_b, bys, bxs, range_temp, sigma_spatial, B,
-                              GH, GW, OH, OW, stream);
+                              GH, GW, OH, OW, drop_hidden, stream);
 }
 
 extern "C" int isp_jbu_blend(const void* kc_bf16, void* kc9_bf16, int B, int GH, int GW, int OH, int OW, void* stream) {

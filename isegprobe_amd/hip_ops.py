@@ -538,14 +538,24 @@ def adaptive_avg_pool(x, OH, OW):
     return out
 
 
-def jbu_range_proj(g, w0, b0, w3, b3, exact=False):
+def _drop(drop, B, n):
+    """Optional Dropout2d multipliers [B, n] f32 (0 or 1/(1-p)) -> pointer (or NULL)."""
+    if drop is None:
+        return None
+    _need(drop, torch.float32, "drop")
+    if tuple(drop.shape) != (B, n):
+        raise IspError(f"dropout multipliers must be [{B}, {n}]")
+    return _p(drop)
+
+
+def jbu_range_proj(g, w0, b0, w3, b3, exact=False, drop=None):
     """g [B,3,GH,GW] f32 -> proj [B,GH,GW,32].  ``exact``: both layers in fp32 with the erf GELU, f32 output (the fp32
     checking mode); default: second layer on f16 MFMA, IEEE-half output (what jbu_kernels stages anyway)."""
     _need(g, torch.float32, "guidance")
     B, _, GH, GW = g.shape
     proj = torch.empty(B, GH, GW, 32, device=g.device, dtype=torch.float32 if exact else F16)
-    check(_lib.lib().isp_jbu_range_proj(_p(g), _p(proj), _p(w0), _p(b0), _p(w3), _p(b3), B, GH, GW, int(bool(exact)), _stream()),
-          "isp_jbu_range_proj")
+    check(_lib.lib().isp_jbu_range_proj(_p(g), _p(proj), _p(w0), _p(b0), _p(w3), _p(b3), B, GH, GW, int(bool(exact)),
+                                        _drop(drop, B, 32), _stream()), "isp_jbu_range_proj")
     return proj
 
 
@@ -600,7 +610,7 @@ def _proj_is_half(proj):
     return int(proj.dtype == F16)
 
 
-def jbu_kernels(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial):
+def jbu_kernels(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial, drop=None):
     """-> composite kernels kc [B,GH,GW,8,16] f16 (see include/isegprobe_hip.h); f0w / f3w: f16 [64,64]."""
     _need(f0w, F16, "f0w")
     _need(f3w, F16, "f3w")
@@ -609,11 +619,12 @@ def jbu_kernels(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial):
     bxs = jbu_tables(GW, proj.device)[1]
     kc = torch.empty(B, GH, GW, 8, 16, device=proj.device, dtype=F16)
     check(_lib.lib().isp_jbu_kernels(_p(proj), _proj_is_half(proj), _p(g), _p(kc), _p(f0w), _p(f0b), _p(f3w), _p(f3b), _p(bys), _p(bxs),
-                                     float(range_temp), float(sigma_spatial), B, GH, GW, _stream()), "isp_jbu_kernels")
+                                     float(range_temp), float(sigma_spatial), B, GH, GW, _drop(drop, B, 64), _stream()),
+          "isp_jbu_kernels")
     return kc
 
 
-def jbu_kernels_resized(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial, OH, OW):
+def jbu_kernels_resized(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial, OH, OW, drop=None):
     """jbu_blend(jbu_kernels(...), OH, OW) in one launch -> kc9 [B,OH,OW,9,16] f16."""
     _need(f0w, F16, "f0w")
     _need(f3w, F16, "f3w")
@@ -622,8 +633,8 @@ def jbu_kernels_resized(proj, g, f0w, f0b, f3w, f3b, range_temp, sigma_spatial, 
     bxs = jbu_tables(GW, proj.device)[1]
     kc9 = torch.empty(B, OH, OW, 9, 16, device=proj.device, dtype=F16)
     check(_lib.lib().isp_jbu_kernels_resized(_p(proj), _proj_is_half(proj), _p(g), _p(kc9), _p(f0w), _p(f0b), _p(f3w), _p(f3b), _p(bys), _p(bxs),
-                                             float(range_temp), float(sigma_spatial), B, GH, GW, OH, OW, _stream()),
-          "isp_jbu_kernels_resized")
+                                             float(range_temp), float(sigma_spatial), B, GH, GW, OH, OW, _drop(drop, B, 64),
+                                             _stream()), "isp_jbu_kernels_resized")
     return kc9
 
 

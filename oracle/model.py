@@ -81,7 +81,7 @@ def features_with_grad(image, points, w, cfg):
         elif up == "loftup":
             hr = ups.loftup(feats, image, w, "upsampler.upsampler.", bn_train=bn_train, stats=stats)
         elif up == "jbu_featup":
-            hr = ups.jbu_stack(feats, image, w, "upsampler.upsampler.")
+            hr = ups.jbu_stack(feats, image, w, "upsampler.upsampler.", drops=cfg.get("jbu_drops"))  # net.train(): Dropout2d
         else:
             hr = getattr(ups, up)(feats, image)
         if up != "identity" and hr.shape[2:] != image.shape[2:]:  # iseg_probe_model.py:120-129

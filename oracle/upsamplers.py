@@ -179,12 +179,16 @@ def loftup(source, guidance, w, prefix="upsampler.", heads=4, n_freqs=20, depth=
 # Restated from the published algorithm (featup/upsamplers.py: JBULearnedRange,
 # JBUStack; featup/adaptive_conv_cuda: AdaptiveConv).  *Parity unpinned*: the reference
 # holds no test or fixture for it and the package cannot be imported here.
-def _jbu_stage(source, guidance, w, p, radius=3):
+def _jbu_stage(source, guidance, w, p, radius=3, drops=None):
+    """drops (train mode, the reference's net.train() on the frozen stack): (range [B,32], fixup [B,49]) Dropout2d
+    multipliers -- 0 or 1/(1-p) per (image, channel) -- applied where the modules' Dropout2d(0.1) layers sit."""
     d = 2 * radius + 1
     GB, GC, GH, GW = guidance.shape
-    # range kernel: 1x1(3->32) GELU [Dropout2d eval] 1x1(32->32); 49-tap dot; softmax * temp
-    proj = F.conv2d(F.gelu(F.conv2d(guidance, w[p + "range_proj.0.weight"], w[p + "range_proj.0.bias"])),
-                    w[p + "range_proj.3.weight"], w[p + "range_proj.3.bias"])
+    # range kernel: 1x1(3->32) GELU Dropout2d 1x1(32->32); 49-tap dot; softmax * temp
+    hid = F.gelu(F.conv2d(guidance, w[p + "range_proj.0.weight"], w[p + "range_proj.0.bias"]))
+    if drops is not None:
+        hid = hid * drops[0][:, :, None, None]
+    proj = F.conv2d(hid, w[p + "range_proj.3.weight"], w[p + "range_proj.3.bias"])
     key_dim = proj.shape[1]
     padded = F.pad(proj, [radius] * 4, mode="reflect")
     queries = F.unfold(padded, d).reshape(GB, key_dim, d * d, GH, GW).permute(0, 1, 3, 4, 2)
@@ -196,8 +200,10 @@ def _jbu_stage(source, guidance, w, p, radius=3):
     spatial = torch.exp(-(xx.square() + yy.square()) / (2 * w[p + "sigma_spatial"] ** 2)).reshape(1, d * d, 1, 1)
     k = range_k * spatial
     k = k / k.sum(1, keepdim=True).clamp(1e-7)
-    fix = F.conv2d(torch.cat([k, guidance], dim=1), w[p + "fixup_proj.0.weight"], w[p + "fixup_proj.0.bias"])
-    fix = F.conv2d(F.gelu(fix), w[p + "fixup_proj.3.weight"], w[p + "fixup_proj.3.bias"])
+    fix = F.gelu(F.conv2d(torch.cat([k, guidance], dim=1), w[p + "fixup_proj.0.weight"], w[p + "fixup_proj.0.bias"]))
+    if drops is not None:
+        fix = fix * drops[1][:, :, None, None]
+    fix = F.conv2d(fix, w[p + "fixup_proj.3.weight"], w[p + "fixup_proj.3.bias"])
     k = k + 0.1 * fix
     k = k.permute(0, 2, 3, 1).reshape(GB, GH, GW, d, d)
     hr = F.interpolate(source, (GH, GW), mode="bicubic", align_corners=False)
@@ -210,12 +216,15 @@ def _jbu_stage(source, guidance, w, p, radius=3):
     return out
 
 
-def jbu_stack(source, guidance, w, prefix="upsampler."):
+def jbu_stack(source, guidance, w, prefix="upsampler.", drops=None):
+    """drops: None (eval), or the train-mode Dropout2d multipliers {"stages": [(range [B,32], fixup [B,49])] * 4,
+    "fixup": [B,C]} (see _jbu_stage)."""
     ws = {k[len(prefix):]: v for k, v in w.items() if k.startswith(prefix)}
     x = source
     for s in range(1, 5):
         h, wd = x.shape[2:]
         small = F.adaptive_avg_pool2d(guidance, (h * 2, wd * 2))
-        x = _jbu_stage(x, small, ws, f"up{s}.")
+        x = _jbu_stage(x, small, ws, f"up{s}.", drops=None if drops is None else drops["stages"][s - 1])
     # fixup_proj = Sequential(Dropout2d(0.2), Conv2d 1x1): index 1
-    return F.conv2d(x, ws["fixup_proj.1.weight"], ws["fixup_proj.1.bias"]) * 0.1 + x
+    xin = x if drops is None else x * drops["fixup"][:, :, None, None]
+    return F.conv2d(xin, ws["fixup_proj.1.weight"], ws["fixup_proj.1.bias"]) * 0.1 + x

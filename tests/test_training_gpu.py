@@ -75,15 +75,25 @@ def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
                with_prev_mask=True, use_disks=True, norm_radius=5,
                bn_train=True)  # model.train() below: batch-statistics BatchNorm in the frozen LiFT / LoftUp, as in the reference
     coef = torch.randn(2, 1, 56, 56)
+    model = model.cuda().train()
+    if upsampler == "jbu_featup":
+        # model.train() also switches on the frozen stack's Dropout2d layers (reference net.train(), trainer.py:214): one
+        # fixed draw, with dropped channels in every layer, handed to the model and to the oracle alike
+        stack = model.upsampler.upsampler
+        drops = stack.draw_dropout(2, "cuda", torch.Generator(device="cuda").manual_seed(5))
+        assert all((d == 0).any() for st in drops["stages"] for d in (st[0], st[1][:, :49])) and (drops["fixup"] == 0).any()
+        stack.fixed_dropout = drops
+        cfg["jbu_drops"] = {"stages": [(r.cpu(), f[:, :49].cpu()) for r, f in drops["stages"]], "fixup": drops["fixup"].cpu()}
     ref_out = omodel.forward_with_grad(image, points, w, cfg)
     (ref_out * coef).sum().backward()
-    model = model.cuda().train()
     out = model(image.cuda(), points.cuda())["instances"]
     assert out.requires_grad
     # the training forward (statistics saved) computes the same logits as the no-grad path in the same mode
-    # (lift / loftup: each train-mode forward also moves the running statistics, which batch-statistics BN does not read)
+    # (lift / loftup: each train-mode forward also moves the running statistics, which batch-statistics BN does not read;
+    # jbu: the no-grad forward has no dropout, and it must differ from the training forward)
     with torch.no_grad():
-        assert (model(image.cuda(), points.cuda())["instances"] - out).abs().max().item() < 2e-2
+        diff = (model(image.cuda(), points.cuda())["instances"] - out).abs().max().item()
+        assert diff < 2e-2 if upsampler != "jbu_featup" else diff > 1e-3
     assert (out.detach().cpu() - ref_out.detach()).abs().max().item() < 2e-2 * (1 + ref_out.abs().max().item())
     (out * coef.cuda()).sum().backward()
     named = dict(model.named_parameters())

@@ -72,6 +72,58 @@ def test_jbu_stages_and_stack_vs_oracle():
     assert err.pow(2).mean().sqrt().item() < 5e-3 * max(1.0, ref.pow(2).mean().sqrt().item())
 
 
+def test_jbu_train_mode_dropout():
+    """The reference trains with net.train() on the whole model (trainer.py:214), which switches on the frozen FeatUp
+    stack's Dropout2d layers.  With pinned multipliers the stack equals the oracle's stack with the same multipliers; all-
+    ones multipliers reproduce the eval output bit for bit; a no-grad or eval forward never drops anything; and two
+    training forwards differ (fresh draws)."""
+    from isegprobe_amd.core.model.upsamplers import JBUFeatUpUpsampler
+    from oracle import upsamplers as oups
+    torch.manual_seed(1)
+    C = 128
+    up = seeded_(JBUFeatUpUpsampler("dinov2", feat_dim=C), 21)
+    w = {k: v.clone() for k, v in up.state_dict().items()}
+    src, gd = torch.randn(2, C, 4, 5), torch.randn(2, 3, 64, 80)
+    up = up.cuda()
+    stack = up.upsampler
+    drops = stack.draw_dropout(2, "cuda", torch.Generator(device="cuda").manual_seed(3))
+    assert all((d == 0).any() for st in drops["stages"] for d in (st[0], st[1][:, :49])) and (drops["fixup"] == 0).any()
+    cpu = {"stages": [(r.cpu(), f[:, :49].cpu()) for r, f in drops["stages"]], "fixup": drops["fixup"].cpu()}
+    ref = oups.jbu_stack(src, gd, w, "upsampler.", drops=cpu)
+    ref_eval = oups.jbu_stack(src, gd, w, "upsampler.")
+    assert (ref - ref_eval).abs().max().item() > 0.05  # the draw matters
+    with torch.no_grad():
+        y = _f32(up(src.cuda(), gd.cuda(), drops=drops))
+        y_eval = _f32(up(src.cuda(), gd.cuda()))
+        ones = {"stages": [(torch.ones(2, 32, device="cuda"), torch.ones(2, 64, device="cuda"))] * 4,
+                "fixup": torch.ones(2, C, device="cuda")}
+        assert torch.equal(_f32(up(src.cuda(), gd.cuda(), drops=ones)), y_eval)
+    for got, want in ((y, ref), (y_eval, ref_eval)):
+        err = (got - want).abs()
+        assert err.max().item() < 3e-2 * max(1.0, want.abs().max().item())
+        assert err.pow(2).mean().sqrt().item() < 5e-3 * max(1.0, want.pow(2).mean().sqrt().item())
+    # training forwards draw their own multipliers; eval / no-grad forwards never do
+    up.train()
+    xs = src.cuda().requires_grad_(True)
+    a, b = _f32(up(xs, gd.cuda())), _f32(up(xs, gd.cuda()))
+    assert (a - b).abs().max().item() > 1e-3
+    with torch.no_grad():
+        assert torch.equal(_f32(up(src.cuda(), gd.cuda())), y_eval)
+    up.eval()
+    assert torch.equal(_f32(up(xs, gd.cuda())).detach(), y_eval)
+    # gradient through the dropped fix-up: d/dx sum(c * stack(x)) against the oracle's autograd with the same draw
+    up.train()
+    stack.fixed_dropout = drops
+    coef = torch.randn(2, C, 64, 80)
+    xb = src.cuda().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).requires_grad_(True)  # the featurizer's output form
+    (up(xb.permute(0, 3, 1, 2), gd.cuda()).float() * coef.cuda()).sum().backward()
+    xr = xb.detach().float().permute(0, 3, 1, 2).cpu().requires_grad_(True)
+    (oups.jbu_stack(xr, gd, w, "upsampler.", drops=cpu) * coef).sum().backward()
+    g, gr = xb.grad.float().permute(0, 3, 1, 2).cpu(), xr.grad
+    assert torch.nn.functional.cosine_similarity(g.flatten(), gr.flatten(), dim=0).item() > 0.999
+    assert (g - gr).pow(2).mean().sqrt().item() < 2e-2 * gr.pow(2).mean().sqrt().item()
+
+
 @pytest.mark.parametrize("h,w", [(4, 8), (8, 4), (16, 16), (5, 7), (3, 9)])
 def test_jbu_last_stage_fused_with_resize(h, w):
     """JBUStack.forward_stages(out_size=image size): the last x2 stage and the model's bilinear resize as ONE operator
