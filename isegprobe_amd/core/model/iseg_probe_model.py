@@ -114,6 +114,7 @@ class iSegProbeModel(iSegBaseModel):
             if (not (torch.is_grad_enabled() and backbone_features.requires_grad)
                     and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.head.parameters()))
                     and self.fold_upsampler_affine and isinstance(self.upsampler, JBUFeatUpUpsampler)
+                    and not self.upsampler.upsampler.dropout_active()  # (train mode: the stack's Dropout2d layers run)
                     and isinstance(self.head, ConvSegHead) and self.head.num_layers >= 1):
                 # JBUStack ends with z = x + 0.1*conv1x1(x); that affine map commutes with the bilinear
                 # resize and folds into the head's first conv: the 2.5 TFLOP 1x1 GEMM disappears

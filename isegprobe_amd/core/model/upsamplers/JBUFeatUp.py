@@ -142,8 +142,9 @@ class JBUStack(nn.Module):
     def dropout_active(self):
         """The reference trains with net.train() on the whole model (trainer.py:214), which also switches on the frozen
         stack's Dropout2d layers: 0.1 behind the GELU of every stage's range_proj and fixup_proj, 0.2 in front of the final
-        1x1 conv.  Active for a training forward (module in train mode, autograd recording)."""
-        return self.training and torch.is_grad_enabled()
+        1x1 conv.  Active whenever the module is in train mode, with or without autograd -- nn.Dropout2d's own rule (the
+        reference's trainer calls net.eval() around its no-grad click-simulation forwards, trainer.py:404-414)."""
+        return self.training
 
     def draw_dropout(self, B, device, generator=None):
         """One forward's Dropout2d multipliers (0 or 1/(1-p) per (image, channel)):

@@ -90,10 +90,9 @@ def test_before_backbone_gradients_vs_oracle_autograd(upsampler):
     assert out.requires_grad
     # the training forward (statistics saved) computes the same logits as the no-grad path in the same mode
     # (lift / loftup: each train-mode forward also moves the running statistics, which batch-statistics BN does not read;
-    # jbu: the no-grad forward has no dropout, and it must differ from the training forward)
+    # jbu: with the pinned draw the no-grad forward drops the same channels)
     with torch.no_grad():
-        diff = (model(image.cuda(), points.cuda())["instances"] - out).abs().max().item()
-        assert diff < 2e-2 if upsampler != "jbu_featup" else diff > 1e-3
+        assert (model(image.cuda(), points.cuda())["instances"] - out).abs().max().item() < 2e-2
     assert (out.detach().cpu() - ref_out.detach()).abs().max().item() < 2e-2 * (1 + ref_out.abs().max().item())
     (out * coef.cuda()).sum().backward()
     named = dict(model.named_parameters())

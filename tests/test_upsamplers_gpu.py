@@ -75,8 +75,8 @@ def test_jbu_stages_and_stack_vs_oracle():
 def test_jbu_train_mode_dropout():
     """The reference trains with net.train() on the whole model (trainer.py:214), which switches on the frozen FeatUp
     stack's Dropout2d layers.  With pinned multipliers the stack equals the oracle's stack with the same multipliers; all-
-    ones multipliers reproduce the eval output bit for bit; a no-grad or eval forward never drops anything; and two
-    training forwards differ (fresh draws)."""
+    ones multipliers reproduce the eval output bit for bit; an eval forward never drops anything; and two train-mode
+    forwards differ (fresh draws)."""
     from isegprobe_amd.core.model.upsamplers import JBUFeatUpUpsampler
     from oracle import upsamplers as oups
     torch.manual_seed(1)
@@ -102,13 +102,13 @@ def test_jbu_train_mode_dropout():
         err = (got - want).abs()
         assert err.max().item() < 3e-2 * max(1.0, want.abs().max().item())
         assert err.pow(2).mean().sqrt().item() < 5e-3 * max(1.0, want.pow(2).mean().sqrt().item())
-    # training forwards draw their own multipliers; eval / no-grad forwards never do
+    # train mode draws fresh multipliers per forward, with or without autograd (nn.Dropout2d's rule); eval mode never does
     up.train()
     xs = src.cuda().requires_grad_(True)
     a, b = _f32(up(xs, gd.cuda())), _f32(up(xs, gd.cuda()))
     assert (a - b).abs().max().item() > 1e-3
     with torch.no_grad():
-        assert torch.equal(_f32(up(src.cuda(), gd.cuda())), y_eval)
+        assert (_f32(up(src.cuda(), gd.cuda())) - y_eval).abs().max().item() > 1e-3
     up.eval()
     assert torch.equal(_f32(up(xs, gd.cuda())).detach(), y_eval)
     # gradient through the dropped fix-up: d/dx sum(c * stack(x)) against the oracle's autograd with the same draw
