@@ -31,6 +31,7 @@ extern "C" {
 
 #define ISP_F32 0
 #define ISP_BF16 1
+#define ISP_F16 2 /* IEEE half */
 
 /* ABI version; bumped on any signature change. */
 int isp_abi_version(void);
@@ -96,6 +97,9 @@ typedef struct isp_epilogue {
  * N % 4 == 0.  Replaces nn.Linear in attention.py:54-71, mlp.py:34-40, the patch-embed convs
  * (as GEMMs) and every 1x1 conv on the path. */
 int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* ep, void* stream);
+/* The same on IEEE-half operands with 16-bit outputs in half (LoftUp's inference stream, loftup/layers.py:160-228): epilogue
+ * kinds ISP_EP_BIAS_BF16, ISP_EP_BIAS_GELU_BF16 and ISP_EP_AXPY_RES_BF16 (res and out half); others ISP_ERR_UNSUPPORTED. */
+int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* ep, void* stream);
 
 /* ---- 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on NHWC bf16.
  * in [B,H,W,C] (C % 64 == 0), Wt [N][9*C] with K index = ((ky*3+kx)*C + c), i.e.
@@ -136,6 +140,11 @@ int isp_attention_fwd_logit2(const void* Q, const void* K, const void* V, void* 
                              int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
                              long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
                              void* stream);
+
+/* head_dim 128 / 256 on IEEE-half Q, K, V, O (LoftUp's cross-attention in its half-precision inference stream) */
+int isp_attention_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, int head_dim,
+                          long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
+                          long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
 
 /* Training variant: also writes lse[b*H+h][q] (row stride lse_ld >= Lq, fp32) = log2 sum_k exp2(s_qk * scale * log2 e),
  * the statistic isp_attention_bwd needs to recompute the probabilities. */
@@ -250,6 +259,10 @@ int isp_loftup_fourier_cn(const float* image, const float* minmax_c2, const floa
 /* same, fp32 output (the fp32 checking mode) */
 int isp_loftup_fourier_cn_f32(const float* image, const float* minmax_c2, const float* freqs, const float* bias_sin,
                               const float* bias_cos, const float* gamma, const float* beta, float* out_f32, int B, int H, int W,
+                              int n_freqs, int ldo, float eps, void* stream);
+/* IEEE-half output (the half-precision inference stream) */
+int isp_loftup_fourier_cn_f16(const float* image, const float* minmax_c2, const float* freqs, const float* bias_sin,
+                              const float* bias_cos, const float* gamma, const float* beta, void* out_f16, int B, int H, int W,
                               int n_freqs, int ldo, float eps, void* stream);
 
 /* ---- fused ViT MLP branch, in place on the fp32 residual stream x [M][D]:

@@ -11,9 +11,9 @@ from ..._lib import IspError
 BF16 = torch.bfloat16
 
 
-def to_nhwc_bf16(x):
+def to_nhwc_bf16(x, keep_f16=False):
     """x: [B,C,H,W]-shaped GPU tensor (bf16 channels-last view, or fp32 in any strides)
-    -> contiguous [B,H,W,C] bf16."""
+    -> contiguous [B,H,W,C] bf16 (an IEEE-half channels-last view stays half with ``keep_f16``)."""
     if x.dim() != 4:
         raise IspError(f"expected a 4-D [B,C,H,W] tensor, got {tuple(x.shape)}")
     if not x.is_cuda:
@@ -21,6 +21,10 @@ def to_nhwc_bf16(x):
     if x.dtype == BF16:
         y = x.permute(0, 2, 3, 1)
         return y if y.is_contiguous() else y.contiguous()
+    if x.dtype == torch.float16 and x.permute(0, 2, 3, 1).is_contiguous():
+        if keep_f16:  # IEEE-half NHWC maps (FeatUp-JBU / LoftUp inference output) go to consumers that take them
+            return x.permute(0, 2, 3, 1)
+        return x.permute(0, 2, 3, 1).to(BF16)
     if x.dtype != torch.float32:
         x = x.float()
     return ops.nchw_f32_to_nhwc_bf16(x)

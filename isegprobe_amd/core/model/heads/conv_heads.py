@@ -39,7 +39,7 @@ class ConvModule(nn.Module):
 
     def takes_f16(self):
         """The f16 conv kernel exists for 3x3 layers whose output channels tile into 192-channel blocks."""
-        return self.conv.kernel_size == (3, 3) and self.conv.out_channels % 192 == 0 and self.conv.in_channels % 64 == 0
+        return self.conv.kernel_size == (3, 3) and self.conv.out_channels % 192 == 0 and self.conv.in_channels % 64 == 0  # (fused epilogues need 192-channel blocks)
 
     def run(self, x_nhwc):
         if grad_mode(self.conv) or (torch.is_grad_enabled() and x_nhwc.requires_grad):
@@ -75,11 +75,13 @@ class _StackedHead(BaseClassifierHead):
             for _ in range(num_layers)])
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y, layers = to_nhwc_bf16(x), list(self.convs)
-        if (HEAD_F16 and layers and all(l.takes_f16() for l in layers) and self.num_classes == 1
-                and not (grad_mode(self) or (torch.is_grad_enabled() and y.requires_grad))):
+        layers = list(self.convs)
+        f16_ok = (HEAD_F16 and layers and all(l.takes_f16() for l in layers) and self.num_classes == 1
+                  and not (grad_mode(self) or (torch.is_grad_enabled() and x.requires_grad)))
+        y = to_nhwc_bf16(x, keep_f16=f16_ok)
+        if f16_ok and y.dtype != ops.F16:
             # inference: the convolutions run on IEEE-half operands (weights and the hidden map keep three more
-            # mantissa bits; the bf16 input converts exactly) -- one extra pass over the input map
+            # mantissa bits; a bf16 input converts exactly) -- one extra pass over a map that is not half already
             y = ops.to_f16(y)
         return self._tail(y, layers)
 

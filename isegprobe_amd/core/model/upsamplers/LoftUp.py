@@ -33,6 +33,9 @@ from .._guidance_cache import GuidanceCache
 from . import BaseUpsampler
 
 
+LOFTUP_F16 = os.environ.get("ISEGPROBE_LOFTUP_F16", "1") != "0"  # IEEE-half inference stream (see _run)
+
+
 def _pad64(n):
     return (n + 63) // 64 * 64
 
@@ -137,11 +140,19 @@ class LoftUpUpsampler(BaseUpsampler):
         self._gcache = GuidanceCache()
         self._pe_cache = {}
 
+    def _hdp(self):
+        lu = self.upsampler.upsampler
+        hd = (lu.dim + lu.lr_pe_dim) // lu.num_heads
+        return 64 if hd <= 64 else (128 if hd <= 128 else 256)
+
     def _bn_train(self):
         return self.upsampler.upsampler.first_conv[2].training
 
     # ---- weight packing (bf16, padded, BN folded unless the module is in training mode)
-    def packed(self, train=False):
+    def packed(self, train=False, half=False):
+        """``half``: kernel-layout weights in IEEE half (from the fp32 parameters) for the half-precision inference stream."""
+        wd = ops.F16 if half else BF16
+
         def build():
             lu, cn = self.upsampler.upsampler, self.upsampler.channelnorm
             dev = cn.norm.weight.device
@@ -157,7 +168,7 @@ class LoftUpUpsampler(BaseUpsampler):
             def padded(w, rows, cols):  # [r, k] -> zero-padded bf16 [rows, cols]
                 out = torch.zeros(rows, cols, device=dev, dtype=torch.float32)
                 out[:w.shape[0], :w.shape[1]] = w
-                return out.to(BF16).contiguous()
+                return out.to(wd).contiguous()
 
             def padvec(v, n):
                 out = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -173,14 +184,14 @@ class LoftUpUpsampler(BaseUpsampler):
                     b = (conv.bias.detach().float() - bn.running_mean.float()) * s + bn.bias.detach().float()
                 wt = torch.zeros(cout_p, 3, 3, cin_p, device=dev)
                 wt[:w.shape[0], :, :, :w.shape[1]] = w.permute(0, 2, 3, 1)
-                return wt.reshape(cout_p, 9 * cin_p).to(BF16).contiguous(), padvec(b, cout_p)
+                return wt.reshape(cout_p, 9 * cin_p).to(wd).contiguous(), padvec(b, cout_p)
 
             def head_rows(w, b):  # [heads*hd, k] rows -> [heads*hdp, cp]; bias likewise
                 wo = torch.zeros(heads, hdp, cp, device=dev)
                 wo[:, :hd, :c] = w.detach().float().reshape(heads, hd, c)
                 bo = torch.zeros(heads, hdp, device=dev)
                 bo[:, :hd] = b.detach().float().reshape(heads, hd)
-                return wo.reshape(heads * hdp, cp).to(BF16).contiguous(), bo.reshape(-1).contiguous()
+                return wo.reshape(heads * hdp, cp).to(wd).contiguous(), bo.reshape(-1).contiguous()
 
             P = dict(C=C, c=c, cp=cp, fin=fin, fin_p=fin_p, heads=heads, hd=hd, hdp=hdp,
                      cn_w=f32(cn.norm.weight), cn_b=f32(cn.norm.bias), cn_eps=cn.norm.eps,
@@ -204,7 +215,7 @@ class LoftUpUpsampler(BaseUpsampler):
                 L["wv"], L["bv"] = head_rows(ipw[2 * E:], ipb[2 * E:])
                 wo = torch.zeros(cp, heads, hdp, device=dev)  # out_proj: input index = head*hd + d
                 wo[:c, :, :hd] = ca.attention.out_proj.weight.detach().float().reshape(c, heads, hd)
-                L["wo"], L["bo"] = wo.reshape(cp, heads * hdp).to(BF16).contiguous(), padvec(f32(ca.attention.out_proj.bias), cp)
+                L["wo"], L["bo"] = wo.reshape(cp, heads * hdp).to(wd).contiguous(), padvec(f32(ca.attention.out_proj.bias), cp)
                 L["ff_nw"], L["ff_nb"], L["ff_eps"] = f32(ff.net[0].weight), f32(ff.net[0].bias), ff.net[0].eps
                 hid = ff.net[1].weight.shape[0]
                 hid_p = _pad64(hid)
@@ -221,13 +232,17 @@ class LoftUpUpsampler(BaseUpsampler):
             return P
         if train:  # raw weights: independent of the running statistics the train-mode forward keeps updating
             return self._packed_train.get(self._packed_train.tensors_of(lambda: list(self.upsampler.parameters())), build)
-        params = self._packed.tensors_of(lambda: list(self.upsampler.parameters()) + [b for n, b in self.upsampler.named_buffers() if "running" in n])
-        return self._packed.get(params, build)
+        cache = self._packed
+        if half:
+            from .._tensor import PackedCache
+            cache = self.__dict__.setdefault("_packed_half", PackedCache())
+        params = cache.tensors_of(lambda: list(self.upsampler.parameters()) + [b for n, b in self.upsampler.named_buffers() if "running" in n])
+        return cache.get(params, build)
 
-    def _lr_pe(self, h, w, device):
+    def _lr_pe(self, h, w, device, dtype=BF16):
         """Sine PE of the LR grid (ImplicitFeaturizer(color_feats=False, n_freqs=5), layers.py:107-158):
         depends only on (h, w) and the learnt biases -> a [h*w, 20] table, cached."""
-        key = (h, w, str(device))
+        key = (h, w, str(device), dtype)
         if key not in self._pe_cache:
             with torch.no_grad():
                 lu = self.upsampler.upsampler
@@ -238,7 +253,7 @@ class LoftUpUpsampler(BaseUpsampler):
                 bias = lu.lr_pe.biases.detach().float().to(device)
                 s = torch.sin(feats + bias[0].reshape(5, 2, 1, 1)).reshape(10, h, w)
                 c = torch.cos(feats + bias[1].reshape(5, 2, 1, 1)).reshape(10, h, w)
-                self._pe_cache[key] = torch.cat([s, c], 0).permute(1, 2, 0).reshape(h * w, 20).to(BF16).contiguous()
+                self._pe_cache[key] = torch.cat([s, c], 0).permute(1, 2, 0).reshape(h * w, 20).to(dtype).contiguous()
         return self._pe_cache[key]
 
     def forward(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
@@ -252,23 +267,28 @@ class LoftUpUpsampler(BaseUpsampler):
     def _run(self, src, guidance, save):
         """The whole upsampler on NHWC bf16 LR features; `save` (a dict) collects what the backward needs."""
         train = self._bn_train()
-        P = self.packed(train)
+        # inference runs the whole stream -- tokens, Fourier features, both convolutions, both cross-attention + feed-forward
+        # layers, the final projection and LayerNorms -- on IEEE half: its maps are LayerNorm-bounded, and the twelve bf16
+        # roundings between the ViT's tokens and the head were 2.5e-3 of the 2.7e-3 rms logit error of S/14 + LoftUp
+        half = save is None and not train and LOFTUP_F16 and self._hdp() in (128, 256)  # (the f16 attention's head dims)
+        dt = ops.F16 if half else BF16
+        P = self.packed(train, half)
         B, h, w, C = src.shape
         guidance = guidance.float().contiguous()
         H, W = guidance.shape[2:]
         c, cp, heads, hdp = P["c"], P["cp"], P["heads"], P["hdp"]
         M, T = B * H * W, h * w
         # ---- LR tokens: ChannelNorm(source) ++ sine PE, zero-padded to cp
-        kv = torch.zeros(B, T, cp, device=src.device, dtype=BF16)
-        kv[:, :, :C] = ops.layernorm(src.view(-1, C), P["cn_w"], P["cn_b"], P["cn_eps"]).view(B, T, C)
-        kv[:, :, C:c] = self._lr_pe(h, w, src.device)
+        kv = torch.zeros(B, T, cp, device=src.device, dtype=dt)
+        kv[:, :, :C] = ops.layernorm(src.view(-1, C), P["cn_w"], P["cn_b"], P["cn_eps"], out_dtype=dt).view(B, T, C)
+        kv[:, :, C:c] = self._lr_pe(h, w, src.device, dt)
         kv = kv.view(B * T, cp)
         # ---- queries: Fourier features -> ChannelNorm -> 2 x (conv3x3 + folded BN + ReLU).  Guidance-only: the
         # click loop reuses them (and the first layer's query projection) while the image is unchanged.
         def image_queries():
             mm = ops.minmax_nchw(guidance)
             f = ops.loftup_fourier_cn(guidance, mm, P["freqs"], P["bias_sin"], P["bias_cos"], P["fc_cn_w"], P["fc_cn_b"],
-                                      P["fin_p"], P["fc_cn_eps"])
+                                      P["fin_p"], P["fc_cn_eps"], out_dtype=dt)
             if train:
                 from .LiFT import LiFTUpsampler
                 fc = self.upsampler.upsampler.first_conv
@@ -283,11 +303,11 @@ class LoftUpUpsampler(BaseUpsampler):
             save.update(kv=kv, layers=[], geom=(B, h, w, C, H, W), train=train)
         for li, L in enumerate(P["layers"]):
             def project_q(x=x, L=L):
-                qn = ops.layernorm(x, L["nq_w"], L["nq_b"], L["nq_eps"], D=c, ld_out=cp)
+                qn = ops.layernorm(x, L["nq_w"], L["nq_b"], L["nq_eps"], D=c, ld_out=cp, out_dtype=dt)
                 return ops.linear(qn, L["wq"], L["bq"]).view(B, H * W, heads, hdp)
             # the first layer's queries see the image only (x is still x0)
             q = self._gcache.get(guidance, id(P), "q0", project_q) if (li == 0 and not train) else project_q()
-            kn = ops.layernorm(kv, L["nkv_w"], L["nkv_b"], L["nkv_eps"], D=c, ld_out=cp)
+            kn = ops.layernorm(kv, L["nkv_w"], L["nkv_b"], L["nkv_eps"], D=c, ld_out=cp, out_dtype=dt)
             k = ops.linear(kn, L["wk"], L["bk"]).view(B, T, heads, hdp)
             v = ops.linear(kn, L["wv"], L["bv"]).view(B, T, heads, hdp)
             if save is None:
@@ -296,16 +316,16 @@ class LoftUpUpsampler(BaseUpsampler):
                 a, lse = ops.attention_lse(q, k, v, scale)
                 a = a.view(M, heads * hdp)
             x_mid = ops.linear_axpy_res(a, L["wo"], L["bo"], x, 1.0)        # cross-attention + residual
-            f = ops.layernorm(x_mid, L["ff_nw"], L["ff_nb"], L["ff_eps"], D=c, ld_out=cp)
+            f = ops.layernorm(x_mid, L["ff_nw"], L["ff_nb"], L["ff_eps"], D=c, ld_out=cp, out_dtype=dt)
             if save is None:
                 f = ops.linear(f, L["ff1_w"], L["ff1_b"], "gelu")
             else:
                 f, pre = ops.linear_gelu_save(f, L["ff1_w"], L["ff1_b"])
                 save["layers"].append(dict(x_in=x, q=q, k=k, v=v, a=a, lse=lse, x_mid=x_mid, pre=pre))
             x = ops.linear_axpy_res(f, L["ff2_w"], L["ff2_b"], x_mid, 1.0)  # feed-forward + residual
-        xn = ops.layernorm(x, P["tn_w"], P["tn_b"], P["tn_eps"], D=c, ld_out=cp)
+        xn = ops.layernorm(x, P["tn_w"], P["tn_b"], P["tn_eps"], D=c, ld_out=cp, out_dtype=dt)
         y = ops.linear(xn, P["fin_w"], P["fin_b"])                           # 1x1 conv c -> C
-        out = ops.layernorm(y, P["fln_w"], P["fln_b"], P["fln_eps"], D=C, ld_out=C)  # channel LayerNorm
+        out = ops.layernorm(y, P["fln_w"], P["fln_b"], P["fln_eps"], D=C, ld_out=C, out_dtype=dt)  # channel LayerNorm
         if save is not None:
             save.update(x_fin=x, y=y)
         return out.view(B, H, W, C)

@@ -50,7 +50,7 @@ struct Geo {
     }
 };
 
-template <int HD, int NW>
+template <int HD, int NW, bool F16 = false>  // F16: Q, K, V, P and O are IEEE half (isp_attention_fwd_f16)
 __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                         const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H,
                                                         int Lq, int Lk, long qsb, long qsl, long qsh, long ksb, long ksl,
@@ -147,7 +147,11 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf + k_off[kb][kk]);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+                if constexpr (F16)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, kf), __builtin_bit_cast(f16x8_t, qf[kk]),
+                                                                  s[kb], 0, 0, 0);
+                else
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
             }
         }
         // mask keys past Lk (last tile only; wave-uniform branch)
@@ -193,13 +197,20 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
             for (int ss = 0; ss < 2; ++ss) {
                 bf16x8 pf;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s[kb][8 * ss + j]);
+                for (int j = 0; j < 8; j += 2) {
+                    const unsigned pk = pack2o<!F16>(s[kb][8 * ss + j], s[kb][8 * ss + j + 1]);
+                    pf[j] = (short)(pk & 0xffffu), pf[j + 1] = (short)(pk >> 16);
+                }
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const s16x4 lo = tr_read(buf + v_off[db][kb][ss][0]);
                     const s16x4 hi = tr_read(buf + v_off[db][kb][ss][1]);
                     const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+                    if constexpr (F16)
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, vf), __builtin_bit_cast(f16x8_t, pf),
+                                                                      o[db], 0, 0, 0);
+                    else
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
                 }
             }
         __syncthreads();
@@ -218,19 +229,19 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = db * 32 + 8 * g4 + 4 * hh;
                 *reinterpret_cast<uint2*>(op + d) =
-                    make_uint2(pack2bf(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv),
-                               pack2bf(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
+                    make_uint2(pack2o<!F16>(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv),
+                               pack2o<!F16>(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
             }
     }
 }
 
-template <int HD, int NW = 4>
+template <int HD, int NW = 4, bool F16 = false>
 int launch_attention(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, long qsb,
                      long qsl, long qsh, long ksb, long ksl, long ksh, long osb, long osl, long osh, float scale,
                      float* lse, long lse_ld, hipStream_t s) {
     static bool attr_done = false;
     constexpr int QB = 32 * NW;
-    auto kern = attention_kernel<HD, NW>;
+    auto kern = attention_kernel<HD, NW, F16>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<HD>::LDS) != hipSuccess)
             return ISP_ERR_LAUNCH;
@@ -606,4 +617,26 @@ extern "C" int isp_attention_fwd_logit2(const void* Q, const void* K, const void
                                         long o_stride_h, void* stream) {
     return attention_fwd_impl(Q, K, V, O, B, H, Lq, Lk, head_dim, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
                               kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, stream, true);
+}
+
+// IEEE-half Q, K, V, O (and probabilities) for head_dim 128 / 256: LoftUp's cross-attention in its half-precision
+// inference stream (same layouts, strides and kernels as isp_attention_fwd).
+extern "C" int isp_attention_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
+                                     int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
+                                     long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
+                                     float scale, void* stream) {
+    ISP_CHECK_ARG(Q && K && V && O && B > 0 && H > 0 && Lq > 0 && Lk > 0 && scale > 0.f);
+    ISP_CHECK_ARG((long)B * H <= 65535);
+    ISP_CHECK_ARG(q_stride_b % 8 == 0 && q_stride_l % 8 == 0 && q_stride_h % 8 == 0);
+    ISP_CHECK_ARG(kv_stride_b % 8 == 0 && kv_stride_l % 8 == 0 && kv_stride_h % 8 == 0);
+    ISP_CHECK_ARG(o_stride_b % 4 == 0 && o_stride_l % 4 == 0 && o_stride_h % 4 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = (long)((Lq + 255) / 256) * B * H >= 2048;  // 256-query blocks once they still fill the chip several times
+#define ISP_ATT_F16(HD, NW)                                                                                                  \
+    launch_attention<HD, NW, true>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l, \
+                                   kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, nullptr, 0, s)
+    if (head_dim == 128) return wide ? ISP_ATT_F16(128, 8) : ISP_ATT_F16(128, 4);
+    if (head_dim == 256) return wide ? ISP_ATT_F16(256, 8) : ISP_ATT_F16(256, 4);
+#undef ISP_ATT_F16
+    return ISP_ERR_UNSUPPORTED;
 }

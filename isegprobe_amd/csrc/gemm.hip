@@ -286,7 +286,8 @@ struct EpResidual {  // x[m][n] += gamma[n] * (v + bias[n])   (LayerScale + resi
     }
 };
 
-struct EpAxpyResBf16 {  // out = res + alpha * (v + bias), bf16 in/out (FeatUp JBUStack final fix-up)
+template <bool F16 = false>
+struct EpAxpyResBf16 {  // out = res + alpha * (v + bias), bf16 (or half) in/out (FeatUp JBUStack final fix-up, LoftUp residuals)
     bf16_t* out;
     const bf16_t* res;
     const float* bias;
@@ -297,11 +298,11 @@ struct EpAxpyResBf16 {  // out = res + alpha * (v + bias), bf16 in/out (FeatUp J
     __device__ __forceinline__ Cols cols(int n) const { return load_bias(bias, n); }
     __device__ __forceinline__ Pre pre(long m, int n) const { return *reinterpret_cast<const uint2*>(res + (size_t)m * ldo + n); }
     __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c, const Pre& u) const {
-        const float r0 = __uint_as_float(u.x << 16) + alpha * (v[0] + c.b.x);
-        const float r1 = __uint_as_float(u.x & 0xffff0000u) + alpha * (v[1] + c.b.y);
-        const float r2 = __uint_as_float(u.y << 16) + alpha * (v[2] + c.b.z);
-        const float r3 = __uint_as_float(u.y & 0xffff0000u) + alpha * (v[3] + c.b.w);
-        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = make_uint2(pack2bf(r0, r1), pack2bf(r2, r3));
+        const float x0 = F16 ? h_lo(u.x) : __uint_as_float(u.x << 16), x1 = F16 ? h_hi(u.x) : __uint_as_float(u.x & 0xffff0000u);
+        const float x2 = F16 ? h_lo(u.y) : __uint_as_float(u.y << 16), x3 = F16 ? h_hi(u.y) : __uint_as_float(u.y & 0xffff0000u);
+        const float r0 = x0 + alpha * (v[0] + c.b.x), r1 = x1 + alpha * (v[1] + c.b.y);
+        const float r2 = x2 + alpha * (v[2] + c.b.z), r3 = x3 + alpha * (v[3] + c.b.w);
+        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = make_uint2(pack2o<!F16>(r0, r1), pack2o<!F16>(r2, r3));
     }
 };
 
@@ -510,7 +511,7 @@ __device__ __forceinline__ void staged_epilogue(const EP& ep, f32x4 (&acc)[TM][T
     }
 }
 
-template <class CFG, class AL, class EP>
+template <class CFG, class AL, class EP, bool F16 = false>  // F16: IEEE-half operands (isp_gemm_f16), same MFMA rate
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL al, const bf16_t* __restrict__ Wt, long M,
                                                                           int N, int K, int tiles_n, int nwg, EP ep) {
     constexpr int BM = CFG::BM, BN = CFG::BN, NW = CFG::NW, TM = CFG::TM, TN = CFG::TN, PA = CFG::PA, PW = CFG::PW;
@@ -583,7 +584,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+                    if constexpr (F16)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fw[ni]),
+                                                                            __builtin_bit_cast(f16x8_t, fa[mi]), acc[mi][ni], 0, 0, 0);
+                    else
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[mi][ni], 0, 0, 0);
         }
     };
 
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
     }
 }
 
-template <class CFG, class AL, class EP>
+template <class CFG, bool F16 = false, class AL, class EP>
 int launch_gemm(AL al, const void* Wt, long M, int N, int K, EP ep, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 4 != 0) return ISP_ERR_INVALID;
     const long tiles_m = al.template num_tiles<CFG::BM>();
@@ -659,7 +664,7 @@ int launch_gemm(AL al, const void* Wt, long M, int N, int K, EP ep, hipStream_t 
     const long nwg = tiles_m * tiles_n;
     if (nwg > 0x7fffffffL) return ISP_ERR_INVALID;
     static bool attr_done = false;  // per instantiation; raising the dynamic-LDS cap is idempotent
-    auto kern = gemm_tile_kernel<CFG, AL, EP>;
+    auto kern = gemm_tile_kernel<CFG, AL, EP, F16>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS) != hipSuccess)
             return ISP_ERR_LAUNCH;
@@ -1117,12 +1122,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel_192(const bf16_t
                                                                     int nwg, EP ep) {
     conv3x3_patch4_body<EP, 6, F16>(in, Wt, H, W, C, N, tiles_x, tiles_y, tiles_n, nwg, ep);
 }
-template <class EP>
+template <class EP, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_patch4_kernel_128(const bf16_t* __restrict__ in,
                                                                     const bf16_t* __restrict__ Wt, int H, int W, int C,
                                                                     int N, int tiles_x, int tiles_y, int tiles_n,
                                                                     int nwg, EP ep) {
-    conv3x3_patch4_body<EP, 4>(in, Wt, H, W, C, N, tiles_x, tiles_y, tiles_n, nwg, ep);
+    conv3x3_patch4_body<EP, 4, F16>(in, Wt, H, W, C, N, tiles_x, tiles_y, tiles_n, nwg, ep);
 }
 
 template <int TN, class EP, bool F16 = false>
@@ -1135,9 +1140,8 @@ int launch_conv_patch4(const void* in, const void* Wt, int B, int H, int W, int 
     static bool attr_done = false;
     static_assert(TN == 6 || TN == 4);
     void (*kern)(const bf16_t*, const bf16_t*, int, int, int, int, int, int, int, int, EP);
-    static_assert(!F16 || TN == 6, "the f16 form exists for 192-channel blocks only");
     if constexpr (TN == 6) kern = conv3x3_patch4_kernel_192<EP, F16>;
-    else kern = conv3x3_patch4_kernel_128<EP>;
+    else kern = conv3x3_patch4_kernel_128<EP, F16>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess)
             return ISP_ERR_LAUNCH;
@@ -1244,7 +1248,7 @@ int dispatch_epilogue(AL al, const void* Wt, long M, int N, int K, const isp_epi
             if constexpr (!((KINDS >> ISP_EP_AXPY_RES_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
             if (!e->res) return ISP_ERR_INVALID;
             return launch_gemm<CFG>(al, Wt, M, N, K,
-                               EpAxpyResBf16{(bf16_t*)e->out, (const bf16_t*)e->res, e->bias, e->alpha, ldo}, s);
+                               EpAxpyResBf16<>{(bf16_t*)e->out, (const bf16_t*)e->res, e->bias, e->alpha, ldo}, s);
             }
         case ISP_EP_BIAS_TAPS_RELU_BF16:
             if constexpr (!((KINDS >> ISP_EP_BIAS_TAPS_RELU_BF16) & 1u)) return ISP_ERR_UNSUPPORTED; else {
@@ -1310,6 +1314,37 @@ extern "C" int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, in
     return run(Cfg128{});
 }
 
+// IEEE-half operands and 16-bit outputs (LoftUp's inference stream: three more mantissa bits on every operand and map of
+// its two cross-attention + feed-forward layers).  Epilogues: bias, bias + GELU, residual add (res / out half).
+extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* e, void* stream) {
+    ISP_CHECK_ARG(A && Wt && e && e->out && lda >= K && lda % 8 == 0);
+    const long ldo = e->ldo > 0 ? e->ldo : N;
+    if (ldo % 4 != 0) return ISP_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    auto run = [&](auto cfg) {
+        using CFG = decltype(cfg);
+        DenseA<CFG::PA> al;
+        al.A = (const bf16_t*)A;
+        al.lda = lda;
+        al.M = M;
+        switch (e->kind) {
+            case ISP_EP_BIAS_BF16:
+                return launch_gemm<CFG, true>(al, Wt, M, N, K, EpBiasActBf16<ACT_NONE, true>{(bf16_t*)e->out, e->bias, ldo}, s);
+            case ISP_EP_BIAS_GELU_BF16:
+                return launch_gemm<CFG, true>(al, Wt, M, N, K, EpBiasActBf16<ACT_GELU, true>{(bf16_t*)e->out, e->bias, ldo}, s);
+            case ISP_EP_AXPY_RES_BF16:
+                if (!e->res) return (int)ISP_ERR_INVALID;
+                return launch_gemm<CFG, true>(al, Wt, M, N, K,
+                                              EpAxpyResBf16<true>{(bf16_t*)e->out, (const bf16_t*)e->res, e->bias, e->alpha, ldo}, s);
+            default:
+                return (int)ISP_ERR_UNSUPPORTED;
+        }
+    };
+    if ((M + 255) / 256 >= 512 && N >= 384) return run(CfgConv192{});
+    if (((M + 127) / 128) * ((N + 127) / 128) < 256) return run(Cfg64{});
+    return run(Cfg128{});
+}
+
 // A/B switch for experiments: ISEGPROBE_CONV_ENGINE=tile selects the generic tile engine for every conv
 static bool ep_forces_tile_engine() {
     static int v = -1;
@@ -1341,8 +1376,19 @@ extern "C" int isp_conv3x3_nhwc_f16(const void* in, const void* Wt, int B, int H
     const long M = (long)B * H * W;
     ISP_CHECK_ARG(M <= 0x7fffffffL);
     const long ldo = e->ldo > 0 ? e->ldo : N;
-    if (N % 192 != 0 || ldo % 8 != 0 || (reinterpret_cast<size_t>(e->out) & 15) != 0) return ISP_ERR_UNSUPPORTED;
+    if (ldo % 8 != 0 || (reinterpret_cast<size_t>(e->out) & 15) != 0) return ISP_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (N % 192 != 0) {  // 128-channel blocks (LoftUp's 448-channel maps): plain epilogues only
+        if (!patch128_ok(N)) return ISP_ERR_UNSUPPORTED;
+        switch (e->kind) {
+            case ISP_EP_BIAS_BF16:
+                return launch_conv_patch4<4, EpBiasActBf16<ACT_NONE, true>, true>(in, Wt, B, H, W, C, N, {(bf16_t*)e->out, e->bias, ldo}, s);
+            case ISP_EP_BIAS_RELU_BF16:
+                return launch_conv_patch4<4, EpBiasActBf16<ACT_RELU, true>, true>(in, Wt, B, H, W, C, N, {(bf16_t*)e->out, e->bias, ldo}, s);
+            default:
+                return ISP_ERR_UNSUPPORTED;
+        }
+    }
     switch (e->kind) {
         case ISP_EP_BIAS_BF16:
             return launch_conv_patch4<6, EpBiasActBf16<ACT_NONE, true>, true>(in, Wt, B, H, W, C, N, {(bf16_t*)e->out, e->bias, ldo}, s);

@@ -58,7 +58,10 @@ __device__ __forceinline__ float linspace_pm1(int i, int n) {
 // output row of `ldo` bf16 (channels past 203 zero-filled).
 //   feats5 = [grid_h, grid_w, c0, c1, c2],  ci = (img - lo_i) / max(hi_i - lo_i, 1e-4) - 0.5
 //   sin block: idx = f*5 + m -> sin(feats5[m] * freq[f] + bias_sin[idx]);  cos block likewise.
-template <class TOut>  // bf16 (product path) or fp32 (the fp32 checking mode, core/model/precise.py)
+struct half_out_t {  // IEEE-half output tag (bf16_t is a plain unsigned short)
+    unsigned short bits;
+};
+template <class TOut>  // bf16 / IEEE half (product path, training / inference) or fp32 (the fp32 checking mode, core/model/precise.py)
 __global__ __launch_bounds__(256) void loftup_fourier_cn_kernel(const float* __restrict__ img,
                                                                  const float* __restrict__ mm /* [3][2] lo,hi */,
                                                                  const float* __restrict__ freqs,
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256) void loftup_fourier_cn_kernel(const float* __r
         if (ch < ldo) {
             const float o = ch < nfeat ? (v[i] - mean) * rstd * gamma[ch] + beta[ch] : 0.f;
             if constexpr (sizeof(TOut) == 4) orow[ch] = o;
+            else if constexpr (sizeof(TOut) == 2 && !__is_same(TOut, bf16_t)) orow[ch].bits = (unsigned short)(pack2h(o, 0.f) & 0xffffu);
             else orow[ch] = f2bf(o);
         }
     }
@@ -158,5 +162,16 @@ extern "C" int isp_loftup_fourier_cn_f32(const float* image, const float* minmax
     const long npix = (long)B * H * W;
     loftup_fourier_cn_kernel<float><<<(unsigned)((npix + 3) / 4), 256, 0, (hipStream_t)stream>>>(
         image, minmax_c2, freqs, bias_sin, bias_cos, gamma, beta, out_f32, H, W, n_freqs, ldo, eps, npix);
+    return isp_launch_status();
+}
+
+extern "C" int isp_loftup_fourier_cn_f16(const float* image, const float* minmax_c2, const float* freqs, const float* bias_sin,
+                                         const float* bias_cos, const float* gamma, const float* beta, void* out_f16, int B,
+                                         int H, int W, int n_freqs, int ldo, float eps, void* stream) {
+    ISP_CHECK_ARG(image && minmax_c2 && freqs && bias_sin && bias_cos && gamma && beta && out_f16);
+    ISP_CHECK_ARG(B > 0 && H > 0 && W > 0 && n_freqs > 0 && 10 * n_freqs + 3 <= 256 && ldo >= 10 * n_freqs + 3 && ldo <= 256);
+    const long npix = (long)B * H * W;
+    loftup_fourier_cn_kernel<half_out_t><<<(unsigned)((npix + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+        image, minmax_c2, freqs, bias_sin, bias_cos, gamma, beta, (half_out_t*)out_f16, H, W, n_freqs, ldo, eps, npix);
     return isp_launch_status();
 }

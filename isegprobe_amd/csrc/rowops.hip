@@ -1,6 +1,7 @@
 // Row-wise HBM-bound kernels on the token / pixel axis: LayerNorm (fp32 stats), the
 // bilinear(align_corners=True) NHWC resize, the C->1 classifier, layout converters.
 #include "isp_common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------
 // LayerNorm over the last dim.  One wave per row; the row lives in registers (two-pass
@@ -8,6 +9,27 @@
 // Row remap: out row r reads input row  r + (r / group_out) * skip + skip_first  where
 // skip_first rows are dropped at the start of each group of group_in = group_out + skip
 // rows (used to drop the cls token: DINOv2.py:533-534).
+struct f16_t {  // IEEE-half storage tag (bf16_t is a plain unsigned short): same size, different conversion
+    unsigned short bits;
+};
+template <typename T>
+__device__ __forceinline__ float4 load4_as_float(const T* p) {
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const float4*>(p);
+    } else {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        if constexpr (std::is_same_v<T, f16_t>) return make_float4(h_lo(u.x), h_hi(u.x), h_lo(u.y), h_hi(u.y));
+        else return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                __uint_as_float(u.y & 0xffff0000u));
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store4_from_float(T* p, float4 o) {
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(p) = o;
+    else if constexpr (std::is_same_v<T, f16_t>) *reinterpret_cast<uint2*>(p) = make_uint2(pack2h(o.x, o.y), pack2h(o.z, o.w));
+    else *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+}
+
 template <typename TIN, typename TOUT, int MAXV>  // MAXV: float4 chunks per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ x, TOUT* __restrict__ y,
                                                          const float* __restrict__ gamma,
@@ -25,13 +47,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane + i * 64;
         if (c < nchunk) {
-            if constexpr (sizeof(TIN) == 4) {
-                v[i] = *reinterpret_cast<const float4*>(xr + c * 4);
-            } else {
-                const uint2 u = *reinterpret_cast<const uint2*>(xr + c * 4);
-                v[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                                   __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-            }
+            v[i] = load4_as_float(xr + c * 4);
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         } else {
             v[i] = make_float4(0, 0, 0, 0);
@@ -68,11 +84,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
             o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z;
             o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            if constexpr (sizeof(TOUT) == 4) {
-                *reinterpret_cast<float4*>(yr + c * 4) = o;
-            } else {
-                *reinterpret_cast<uint2*>(yr + c * 4) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
-            }
+            store4_from_float(yr + c * 4, o);
         }
     }
 }
@@ -106,6 +118,10 @@ extern "C" int isp_layernorm_fwd(const void* x, void* y, const float* gamma, con
     if (in_dtype == ISP_F32 && out_dtype == ISP_F32) return launch_ln<float, float>(x, y, gamma, beta, rows, D, eps, group_out, skip, ld_in, ld_out, s);
     if (in_dtype == ISP_BF16 && out_dtype == ISP_BF16) return launch_ln<bf16_t, bf16_t>(x, y, gamma, beta, rows, D, eps, group_out, skip, ld_in, ld_out, s);
     if (in_dtype == ISP_BF16 && out_dtype == ISP_F32) return launch_ln<bf16_t, float>(x, y, gamma, beta, rows, D, eps, group_out, skip, ld_in, ld_out, s);
+    // IEEE-half rows (LoftUp's inference stream): from bf16 tokens, fp32 or half maps; to half
+    if (in_dtype == ISP_BF16 && out_dtype == ISP_F16) return launch_ln<bf16_t, f16_t>(x, y, gamma, beta, rows, D, eps, group_out, skip, ld_in, ld_out, s);
+    if (in_dtype == ISP_F16 && out_dtype == ISP_F16) return launch_ln<f16_t, f16_t>(x, y, gamma, beta, rows, D, eps, group_out, skip, ld_in, ld_out, s);
+    if (in_dtype == ISP_F32 && out_dtype == ISP_F16) return launch_ln<float, f16_t>(x, y, gamma, beta, rows, D, eps, group_out, skip, ld_in, ld_out, s);
     return ISP_ERR_UNSUPPORTED;
 }
 

@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import Epilogue, IspError, check
 
 BF16 = torch.bfloat16
+F16 = torch.float16  # IEEE half: the FeatUp-JBU stack, the seg head's inference convolutions, LoftUp's inference stream
 
 
 def _stream():
@@ -92,21 +93,25 @@ def _epilogue(kind, out, ldo=0, bias=None, gamma=None, pos=None, tokens=0, res=N
 
 
 def gemm(A, Wt, ep, M=None):
-    """A [M,K] bf16 (row stride A.stride(0)), Wt [N,K] bf16, ep from _epilogue."""
-    _need(A, BF16, "A", contiguous=False)
-    _need(Wt, BF16, "Wt")
+    """A [M,K] bf16 (row stride A.stride(0)), Wt [N,K] bf16, ep from _epilogue.  Both IEEE half: the f16 engine (bias,
+    bias + GELU and residual epilogues only; 16-bit outputs are half)."""
+    half = A.dtype == F16
+    _need(A, F16 if half else BF16, "A", contiguous=False)
+    _need(Wt, F16 if half else BF16, "Wt")
     if A.stride(1) != 1:
         raise IspError("A must be row-major")
     N, K = Wt.shape
     M = A.shape[0] if M is None else M
-    check(_lib.lib().isp_gemm_bf16(_p(A), A.stride(0), _p(Wt), M, N, K, ctypes.byref(ep), _stream()), "isp_gemm_bf16")
+    fn, name = (_lib.lib().isp_gemm_f16, "isp_gemm_f16") if half else (_lib.lib().isp_gemm_bf16, "isp_gemm_bf16")
+    check(fn(_p(A), A.stride(0), _p(Wt), M, N, K, ctypes.byref(ep), _stream()), name)
 
 
-def linear(A, Wt, bias=None, act=None, out_dtype=BF16):
-    """bf16 A [M,K] x Wt[N,K]^T + bias, optional 'relu'/'gelu'; returns [M,N]."""
+def linear(A, Wt, bias=None, act=None, out_dtype=None):
+    """bf16 (or f16) A [M,K] x Wt[N,K]^T + bias, optional 'relu'/'gelu'; returns [M,N] in A's dtype (or f32 for bf16 A)."""
     N = Wt.shape[0]
+    out_dtype = A.dtype if out_dtype is None else out_dtype
     out = torch.empty(A.shape[0], N, device=A.device, dtype=out_dtype)
-    if out_dtype == BF16:
+    if out_dtype == A.dtype:
         kind = {None: _lib.EP_BIAS_BF16, "relu": _lib.EP_BIAS_RELU_BF16, "gelu": _lib.EP_BIAS_GELU_BF16,
                 "quick_gelu": _lib.EP_BIAS_QGELU_BF16}[act]
     else:
@@ -176,13 +181,19 @@ def vit_mlp_fused_supported(D, hid):
     return (D, hid) == (384, 1536)
 
 
+def conv_takes_f16(N):
+    """Output-channel counts the f16 patch conv handles: 192-channel blocks, or 128-channel blocks wasting <= 15 %
+    (plain bias / ReLU epilogues only in that case)."""
+    return N % 192 == 0 or (N >= 128 and ((N + 127) // 128 * 128 - N) * 100 <= 15 * N)
+
+
 def _conv_entry(x, Wt):
     """The conv entry point for an operand pair: both bf16, or both IEEE half (the head behind FeatUp JBU)."""
     if x.dtype == F16:
         _need(x, F16, "x")
         _need(Wt, F16, "Wt")
-        if Wt.shape[0] % 192:
-            raise IspError("the f16 conv handles N % 192 == 0 only (convert to bf16 otherwise)")
+        if not conv_takes_f16(Wt.shape[0]):
+            raise IspError("the f16 conv needs output channels that tile into 192- or (nearly) 128-channel blocks")
         return _lib.lib().isp_conv3x3_nhwc_f16, "isp_conv3x3_nhwc_f16"
     _need(x, BF16, "x")
     _need(Wt, BF16, "Wt")
@@ -242,11 +253,14 @@ def conv3x3_relu_classifier(x, Wt, bias, wcls, bcls):
     return out
 
 
+_DTYPE_CODE = {torch.float32: _lib.ISP_F32, BF16: _lib.ISP_BF16, torch.float16: _lib.ISP_F16}
+
+
 def layernorm(x, gamma, beta, eps, out_dtype=BF16, group_out=0, skip=0, rows_out=None, D=None, ld_out=None):
-    """LayerNorm over the first D columns of a [rows, ld] f32/bf16 tensor (D defaults to ld); the
-    output has row stride ld_out (default D) with columns [D, ld_out) zero-filled."""
-    if x.dtype not in (torch.float32, BF16):
-        raise IspError("layernorm input must be f32 or bf16")
+    """LayerNorm over the first D columns of a [rows, ld] f32/bf16/f16 tensor (D defaults to ld); the
+    output (f32, bf16, or f16) has row stride ld_out (default D) with columns [D, ld_out) zero-filled."""
+    if x.dtype not in (torch.float32, BF16, F16):
+        raise IspError("layernorm input must be f32, bf16 or f16")
     _need(x, x.dtype, "x")
     ld_in = x.shape[-1]
     D = ld_in if D is None else D
@@ -254,8 +268,7 @@ def layernorm(x, gamma, beta, eps, out_dtype=BF16, group_out=0, skip=0, rows_out
     rows = x.numel() // ld_in if rows_out is None else rows_out
     out = torch.empty(rows, ld_out, device=x.device, dtype=out_dtype)
     check(_lib.lib().isp_layernorm_fwd(_p(x), _p(out), _p(gamma), _p(beta), rows, D, float(eps),
-                                       _lib.ISP_F32 if x.dtype == torch.float32 else _lib.ISP_BF16,
-                                       _lib.ISP_F32 if out_dtype == torch.float32 else _lib.ISP_BF16,
+                                       _DTYPE_CODE[x.dtype], _DTYPE_CODE[out_dtype],
                                        group_out, skip, ld_in, ld_out, _stream()), "isp_layernorm_fwd")
     return out
 
@@ -441,19 +454,19 @@ def attention_lse(q, k, v, scale):
 def attention(q, k, v, scale):
     """q [B,Lq,H,hd], k/v [B,Lk,H,hd] bf16, hd in {64,128} (any strides with unit last-dim stride)."""
     hd = q.shape[3]
+    half = q.dtype == F16  # (head_dim 128 / 256 only: LoftUp's inference stream)
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
-        _need(t, BF16, n, contiguous=False)
-        if t.stride(3) != 1 or t.shape[3] != hd or hd not in (64, 128, 256):
-            raise IspError(f"{n}: head_dim must be 64, 128 or 256 with unit stride")
+        _need(t, q.dtype if half else BF16, n, contiguous=False)
+        if t.stride(3) != 1 or t.shape[3] != hd or hd not in ((128, 256) if half else (64, 128, 256)):
+            raise IspError(f"{n}: head_dim must be 64, 128 or 256 with unit stride (128 or 256 for f16)")
     if k.stride() != v.stride():
         raise IspError("k and v must share strides")
     B, Lq, H, _ = q.shape
     Lk = k.shape[1]
-    out = torch.empty(B, Lq, H, hd, device=q.device, dtype=BF16)
-    check(_lib.lib().isp_attention_fwd(_p(q), _p(k), _p(v), _p(out), B, H, Lq, Lk, hd,
-                                       q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
-                                       out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()),
-          "isp_attention_fwd")
+    out = torch.empty(B, Lq, H, hd, device=q.device, dtype=q.dtype)
+    fn, name = (_lib.lib().isp_attention_fwd_f16, "isp_attention_fwd_f16") if half else (_lib.lib().isp_attention_fwd, "isp_attention_fwd")
+    check(fn(_p(q), _p(k), _p(v), _p(out), B, H, Lq, Lk, hd, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1),
+             k.stride(2), out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()), name)
     return out
 
 
@@ -591,7 +604,6 @@ def jbu_tables(G, device):
     return _JBU_TABLES[key]
 
 
-F16 = torch.float16  # the dtype inside the FeatUp-JBU stack (records, fix-up MLP weights, maps between stages)
 
 
 def to_f16(x):
@@ -684,10 +696,10 @@ def jbu_apply_bwd(gout, kc):
 
 
 def linear_axpy_res(A, Wt, bias, res, alpha):
-    """bf16: res + alpha * (A Wt^T + bias)."""
-    _need(res, BF16, "res")
+    """bf16 (or f16, all operands alike): res + alpha * (A Wt^T + bias)."""
+    _need(res, A.dtype, "res")
     N = Wt.shape[0]
-    out = torch.empty(A.shape[0], N, device=A.device, dtype=BF16)
+    out = torch.empty(A.shape[0], N, device=A.device, dtype=A.dtype)
     gemm(A, Wt, _epilogue(_lib.EP_AXPY_RES_BF16, out, N, bias, res=res, alpha=alpha))
     return out
 
@@ -722,7 +734,8 @@ def loftup_fourier_cn(image, mm, freqs, bias_sin, bias_cos, gamma, beta, ldo, ep
     _need(image, torch.float32, "image")
     B, _, H, W = image.shape
     out = torch.empty(B, H, W, ldo, device=image.device, dtype=out_dtype)
-    fn = _lib.lib().isp_loftup_fourier_cn if out_dtype == BF16 else _lib.lib().isp_loftup_fourier_cn_f32
+    fn = {BF16: _lib.lib().isp_loftup_fourier_cn, F16: _lib.lib().isp_loftup_fourier_cn_f16,
+          torch.float32: _lib.lib().isp_loftup_fourier_cn_f32}[out_dtype]
     check(fn(_p(image), _p(mm), _p(freqs), _p(bias_sin), _p(bias_cos), _p(gamma), _p(beta), _p(out), B, H, W,
              freqs.numel(), ldo, float(eps), _stream()), "isp_loftup_fourier_cn")
     return out

@@ -417,3 +417,47 @@ def test_sigmoid_gelu_far_from_zero(ops):
     hid = F.gelu(torch.einsum("bchw,nc->bhwn", g, w0) + b0)
     refp = hid @ w3.t() + b3
     assert (proj - refp).abs().max().item() < 2e-2 * refp.abs().max().item()
+
+
+def test_f16_stream_kernels(ops):
+    """IEEE-half forms used by LoftUp's inference stream: LayerNorm (bf16 / f16 / f32 in, f16 out), the dense GEMM with its
+    bias, bias + GELU and residual epilogues, head_dim-128 / 256 attention -- each against fp32 on the half-rounded
+    operands, and each clearly tighter than its bf16 twin."""
+    torch.manual_seed(12)
+    M, K, N = 1000, 448, 512
+    x = torch.randn(M, K, device="cuda") * 3 + 0.5
+    g, b = torch.randn(K, device="cuda") * 0.3 + 1, torch.randn(K, device="cuda") * 0.2
+    ref = F.layer_norm(x, (K,), g, b, 1e-5)
+    for xin in (x, x.half(), bf(x)):
+        y = ops.layernorm(xin.contiguous(), g, b, 1e-5, out_dtype=torch.float16)
+        assert y.dtype == torch.float16
+        tol = 2e-3 if xin.dtype != BF else 3e-2
+        assert (y.float() - F.layer_norm(xin.float(), (K,), g, b, 1e-5)).abs().max().item() < tol
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / math.sqrt(K)
+    bias = torch.randn(N, device="cuda")
+    ah, wh = a.half(), w.half()
+    exact = a @ w.t() + bias
+    for act, fn in ((None, lambda t: t), ("gelu", F.gelu)):
+        y16 = ops.linear(ah, wh, bias, act)
+        yb = ops.linear(bf(a), bf(w), bias, act)
+        assert y16.dtype == torch.float16
+        e16, eb = (y16.float() - fn(exact)).abs().max().item(), (yb.float() - fn(exact)).abs().max().item()
+        assert (y16.float() - fn(ah.float() @ wh.float().t() + bias)).abs().max().item() < 4e-3
+        assert e16 < eb / 3, (e16, eb)
+    res = torch.randn(M, N, device="cuda")
+    yr = ops.linear_axpy_res(ah, wh, bias, res.half(), 0.5)
+    assert (yr.float() - (res.half().float() + 0.5 * (ah.float() @ wh.float().t() + bias))).abs().max().item() < 6e-3
+    for hd, real in ((128, 101), (256, 197)):
+        B, Lq, Lk, H = 2, 300, 260, 2
+        def mk(L):
+            t = torch.randn(B, L, H, hd, device="cuda")
+            t[..., real:] = 0
+            return t
+        q, k, v = mk(Lq), mk(Lk), mk(Lk)
+        o16 = ops.attention(q.half(), k.half(), v.half(), real ** -0.5)
+        ob = ops.attention(bf(q), bf(k), bf(v), real ** -0.5)
+        p = ((q.permute(0, 2, 1, 3) @ k.permute(0, 2, 3, 1)) * real ** -0.5).softmax(-1)
+        refo = (p @ v.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+        e16, eb = (o16.float() - refo).abs().max().item(), (ob.float() - refo).abs().max().item()
+        assert o16.dtype == torch.float16 and e16 < 3e-3 and e16 < eb / 2, (hd, e16, eb)

@@ -182,10 +182,11 @@ def test_s14_learned_upsamplers_vs_oracle(up, size, params):
     # LiFT 6.4e-3 (5.5e-3 here); FeatUp JBU 6.4e-3, rms 1.4e-3 -- 1.22e-2 while the stack's records and inter-stage maps
     # were bf16 (they are IEEE half now, tools/diag_jbu_precision.py) and 8.4e-3 .. 1.08e-2 depending on the image (rms
     # 1.9e-3, i.e. the maximum over 200 k pixels is a 5-sigma event) while the head's convolutions took bf16 operands: they
-    # now run in half behind the JBU stack (isp_conv3x3_nhwc_f16); LoftUp 1.36e-2, of which 2.75e-3 is a CONSTANT offset: rounding the head's weights to
-    # bf16 shifts the logits' 0.6 DC component by 0.45 % (the fp32 oracle on bf16-rounded head weights alone shows it) --
-    # north_star's 1e-2 holds for LiFT and JBU; LoftUp is held to 1.5e-2.
-    gate = {"lift": 1e-2, "jbu_featup": 1e-2, "loftup": 1.5e-2}[up]
+    # now run in half behind the JBU stack (isp_conv3x3_nhwc_f16); LoftUp 3.3e-3, rms 0.8e-3 -- 1.36e-2 / 2.7e-3 while its
+    # inference stream (tokens, Fourier features, both convolutions, both cross-attention + feed-forward layers, final
+    # projection and LayerNorms: twelve roundings between the ViT's tokens and the head) was bf16; it is IEEE half now.
+    # north_star's 1e-2 holds for all three.
+    gate = {"lift": 1e-2, "jbu_featup": 1e-2, "loftup": 1e-2}[up]
     assert err.max().item() <= gate, err.max().item()
     assert err.pow(2).mean().sqrt().item() <= 4e-3
     assert _mask_agreement(y, ref) == 1.0
@@ -486,7 +487,7 @@ def test_cfg4_vitb14_loftup_forward_and_gradients_vs_oracle():
     err = (y - ref).abs()
     print(f"cfg4 B/14+LoftUp(768)@224: max|logit err| {err.max():.4g} rms {err.pow(2).mean().sqrt():.4g}, logit range "
           f"{ref.min():.3f}..{ref.max():.3f}, mask agreement {_mask_agreement(y, ref):.6f}")
-    assert err.max().item() <= 1.5e-2, err.max().item()  # absolute, centred logits; see test_s14_learned_upsamplers_vs_oracle
+    assert err.max().item() <= 1e-2, err.max().item()  # absolute, centred logits (measured 3.1e-3); see test_s14_learned_upsamplers_vs_oracle
     assert _mask_agreement(y, ref) == 1.0
     model.train()
     model.upsampler.eval()  # same BatchNorm mode as the oracle pass above (DataParallelTrainer(frozen_bn_batch_stats=False)); the
