@@ -355,7 +355,7 @@ def run_forward(args):
     # beside the headline as `alt_head_bf16`, never as `value` -- the half form costs ~3 % (its multipliers draw more power
     # and the socket is at its limit during these kernels) and buys the logit-error margin DESIGN.md section 4 describes.
     dt_bf16 = None
-    if getattr(model, "head_f16", False) and fused_jbu and world == 1:
+    if getattr(model, "head_f16", False) and fused_jbu and world == 1 and not args.no_alt:
         from isegprobe_amd.core.model.heads import conv_heads
         saved = (model.head_f16, conv_heads.HEAD_F16)
         model.head_f16 = conv_heads.HEAD_F16 = False
@@ -569,6 +569,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="batch-8 CPU baseline as the median of 3 runs (slow)")
     ap.add_argument("--no-stages", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second timed region (bf16 head convolutions, alt_head_bf16)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     train = args.mode == "train"

@@ -24,7 +24,7 @@ class ConvModule(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding)
         self.activate = nn.ReLU(inplace=True)
-        self._packed = PackedCache()
+        self._packed, self._packed_f16 = PackedCache(), PackedCache()
 
     def packed(self, dtype=BF16):
         """Kernel-layout weights in ``dtype``: bf16, or IEEE half for the f16 form of the 3x3 conv (``takes_f16``)."""
@@ -34,7 +34,7 @@ class ConvModule(nn.Module):
             # [N, C, kh, kw] -> [N, kh*kw*C] (tap-major, channel-minor: the implicit-GEMM K order)
             return (w.permute(0, 2, 3, 1).reshape(n, -1).to(dtype).contiguous(),
                     self.conv.bias.detach().float().contiguous())
-        cache = self._packed if dtype == BF16 else self.__dict__.setdefault("_packed_f16", PackedCache())
+        cache = self._packed if dtype == BF16 else self._packed_f16
         return cache.get((self.conv.weight, self.conv.bias), build)
 
     def takes_f16(self):

@@ -136,7 +136,7 @@ class LoftUpUpsampler(BaseUpsampler):
         super().__init__()
         self.upsampler = load_loftup_checkpoint(upsampler_path, n_dim, lr_pe_type, lr_size)
         self._packed = PackedCache()
-        self._packed_train = PackedCache()
+        self._packed_train, self._packed_half = PackedCache(), PackedCache()
         self._gcache = GuidanceCache()
         self._pe_cache = {}
 
@@ -232,10 +232,7 @@ class LoftUpUpsampler(BaseUpsampler):
             return P
         if train:  # raw weights: independent of the running statistics the train-mode forward keeps updating
             return self._packed_train.get(self._packed_train.tensors_of(lambda: list(self.upsampler.parameters())), build)
-        cache = self._packed
-        if half:
-            from .._tensor import PackedCache
-            cache = self.__dict__.setdefault("_packed_half", PackedCache())
+        cache = self._packed_half if half else self._packed
         params = cache.tensors_of(lambda: list(self.upsampler.parameters()) + [b for n, b in self.upsampler.named_buffers() if "running" in n])
         return cache.get(params, build)
 

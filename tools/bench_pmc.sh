@@ -5,7 +5,7 @@
 # Summaries: python tools/bench_pmc_parse.py  ->  profiles/r02_*.json / .csv
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 set -e
-ARGS="--no-stages --no-cpu-baseline"
+ARGS="--no-stages --no-cpu-baseline --no-alt"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_kstats -- python bench.py --steps 20 --warmup 5 $ARGS > gpurun_out/r02_kstats.log 2>&1
 echo kstats done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r02_pmc_fetch -- python bench.py --steps 3 --warmup 1 $ARGS > gpurun_out/r02_pmc_fetch.log 2>&1
