@@ -141,7 +141,8 @@ int isp_attention_fwd_logit2(const void* Q, const void* K, const void* V, void* 
                              long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
                              void* stream);
 
-/* head_dim 128 / 256 on IEEE-half Q, K, V, O (LoftUp's cross-attention in its half-precision inference stream) */
+/* IEEE-half Q, K, V, O on the generic kernel (head_dim 64 / 128 / 256): LoftUp's cross-attention in its half-precision
+ * inference stream */
 int isp_attention_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, int head_dim,
                           long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
                           long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);

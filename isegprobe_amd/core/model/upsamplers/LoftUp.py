@@ -267,7 +267,7 @@ class LoftUpUpsampler(BaseUpsampler):
         # inference runs the whole stream -- tokens, Fourier features, both convolutions, both cross-attention + feed-forward
         # layers, the final projection and LayerNorms -- on IEEE half: its maps are LayerNorm-bounded, and the twelve bf16
         # roundings between the ViT's tokens and the head were 2.5e-3 of the 2.7e-3 rms logit error of S/14 + LoftUp
-        half = save is None and not train and LOFTUP_F16 and self._hdp() in (128, 256)  # (the f16 attention's head dims)
+        half = save is None and not train and LOFTUP_F16
         dt = ops.F16 if half else BF16
         P = self.packed(train, half)
         B, h, w, C = src.shape

@@ -619,7 +619,7 @@ extern "C" int isp_attention_fwd_logit2(const void* Q, const void* K, const void
                               kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, stream, true);
 }
 
-// IEEE-half Q, K, V, O (and probabilities) for head_dim 128 / 256: LoftUp's cross-attention in its half-precision
+// IEEE-half Q, K, V, O (and probabilities), head_dim 64 / 128 / 256 on the generic kernel: LoftUp's cross-attention in its half-precision
 // inference stream (same layouts, strides and kernels as isp_attention_fwd).
 extern "C" int isp_attention_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
                                      int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
@@ -635,6 +635,7 @@ extern "C" int isp_attention_fwd_f16(const void* Q, const void* K, const void* V
 #define ISP_ATT_F16(HD, NW)                                                                                                  \
     launch_attention<HD, NW, true>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l, \
                                    kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, nullptr, 0, s)
+    if (head_dim == 64) return ISP_ATT_F16(64, 4);  // (LoftUp on narrow feature maps: head dims <= 64)
     if (head_dim == 128) return wide ? ISP_ATT_F16(128, 8) : ISP_ATT_F16(128, 4);
     if (head_dim == 256) return wide ? ISP_ATT_F16(256, 8) : ISP_ATT_F16(256, 4);
 #undef ISP_ATT_F16

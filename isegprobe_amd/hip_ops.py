@@ -454,11 +454,11 @@ def attention_lse(q, k, v, scale):
 def attention(q, k, v, scale):
     """q [B,Lq,H,hd], k/v [B,Lk,H,hd] bf16, hd in {64,128} (any strides with unit last-dim stride)."""
     hd = q.shape[3]
-    half = q.dtype == F16  # (head_dim 128 / 256 only: LoftUp's inference stream)
+    half = q.dtype == F16  # (LoftUp's inference stream)
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _need(t, q.dtype if half else BF16, n, contiguous=False)
-        if t.stride(3) != 1 or t.shape[3] != hd or hd not in ((128, 256) if half else (64, 128, 256)):
-            raise IspError(f"{n}: head_dim must be 64, 128 or 256 with unit stride (128 or 256 for f16)")
+        if t.stride(3) != 1 or t.shape[3] != hd or hd not in (64, 128, 256):
+            raise IspError(f"{n}: head_dim must be 64, 128 or 256 with unit stride")
     if k.stride() != v.stride():
         raise IspError("k and v must share strides")
     B, Lq, H, _ = q.shape
