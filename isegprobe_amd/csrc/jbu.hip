@@ -141,10 +141,10 @@ __global__ __launch_bounds__(256) void jbu_range_proj_kernel(const float* __rest
 }
 
 // --------------------------------------------------------------------------------------
-// Per-pixel 7x7 kernels.  Block = 32x8 pixels; the 38x14 reflect-padded proj tile is staged in LDS with a pixel
-// stride of 36 floats (9 sixteen-byte slots: consecutive pixels of ONE row rotate through all 16 slots).  The block is
-// 32 wide so that each 16-lane group of a ds_read_b128 stays inside one tile row -- a 16x16 block mixed two rows per
-// group and 47 % of its LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+// Per-pixel 7x7 kernels.  Block = 32x8 pixels; the 38x14 reflect-padded proj tile is staged in LDS as IEEE half in four
+// k-chunk planes [k/8][pixel][8 halfs] (see the kernel body: both MFMA operands of the range logits are then conflict-free
+// ds_read_b128).  The block is 32 wide so that each 16-lane group of such a read stays inside one tile row -- a 16x16
+// block mixed two rows per group and 47 % of its LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr int TSX = 32, TSY = 8, HALOX = TSX + 2 * R, HALOY = TSY + 2 * R;
 constexpr int PLANE = ((HALOY * HALOX * 16 + 255) / 256) * 256;  // one k-chunk plane of the half proj tile, 256-B multiple
