@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Random-shape sweep of the main kernels against torch fp32 (GPU box): conv3x3 (bf16 / f16, plain + fused epilogues), dense
+GEMM (bf16 / f16), ViT self-attention (both entry points), generic attention (bf16 / f16), LayerNorm dtypes.
+usage: fuzz_kernels.py [seed] [rounds]   -- prints one line per case, exits non-zero on the first mismatch."""
+import math
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, ".")
+from isegprobe_amd import hip_ops as ops
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+g = torch.Generator().manual_seed(seed)
+ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+pick = lambda xs: xs[ri(0, len(xs) - 1)]
+BF, H16 = torch.bfloat16, torch.float16
+bad = 0
+
+
+def check(name, got, ref, tol):
+    global bad
+    err = (got.float() - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    ok = err <= tol * scale and torch.isfinite(got.float()).all().item()
+    print(f"{'ok  ' if ok else 'FAIL'} {name}: max err {err:.3g} (scale {scale:.3g}, tol {tol * scale:.3g})", flush=True)
+    bad += 0 if ok else 1
+
+
+for r in range(rounds):
+    torch.manual_seed(seed * 1000 + r)
+    # ---- conv3x3
+    B, H, W = ri(1, 3), ri(5, 90), ri(5, 90)
+    C, N = pick([64, 128, 192, 256, 384]), pick([64, 128, 192, 320, 384, 448, 768])
+    x = torch.randn(B, C, H, W, device="cuda")
+    w = torch.randn(N, C, 3, 3, device="cuda") / math.sqrt(9 * C)
+    bias = torch.randn(N, device="cuda")
+    for dt, tol in ((BF, 2e-2), (H16, 4e-3)):
+        if dt == H16 and not ops.conv_takes_f16(N):
+            continue
+        xd, wd = x.to(dt), w.to(dt)
+        ref = F.relu(F.conv2d(xd.float(), wd.float(), bias, padding=1))
+        y = ops.conv3x3(xd.permute(0, 2, 3, 1).contiguous(), wd.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), bias, "relu")
+        check(f"conv3x3 {dt} B{B} {H}x{W} C{C} N{N}", y.permute(0, 3, 1, 2), ref, tol)
+        if N % 192 == 0 and (B * H * W) % 4 == 0:
+            wc = torch.randn(N, device="cuda") / math.sqrt(N)
+            z = ops.conv3x3_relu_classifier(xd.permute(0, 2, 3, 1).contiguous(), wd.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), bias, wc, 0.1)
+            check(f"conv+classifier {dt} B{B} {H}x{W} C{C} N{N}", z, (ref * wc.view(1, N, 1, 1)).sum(1) + 0.1, tol)
+    # ---- dense GEMM
+    M, K, N = ri(1, 5000), 64 * ri(1, 12), 4 * ri(1, 200)
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") / math.sqrt(K)
+    bias = torch.randn(N, device="cuda")
+    for dt, tol in ((BF, 2e-2), (H16, 4e-3)):
+        for act, fn in ((None, lambda t: t), ("gelu", F.gelu)):
+            y = ops.linear(a.to(dt), w.to(dt), bias, act)
+            check(f"linear {dt} {act} M{M} K{K} N{N}", y, fn(a.to(dt).float() @ w.to(dt).float().t() + bias), tol)
+        res = torch.randn(M, N, device="cuda").to(dt)
+        y = ops.linear_axpy_res(a.to(dt), w.to(dt), bias, res, 0.7)
+        check(f"axpy_res {dt} M{M} K{K} N{N}", y, res.float() + 0.7 * (a.to(dt).float() @ w.to(dt).float().t() + bias), tol * 1.5)
+    # ---- ViT self-attention, packed qkv
+    Bq, L, heads = ri(1, 3), ri(1, 1300), ri(1, 6)
+    D = heads * 64
+    qkv = torch.randn(Bq * L, 3 * D, device="cuda").to(BF)
+    q, k, v = qkv.float().view(Bq, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = ((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(Bq * L, D)
+    check(f"attention64 scale B{Bq} L{L} h{heads}", ops.attention_packed_qkv(qkv, Bq, L, heads, 0.125), ref, 2e-2)
+    q2 = qkv.clone()
+    q2[:, :D] = (qkv[:, :D].float() * ops.ATTENTION_LOGIT2_SCALE).to(BF)
+    qq = q2[:, :D].float().view(Bq, L, heads, 64).permute(0, 2, 1, 3)
+    ref2 = ((qq @ k.transpose(-2, -1)) * math.log(2.0)).softmax(-1) @ v
+    check(f"attention64 logit2 B{Bq} L{L} h{heads}", ops.attention_packed_qkv(q2, Bq, L, heads, None, q_logit2=True),
+          ref2.transpose(1, 2).reshape(Bq * L, D), 2e-2)
+    # ---- generic attention (cross): hd 64 / 128 / 256
+    hd = pick([64, 128, 256])
+    Lq, Lk, Hh = ri(1, 900), ri(1, 400), ri(1, 3)
+    q, k, v = (torch.randn(2, n, Hh, hd, device="cuda") for n in (Lq, Lk, Lk))
+    for dt, tol in ((BF, 2e-2), (H16, 4e-3)):
+        o = ops.attention(q.to(dt), k.to(dt), v.to(dt), hd ** -0.5)
+        p = ((q.to(dt).float().permute(0, 2, 1, 3) @ k.to(dt).float().permute(0, 2, 3, 1)) * hd ** -0.5).softmax(-1)
+        check(f"attention {dt} hd{hd} Lq{Lq} Lk{Lk} H{Hh}", o, (p @ v.to(dt).float().permute(0, 2, 1, 3)).permute(0, 2, 1, 3), tol)
+    # ---- LayerNorm dtypes
+    rows, Dn = ri(1, 3000), 4 * ri(4, 300)
+    xx = torch.randn(rows, Dn, device="cuda") * 3 + 1
+    gg, bb = torch.randn(Dn, device="cuda"), torch.randn(Dn, device="cuda")
+    for din in (torch.float32, BF, H16):
+        for dout, tol in ((BF, 3e-2), (H16, 4e-3), (torch.float32, 1e-4)):
+            if (din, dout) in ((H16, BF), (H16, torch.float32)):
+                continue
+            y = ops.layernorm(xx.to(din).contiguous(), gg, bb, 1e-5, out_dtype=dout)
+            check(f"layernorm {din}->{dout} rows{rows} D{Dn}", y, F.layer_norm(xx.to(din).float(), (Dn,), gg, bb, 1e-5), tol)
+print(f"{bad} mismatches")
+sys.exit(1 if bad else 0)
