@@ -280,7 +280,13 @@ int launch_attention(const void* Q, const void* K, const void* V, void* O, int B
 // what is left is latency, and three waves per SIMD hide it best -- a software-pipelined variant at two waves per SIMD
 // (K fragments and V reads a phase ahead, three LDS slots; 96 us), the same with register-staged tiles (108 us) and
 // this kernel squeezed to four waves per SIMD (101 us) all lost.  Removing the exponentials, the PV product, the V
-// reads or the barrier from the loop moves the time by < 12 % each.
+// reads or the barrier from the loop moves the time by < 12 % each.  Two more ablations locate the rest: without the
+// whole softmax (max, rebase, exp) the time does not move (90.8 vs 91.1 us: the VALU work is fully hidden), and with every
+// MFMA replaced by one VALU op it drops to 51.6 us -- a 52 us skeleton of LDS fragment reads (each of the block's four
+// waves reads ALL of a tile's K and V fragments: 1.9 GB of LDS reads per launch, ~27 us at 128 B/clk/CU, plus 7 us of DMA
+// writes), barriers and stores, with ~40 us of MFMA time (30 us at a full pipe) ADDED to it rather than hidden under it.
+// What would move it: 64 queries (two 32-query streams) per wave sharing every K / V fragment read -- half the LDS
+// traffic per query -- at ~220 registers (no -m accumulator trick, VALU row sums: the VALU has the room).
 #ifndef ISP_ATT_THR
 #define ISP_ATT_THR 6.0f
 #endif
