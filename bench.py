@@ -392,7 +392,7 @@ def run_forward(args):
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if not (getattr(model, "head_f16", False) and fused_jbu) else
-                     "bf16 (ViT) + f16 (FeatUp-JBU stack and seg-head convolutions), fp32 accumulation",
+                     "f16 (16-bit operands of the ViT blocks, the FeatUp-JBU stack and the seg-head convolutions; bf16 patch matrix and trunk output), fp32 accumulation",
             "data": "synthetic",
             "config": {"workload": f"{args.arch} + {args.upsampler} + ConvSegHead({D},2,1), {S}x{S}, batch {B}/GPU, "
                                    "forward-only, seeded random-init weights", "per_gpu_batch": B,
@@ -408,7 +408,7 @@ def run_forward(args):
         if dt_bf16 is not None:
             line["alt_head_bf16"] = {"value": B * args.steps / dt_bf16, "unit": "images/sec", "ms_per_step": dt_bf16 / args.steps * 1e3,
                                      "note": "same steps with ISEGPROBE_HEAD_F16=0 (bf16 head convolutions: bench-workload logit "
-                                             "error 9.7e-3 max / 1.9e-3 rms instead of 6.4e-3 / 1.4e-3)"}
+                                             "error 8.5e-3 max / 1.7e-3 rms instead of 4.8e-3 / 0.8e-3)"}
         pk = _pmc_traffic("r01_peaks.json")
         if pk is not None:
             rnd = pk["mfma_bf16_16x16x32_register_loop_tflops"]["random"]

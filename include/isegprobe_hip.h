@@ -98,7 +98,8 @@ typedef struct isp_epilogue {
  * (as GEMMs) and every 1x1 conv on the path. */
 int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* ep, void* stream);
 /* The same on IEEE-half operands with 16-bit outputs in half (LoftUp's inference stream, loftup/layers.py:160-228): epilogue
- * kinds ISP_EP_BIAS_BF16, ISP_EP_BIAS_GELU_BF16 and ISP_EP_AXPY_RES_BF16 (res and out half); others ISP_ERR_UNSUPPORTED. */
+ * kinds ISP_EP_BIAS_BF16, ISP_EP_BIAS_GELU_BF16 (half outputs saturate at +-65504), ISP_EP_AXPY_RES_BF16 (res and out half)
+ * and ISP_EP_RESIDUAL_F32 (the ViT's fp32 residual stream); others ISP_ERR_UNSUPPORTED. */
 int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* ep, void* stream);
 
 /* ---- 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on NHWC bf16.
@@ -146,6 +147,12 @@ int isp_attention_fwd_logit2(const void* Q, const void* K, const void* V, void* 
 int isp_attention_fwd_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, int head_dim,
                           long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
                           long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
+
+/* isp_attention_fwd_logit2 on IEEE-half Q, K, V, O (the ViT trunk's half-precision inference stream, head_dim 64) */
+int isp_attention_fwd_logit2_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
+                                 int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
+                                 long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
+                                 void* stream);
 
 /* Training variant: also writes lse[b*H+h][q] (row stride lse_ld >= Lq, fp32) = log2 sum_k exp2(s_qk * scale * log2 e),
  * the statistic isp_attention_bwd needs to recompute the probabilities. */

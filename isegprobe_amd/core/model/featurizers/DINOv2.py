@@ -33,6 +33,7 @@ ARCHS = {  # DINOv2.py:413-449 (vit_giant2 uses SwiGLU: not built)
     "dinov2_vitl14": dict(embed_dim=1024, depth=24, num_heads=16),
 }
 LN_EPS = 1e-6  # DINOv2.py:98
+VIT_F16 = os.environ.get("ISEGPROBE_VIT_F16", "1") != "0"  # IEEE-half 16-bit operands in the inference trunk (see _blocks)
 
 
 def _pad64(k):
@@ -164,8 +165,11 @@ class DINOv2Featurizer(nn.Module):
                 if D // heads == 64:
                     qw[:D] *= ops.ATTENTION_LOGIT2_SCALE
                     qb[:D] *= ops.ATTENTION_LOGIT2_SCALE
+                half = lambda t: t.detach().to(ops.F16).contiguous()  # (from the fp32 parameters, not from their bf16 copies)
                 blocks.append(dict(
                     qkv_w2=qw.to(BF16).contiguous(), qkv_b2=qb.contiguous(),
+                    h_qkv_w=qw.to(ops.F16).contiguous(), h_proj_w=half(blk.attn.proj.weight),
+                    h_fc1_w=half(blk.mlp.fc1.weight), h_fc2_w=half(blk.mlp.fc2.weight),
                     n1w=f32(blk.norm1.weight), n1b=f32(blk.norm1.bias),
                     qkv_w=b16(blk.attn.qkv.weight), qkv_b=f32(blk.attn.qkv.bias),
                     proj_w=b16(blk.attn.proj.weight), proj_b=f32(blk.attn.proj.bias),
@@ -220,11 +224,29 @@ class DINOv2Featurizer(nn.Module):
         x.view(B, T + 1, D)[:, 0].copy_(cls_row)  # cls_token + pos[0] (DINOv2.py:525-528)
         return x, T
 
-    def _blocks(self, x, B, T, want_last_keys=False):
+    def _blocks(self, x, B, T, want_last_keys=False, out_f16=False):
+        """The frozen trunk on the fp32 residual stream ``x``.  With VIT_F16 the 16-bit operands of every block (LayerNorm
+        outputs, qkv, attention output, MLP hidden, the weights) are IEEE half instead of bf16: three more mantissa bits on
+        all of them at the same cost -- these kernels are bound by memory traffic, not by the MFMA pipe.  Half's range is
+        65504: LayerNorm outputs and projections of them are far inside it, the GELU epilogue saturates instead of
+        overflowing (``ISEGPROBE_VIT_F16=0`` keeps bf16, whose range is fp32's).  ``out_f16``: the final LayerNorm writes half
+        for a consumer that takes it (FeatUp JBU, LoftUp)."""
         P = self.packed()
         heads = self.model.num_heads
         L = T + 1
         nblk = len(P["blocks"])
+        if VIT_F16 and not want_last_keys and self.model.embed_dim // heads == 64:
+            H16 = ops.F16
+            for blk in P["blocks"]:
+                hbuf = ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, out_dtype=H16)
+                qkv = ops.linear(hbuf, blk["h_qkv_w"], blk["qkv_b2"])
+                att = ops.attention_packed_qkv(qkv, B, L, heads, None, q_logit2=True)
+                ops.linear_residual_(x, att, blk["h_proj_w"], blk["proj_b"], blk["ls1"])
+                hbuf = ops.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, out_dtype=H16)
+                hid = ops.linear(hbuf, blk["h_fc1_w"], blk["fc1_b"], "gelu")
+                ops.linear_residual_(x, hid, blk["h_fc2_w"], blk["fc2_b"], blk["ls2"])
+            return ops.layernorm(x, P["nw"], P["nb"], LN_EPS, group_out=T, skip=1, rows_out=B * T,
+                                 out_dtype=H16 if out_f16 else BF16)
         for i, blk in enumerate(P["blocks"]):
             hbuf = ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS)
             qkv = ops.linear(hbuf, blk["qkv_w2"], blk["qkv_b2"])

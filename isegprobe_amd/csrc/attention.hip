@@ -299,7 +299,13 @@ __device__ __forceinline__ float xhalf_max(float x) {  // max(x of lane, x of la
     return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
 }
 
-template <bool PRESCALED>
+template <bool F16>
+__device__ __forceinline__ f32x16 att_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <bool PRESCALED, bool F16 = false>  // F16: Q, K, V, P and O are IEEE half
 __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                              const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H,
                                                              int Lq, int Lk, long qsb, long qsl, long qsh, long ksb,
@@ -385,7 +391,8 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
     f32x16 o[DB], negm;
 #if ISP_ATT_ONES
     f32x16 lacc;
-    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    constexpr short kOne = F16 ? 0x3c00 : 0x3f80;  // 1.0 in half / bf16
+    const bf16x8 ones = {kOne, kOne, kOne, kOne, kOne, kOne, kOne, kOne};
 #else
     float l_run = 0.f;
 #endif
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf + k_off[kb][kk]);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+            s = att_mfma<F16>(kf, qf[kk], s);
         }
         if (mask) {
 #pragma unroll
@@ -437,16 +444,19 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
         for (int ss = 0; ss < 2; ++ss) {
             bf16x8 pf;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s[8 * ss + j]);
+            for (int j = 0; j < 8; j += 2) {
+                const unsigned pk = pack2o<!F16>(s[8 * ss + j], s[8 * ss + j + 1]);
+                pf[j] = (short)(pk & 0xffffu), pf[j + 1] = (short)(pk >> 16);
+            }
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const s16x4 lo = tr_read(buf + v_off[db][kb][ss][0]);
                 const s16x4 hi = tr_read(buf + v_off[db][kb][ss][1]);
                 const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+                o[db] = att_mfma<F16>(vf, pf, o[db]);
             }
 #if ISP_ATT_ONES
-            lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+            lacc = att_mfma<F16>(ones, pf, lacc);
 #endif
         }
     };
@@ -523,20 +533,20 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = db * 32 + 8 * g4 + 4 * hh;
                 *reinterpret_cast<uint2*>(op + d) =
-                    make_uint2(pack2bf(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv),
-                               pack2bf(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
+                    make_uint2(pack2o<!F16>(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv),
+                               pack2o<!F16>(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
             }
     }
 }
 
 constexpr int kAtt64Lds = Geo<64>::LDS;  // (K + V) x 2 buffers
 
-template <bool PRESCALED>
+template <bool PRESCALED, bool F16 = false>
 int launch_attention64(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, long qsb,
                        long qsl, long qsh, long ksb, long ksl, long ksh, long osb, long osl, long osh, float scale,
                        float* lse, long lse_ld, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = attention64_kernel<PRESCALED>;
+    auto kern = attention64_kernel<PRESCALED, F16>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kAtt64Lds) != hipSuccess)
             return ISP_ERR_LAUNCH;
@@ -646,4 +656,21 @@ extern "C" int isp_attention_fwd_f16(const void* Q, const void* K, const void* V
     if (head_dim == 256) return wide ? ISP_ATT_F16(256, 8) : ISP_ATT_F16(256, 4);
 #undef ISP_ATT_F16
     return ISP_ERR_UNSUPPORTED;
+}
+
+// isp_attention_fwd_logit2 on IEEE-half Q, K, V, O: the ViT trunk's half-precision inference stream (head_dim 64).
+extern "C" int isp_attention_fwd_logit2_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
+                                            int head_dim, long q_stride_b, long q_stride_l, long q_stride_h,
+                                            long kv_stride_b, long kv_stride_l, long kv_stride_h, long o_stride_b,
+                                            long o_stride_l, long o_stride_h, void* stream) {
+    ISP_CHECK_ARG(Q && K && V && O && B > 0 && H > 0 && Lq > 0 && Lk > 0);
+    if (head_dim != 64) return ISP_ERR_UNSUPPORTED;
+    ISP_CHECK_ARG(q_stride_b % 8 == 0 && q_stride_l % 8 == 0 && q_stride_h % 8 == 0);
+    ISP_CHECK_ARG(kv_stride_b % 8 == 0 && kv_stride_l % 8 == 0 && kv_stride_h % 8 == 0);
+    ISP_CHECK_ARG(o_stride_b % 4 == 0 && o_stride_l % 4 == 0 && o_stride_h % 4 == 0);
+    if (!(kv_stride_l >= 64 && ((long)(Lk - 1) * kv_stride_l + 64) * 2 < (1L << 31) &&
+          (long)KB * kv_stride_l * 2 * ((Lk + KB - 1) / KB) < (1L << 31)))
+        return ISP_ERR_UNSUPPORTED;
+    return launch_attention64<true, true>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l,
+                                          kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, (hipStream_t)stream);
 }

@@ -185,6 +185,7 @@ struct EpBiasActBf16 {  // out[m][n] = bf16(act(v + bias[n]))
             if (ACT == ACT_RELU) r[j] = fmaxf(r[j], 0.f);
             if (ACT == ACT_GELU) r[j] = gelu_erf(r[j]);
             if (ACT == ACT_QGELU) r[j] = r[j] / (1.0f + __expf(-1.702f * r[j]));
+            if (F16) r[j] = __builtin_amdgcn_fmed3f(r[j], -65504.f, 65504.f);  // saturate instead of overflowing to inf
         }
         return make_uint2(pack2o<!F16>(r[0], r[1]), pack2o<!F16>(r[2], r[3]));
     }
@@ -1336,6 +1337,8 @@ extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int
                 if (!e->res) return (int)ISP_ERR_INVALID;
                 return launch_gemm<CFG, true>(al, Wt, M, N, K,
                                               EpAxpyResBf16<true>{(bf16_t*)e->out, (const bf16_t*)e->res, e->bias, e->alpha, ldo}, s);
+            case ISP_EP_RESIDUAL_F32:  // the ViT's fp32 residual stream: x += gamma * (A W^T + bias) with half operands
+                return launch_gemm<CFG, true>(al, Wt, M, N, K, EpResidual{(float*)e->out, e->bias, e->gamma, ldo}, s);
             default:
                 return (int)ISP_ERR_UNSUPPORTED;
         }

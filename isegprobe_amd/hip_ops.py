@@ -279,15 +279,19 @@ ATTENTION_LOGIT2_SCALE = 64 ** -0.5 * 1.4426950408889634  # what `q_logit2` expe
 def attention_packed_qkv(qkv, B, L, heads, scale, q_logit2=False):
     """qkv [B*L, 3*heads*64] bf16 laid out (3, heads, 64) per token (attention.py:56-60).  q_logit2: the q third
     already carries scale * log2(e) (folded into the qkv weights, see DINOv2 featurizer): `scale` is then unused."""
-    _need(qkv, BF16, "qkv")
+    half = qkv.dtype == F16  # (the trunk's half-precision inference stream: q_logit2 form only)
+    _need(qkv, F16 if half else BF16, "qkv")
+    if half and not q_logit2:
+        raise IspError("f16 qkv needs q_logit2=True")
     D = heads * 64
-    out = torch.empty(B * L, D, device=qkv.device, dtype=BF16)
+    out = torch.empty(B * L, D, device=qkv.device, dtype=qkv.dtype)
     base = qkv.data_ptr()
     q, k, v = (ctypes.c_void_p(base + i * D * 2) for i in range(3))
     strides = (L * 3 * D, 3 * D, 64, L * 3 * D, 3 * D, 64, L * D, D, 64)
     if q_logit2:
-        check(_lib.lib().isp_attention_fwd_logit2(q, k, v, _p(out), B, heads, L, L, 64, *strides, _stream()),
-              "isp_attention_fwd_logit2")
+        fn, name = ((_lib.lib().isp_attention_fwd_logit2_f16, "isp_attention_fwd_logit2_f16") if half
+                    else (_lib.lib().isp_attention_fwd_logit2, "isp_attention_fwd_logit2"))
+        check(fn(q, k, v, _p(out), B, heads, L, L, 64, *strides, _stream()), name)
     else:
         check(_lib.lib().isp_attention_fwd(q, k, v, _p(out), B, heads, L, L, 64, *strides, float(scale), _stream()),
               "isp_attention_fwd")

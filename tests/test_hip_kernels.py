@@ -461,3 +461,34 @@ def test_f16_stream_kernels(ops):
         refo = (p @ v.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
         e16, eb = (o16.float() - refo).abs().max().item(), (ob.float() - refo).abs().max().item()
         assert o16.dtype == torch.float16 and e16 < 3e-3 and e16 < eb / 2, (hd, e16, eb)
+
+
+def test_f16_trunk_kernels(ops):
+    """The ViT trunk's half-precision inference stream: packed-qkv attention on IEEE half (base-2 logit form), the fp32
+    residual update from half operands, and the saturating half GELU epilogue (no inf where bf16 would still be finite)."""
+    torch.manual_seed(21)
+    B, L, heads = 2, 517, 3
+    D = heads * 64
+    qkv = torch.randn(B * L, 3 * D, device="cuda")
+    qkv[:, :D] *= ops.ATTENTION_LOGIT2_SCALE
+    qh = qkv.half()
+    out = ops.attention_packed_qkv(qh, B, L, heads, None, q_logit2=True)
+    assert out.dtype == torch.float16
+    q, k, v = qh.float().view(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = ((q @ k.transpose(-2, -1)) * math.log(2.0)).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B * L, D)
+    e16 = (out.float() - ref).abs().max().item()
+    outb = ops.attention_packed_qkv(bf(qkv), B, L, heads, None, q_logit2=True)
+    qb, kb, vb = bf(qkv).float().view(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    refb = (((qb @ kb.transpose(-2, -1)) * math.log(2.0)).softmax(-1) @ vb).transpose(1, 2).reshape(B * L, D)
+    eb = (outb.float() - refb).abs().max().item()
+    assert e16 < 2e-3 and e16 < eb / 2, (e16, eb)
+    M, K, N = 700, 384, 384
+    x = torch.randn(M, N, device="cuda")
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") / math.sqrt(K)
+    bias, gamma = torch.randn(N, device="cuda"), torch.randn(N, device="cuda")
+    y = ops.linear_residual_(x.clone(), a.half(), w.half(), bias, gamma)
+    assert (y - (x + gamma * (a.half().float() @ w.half().float().t() + bias))).abs().max().item() < 2e-3
+    big = torch.full((64, 64), 300.0, device="cuda")
+    h = ops.linear(big.half(), torch.full((64, 64), 200.0, device="cuda").half(), None, "gelu")  # 64 * 300 * 200 = 3.8e6
+    assert torch.isfinite(h.float()).all() and h.float().max().item() == 65504.0
