@@ -315,7 +315,7 @@ class DINOv2Featurizer(nn.Module):
             feats = TokenAddFn.apply(feats.view(b, T, D), additional_features)
         return nchw_view(feats.view(b, h, w, D))  # DINOv2.py:545
 
-    def forward_fused_clicks(self, image, prev_mask, click_maps, embed_coords):
+    def forward_fused_clicks(self, image, prev_mask, click_maps, embed_coords, out_f16=False):
         """before_backbone fast path: image patches and click-map patches are embedded by ONE
         GEMM over the concatenated K axis ([W_img | W_click], bias summed) -- numerically
         patch_embed(image) + embed_coords(coord) (DINOv2.py:518-523) without the token
@@ -341,5 +341,5 @@ class DINOv2Featurizer(nn.Module):
             raise IspError("embed_coords.in_chans does not match prev-mask + click-map channels")
         A = ops.patchify(image, prev_mask, click_maps, p, P["fused_w"].shape[1])
         xs, T = self._embed(A, P["fused_w"], P["fused_b"], b, H, W)
-        feats = self._blocks(xs, b, T)
+        feats = self._blocks(xs, b, T, out_f16=out_f16)  # out_f16: for a consumer that takes half (FeatUp JBU, LoftUp inference)
         return nchw_view(feats.view(b, H // p, W // p, self.model.embed_dim))

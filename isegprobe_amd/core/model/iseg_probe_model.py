@@ -75,7 +75,12 @@ class iSegProbeModel(iSegBaseModel):
             # click maps go straight into the patch matrix: no torch.cat, no token round trip
             maps = self.dist_maps(image, points)
             records = self._jbu_records_side_stream(image)
-            feats = self.backbone.forward_fused_clicks(image, prev_mask, maps, self.embed_coords)
+            # FeatUp JBU and LoftUp (inference) work in IEEE half from their first kernel on: the trunk's final LayerNorm
+            # writes half for them (one bf16 rounding less between the trunk and the upsampler)
+            from .upsamplers import LoftUpUpsampler
+            half_out = (self.architecture == "backbone_upsampler_head"
+                        and isinstance(self.upsampler, (JBUFeatUpUpsampler, LoftUpUpsampler)) and not self.upsampler.training)
+            feats = self.backbone.forward_fused_clicks(image, prev_mask, maps, self.embed_coords, out_f16=half_out)
             return self._after_backbone(image, feats, records)
         return super()._forward_prepared(image, prev_mask, points)
 

@@ -117,7 +117,7 @@ class JBUStack(nn.Module):
         With ``out_size`` the model's bilinear resize to the image size (iseg_probe_model.py:120-129) is fused into the
         last stage when the sizes allow it (otherwise the caller resizes as before).  ``out_dtype``: bf16, or IEEE half for
         a consumer that takes the stack's own precision (the seg head's f16 convolutions)."""
-        x = to_nhwc_bf16(source)
+        x = to_nhwc_bf16(source, keep_f16=True)  # (the stack converts to half anyway)
         if records is None:
             records = self.stage_records(guidance, x.shape[1], x.shape[2], out_size)
         for up, kc in zip((self.up1, self.up2, self.up3), records[:3]):
@@ -166,7 +166,7 @@ class JBUStack(nn.Module):
 
     def forward(self, source, guidance, drops=None):
         """``drops``: train-mode Dropout2d multipliers (``draw_dropout``); drawn here when ``dropout_active()``."""
-        x = to_nhwc_bf16(source)
+        x = to_nhwc_bf16(source, keep_f16=True)  # (the stack converts to half anyway)
         guidance = guidance.float().contiguous()
         if drops is None and self.dropout_active():
             drops = getattr(self, "fixed_dropout", None) or self.draw_dropout(x.shape[0], x.device)
@@ -204,7 +204,7 @@ class JBUFeatUpUpsampler(BaseUpsampler):
     def forward(self, source: torch.Tensor, guidance: torch.Tensor, drops=None) -> torch.Tensor:
         """``drops``: explicit train-mode Dropout2d multipliers (tests); by default the stack draws its own whenever the
         module is in train mode and autograd records (``JBUStack.dropout_active``)."""
-        x = to_nhwc_bf16(source)
+        x = to_nhwc_bf16(source, keep_f16=True)  # (the stack converts to half anyway)
         if torch.is_grad_enabled() and x.requires_grad:  # training with clicks injected before the upsampler
             stack = self.upsampler
             if drops is None and stack.dropout_active():

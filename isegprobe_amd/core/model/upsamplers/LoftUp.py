@@ -254,7 +254,7 @@ class LoftUpUpsampler(BaseUpsampler):
         return self._pe_cache[key]
 
     def forward(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
-        src = to_nhwc_bf16(source)
+        src = to_nhwc_bf16(source, keep_f16=LOFTUP_F16 and not self._bn_train())  # (half tokens only for the half stream)
         if torch.is_grad_enabled() and src.requires_grad:
             # training with clicks injected before the upsampler (the reference's default): activation
             # gradients w.r.t. the LR features flow back through the K/V side of both cross-attention layers
