@@ -30,10 +30,10 @@ def _head_weight(w, dtype):
         return w.to(dtype).contiguous()
     if HEAD_W_BITS == 8:
         return w.to(BF16).to(ops.F16).contiguous()
-    drop = 11 - HEAD_W_BITS  # round-to-nearest-even at bit `drop` of the half mantissa
-    bits = w.to(ops.F16).view(torch.int16).to(torch.int32) & 0xFFFF
-    bits = (bits + (1 << (drop - 1)) - 1 + ((bits >> drop) & 1)) & ~((1 << drop) - 1)
-    return bits.to(torch.int16).view(ops.F16).contiguous()
+    drop = 24 - HEAD_W_BITS  # round the fp32 value to nearest-even at that bit (one rounding), then store it in half (exact)
+    bits = w.contiguous().view(torch.int32)
+    bits = (bits + ((1 << (drop - 1)) - 1) + ((bits >> drop) & 1)) & ~((1 << drop) - 1)
+    return bits.view(torch.float32).to(ops.F16).contiguous()
 
 
 class ConvModule(nn.Module):
