@@ -23,6 +23,8 @@ Rooflines in the JSON line (forward mode), all from HIP events on the launch str
   roofline_vit        the DINOv2 blocks (patch embed + 12 blocks + final norm), SURVEY.md 8(d) ViT(D,L,N) FLOPs (MFMA)
   roofline_attention  the fused attention launches alone, L*N*4ND FLOPs over the step (MFMA)
   roofline_upsampler  the upsampler stage (FeatUp JBU: four stages + the fused resize), its algorithmic bytes (HBM)
+and, from the same run (never `value`): `loftup448` (the LoftUp upsampler at 448^2 against the MFMA and the HBM roofline) and
+`size896` (the same path on an 896 x 896 batch): the other numbers BASELINE.json's north_star names.
 """
 import argparse
 import json
@@ -210,6 +212,84 @@ def stage_times(model, image, points, iters=5):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- north_star's other named numbers
+def loftup_flops(C, HW, hw):
+    """LoftUp(C, HW, hw), c = C + 20: HW*[18*203*c + 18c^2 + 2*(4c^2 + 4*hw*c + 4cC) + 2cC] FLOP."""
+    c = C + 20
+    return HW * (18.0 * 203 * c + 18.0 * c * c + 2 * (4.0 * c * c + 4.0 * hw * c + 4.0 * c * C) + 2.0 * c * C)
+
+
+def loftup448_block(B=8, C=384, S=448, warm=2, iters=5):
+    """north_star: "LoftUp upsampler at 448^2" against BOTH rooflines (contraction-bound as an algorithm,
+    HBM-bound only in the reference's materialised-attention form).  The upsampler plugin alone on a batch of B images:
+    source [B,C,32,32] tokens + guidance image -> [B,C,448,448]."""
+    from helpers import seeded_
+    from isegprobe_amd.core.model.upsamplers import LoftUpUpsampler
+    up = seeded_(LoftUpUpsampler(None, n_dim=C), 3).cuda().eval()
+    h = S // 14
+    src = torch.randn(B, C, h, h, device="cuda")
+    gd = torch.randn(B, 3, S, S, device="cuda")
+    with torch.no_grad():
+        for _ in range(warm):
+            y = up(src, gd)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            y = up(src, gd)
+        e.record()
+        torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    assert y.shape == (B, C, S, S) and torch.isfinite(y.float()).all()
+    fl, by = B * loftup_flops(C, S * S, h * h), B * upsampler_bytes("loftup", C, h, h, S, S)
+    tf, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+    del up, y
+    torch.cuda.empty_cache()
+    return {"workload": f"LoftUp(n_dim={C}) upsampler plugin alone, {S}x{S}, batch {B}, {h}x{h} LR tokens, inference stream (IEEE half)",
+            "ms_per_batch": ms, "ms_per_image": ms / B, "images_per_sec": B / (ms * 1e-3),
+            "mfma": {"achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "flops_per_batch": fl},
+            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_batch": by,
+                    "note": "minimal algorithmic bytes HW*(3*4 + 2C) + hw*(C+20)*2 per image: the algorithm is contraction-bound, "
+                            "the HBM fraction is what north_star's '60 % of HBM peak' would mean for it"}}
+
+
+def size896_block(arch, upsampler, B=8, S=896, warm=2, iters=5):
+    """north_star: "images/sec on synthetic ... 896^2 batches": the same per-click path at 896 x 896 (64 x 64 tokens, N = 4097)."""
+    from isegprobe_amd import hip_ops as ops
+    vit = VITS[arch]
+    model = build(upsampler, S, arch).cuda()
+    image, points = synthetic_batch(B, S, seed=896)
+    image, points = image.cuda(), points.cuda()
+    with torch.no_grad():
+        for _ in range(warm):
+            model(image, points)
+        torch.cuda.synchronize()
+        with OpTimer(ops, ("conv3x3", "conv3x3_folded_affine", "conv3x3_relu_classifier")) as t_conv, \
+                OpTimer(model.backbone, ("forward_fused_clicks",)) as t_vit:
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                out = model(image, points)["instances"]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    assert out.shape == (B, 1, S, S) and torch.isfinite(out).all()
+    D, L, hw = vit["embed_dim"], vit["depth"], (S // 14) ** 2
+    conv_ms, vit_ms = t_conv.mean_ms(), t_vit.mean_ms()
+    xin, Wt = t_conv.last_args[0], t_conv.last_args[1]
+    conv_fl = 2.0 * xin.shape[0] * xin.shape[1] * xin.shape[2] * xin.shape[3] * 9 * Wt.shape[0]
+    vfl = B * vit_flops(D, L, hw)
+    mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    del model, out
+    torch.cuda.empty_cache()
+    return {"workload": f"{arch} + {upsampler} + ConvSegHead({D},2,1), {S}x{S}, batch {B}, forward-only", "images_per_sec": B * iters / dt,
+            "ms_per_step": dt / iters * 1e3, "steps": iters, "warmup": warm,
+            "head_conv": {"launch_ms": conv_ms, "achieved": conv_fl / (conv_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                          "frac": conv_fl / (conv_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS},
+            "vit": {"ms_in_step": vit_ms, "achieved": vfl / (vit_ms * 1e-3) / 1e12, "unit": "TFLOP/s",
+                    "frac_in_step": vfl / (vit_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                    "attention_share_of_flops": attention_flops(D, L, hw) / vit_flops(D, L, hw)},
+            "peak_mem_GiB": mem}
+
+
 # ---------------------------------------------------------------------------------------------- CPU baseline (oracle)
 def cpu_baseline(model_sd, size, upsampler, vit, seed, full=False):
     """The CPU oracle (kind "port": torch-CPU restatement of the reference path, pinned by the golden fixtures) on
@@ -304,6 +384,13 @@ def _pmc_traffic(name):
         return None
 
 
+def _head_w_bits(model, fused_jbu):
+    """Significant bits of the seg head's half-format weights in the timed steps (ISEGPROBE_HEAD_W_BITS; 8 = bf16-valued
+    numbers stored as half, 11 = full half): part of the precision the headline was measured at."""
+    from isegprobe_amd.core.model.heads import conv_heads
+    return conv_heads.HEAD_W_BITS if (getattr(model, "head_f16", False) and fused_jbu) else None
+
+
 def run_dry(args):
     """Launch plumbing only (CPU, gloo): the ranks rendezvous, time an empty region the way the real modes do, and
     rank 0 prints one JSON line.  Used by tests/test_distributed_cpu.py to cover `bench.py --gpus N` self-spawn."""
@@ -392,8 +479,9 @@ def run_forward(args):
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if not (getattr(model, "head_f16", False) and fused_jbu) else
-                     "f16 (16-bit operands of the ViT blocks, the FeatUp-JBU stack and the seg-head convolutions; bf16 patch matrix and trunk output), fp32 accumulation",
+                     "f16 (IEEE-half 16-bit operands of the ViT blocks, the FeatUp-JBU stack and the seg-head convolutions -- head weights hold `head_w_bits` significant bits; bf16 patch matrix), fp32 accumulation",
             "data": "synthetic",
+            "head_w_bits": _head_w_bits(model, fused_jbu),
             "config": {"workload": f"{args.arch} + {args.upsampler} + ConvSegHead({D},2,1), {S}x{S}, batch {B}/GPU, "
                                    "forward-only, seeded random-init weights", "per_gpu_batch": B,
                        "global_batch": world * B, "image_size": S, "parallelism": f"replicas x{world}"},
@@ -433,6 +521,9 @@ def run_forward(args):
                                     "bound": "mfma", "achieved": fl / (vit_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                                     "unit": "TFLOP/s", "frac": fl / (vit_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                                     "ms_per_step": vit_ms, "ms_in_step_beside_jbu_records": vit_in, "flops_per_step": fl,
+                                    "frac_in_step": (fl / (vit_in * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS) if vit_in else None,
+                                    "note": "frac = the stage run on its own; frac_in_step = HIP events inside the timed steps, where "
+                                            "FeatUp-JBU's guidance-only kernels share the chip on a second stream",
                                     "traffic": None}
         att_ms = (st or {}).get("attention_launch_ms") or (float(np.mean(att_in)) if att_in else None)
         if att_ms:
@@ -465,6 +556,15 @@ def run_forward(args):
                                           "note": "time = the stage run on its own (stages.*): inside the step its guidance-only half "
                                                   f"overlaps the ViT on a second stream (main-stream share {up_ms_in:.2f} ms)"
                                           if up_ms_seq and up_ms_in else "HIP events inside the timed steps"}
+        if world == 1 and not args.no_extras:
+            # the other numbers north_star names, measured in the same run (never `value`)
+            del out
+            torch.cuda.empty_cache()
+            for key, fn in (("loftup448", lambda: loftup448_block()), ("size896", lambda: size896_block(args.arch, args.upsampler))):
+                try:
+                    line[key] = fn()
+                except Exception as exc:
+                    line[key] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, S, args.upsampler, vit, seed=1000, full=args.cpu_baseline_full)
         print(json.dumps(line), flush=True)
@@ -569,6 +669,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="batch-8 CPU baseline as the median of 3 runs (slow)")
     ap.add_argument("--no-stages", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the loftup448 / size896 blocks (north_star's other named numbers)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region (bf16 head convolutions, alt_head_bf16)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -22,7 +22,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None):
+    """Returns [(dataset name, per-object IoU arrays, results dict of the printed table row)] (tests call it in-process)."""
+    argv = sys.argv[1:] if argv is None else list(argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--dataset", default=None, help="dataset root directory")
     ap.add_argument("--dataset-name", default="GrabCut",
@@ -31,7 +33,8 @@ def main():
     ap.add_argument("--checkpoint", default=None, help="reference-format checkpoint {'state_dict','config'}")
     ap.add_argument("--arch", default="dinov2_vits14")
     ap.add_argument("--upsampler", default="bilinear")
-    ap.add_argument("--eval-mode", default="fixed224", help="fixed<H>[,<W>] (reference eval_cfg.yaml:36)")
+    ap.add_argument("--eval-mode", default="fixed224",
+                    help="fixed<H>[,<W>] or cvpr (448x448, DAVIS 672x672; reference eval_cfg.yaml:36, inference/utils.py:301-316)")
     ap.add_argument("--n-clicks", type=int, default=20)
     ap.add_argument("--thresh", type=float, default=0.5)
     ap.add_argument("--target-iou", type=float, default=0.90)
@@ -41,7 +44,7 @@ def main():
     ap.add_argument("--fp32", action="store_true",
                     help="checking mode: fp32-accurate arithmetic (model.forward_fp32, three bf16 products; 3-4x slower)")
     from isegprobe_amd.core.utils.overrides import DATASET_PATH_KEYS, EVAL_DEFAULTS, apply_overrides, split_overrides
-    overrides, rest = split_overrides(sys.argv[1:])
+    overrides, rest = split_overrides(argv)
     args = ap.parse_args(rest)
     jobs = None  # [(dataset name, root)]
     print_ious = True
@@ -75,8 +78,8 @@ def main():
     from isegprobe_amd.core.model import iSegProbeModel
     from isegprobe_amd.core.utils.serialization import load_model
 
-    parts = args.eval_mode[5:].split(",")
-    crop = (int(parts[0]), int(parts[1]) if len(parts) > 1 else int(parts[0]))  # inference/utils.py:307-316
+    from isegprobe_amd.core.inference.utils import get_zoom_in_params
+    crop = get_zoom_in_params(args.eval_mode, args.dataset_name)["target_size"]  # (model construction: the first dataset's size)
     device = torch.device("cuda")
     if args.checkpoint:
         from isegprobe_amd.core.inference.utils import load_is_model
@@ -103,23 +106,27 @@ def main():
         if not args.dataset:
             raise SystemExit("give --dataset, --synthetic N or +datasets=...")
         jobs = [(args.dataset_name, args.dataset)]
-    predictor = get_predictor(model, "NoBRS", device, prob_thresh=args.thresh,
-                              zoom_in_params={"skip_clicks": -1, "target_size": crop})
     from isegprobe_amd.core.inference.utils import save_iou_analysis_data, save_results
     logs = args.logs or tempfile.mkdtemp(prefix="isegprobe_eval_")
+    out = []
     for i, (name, root) in enumerate(jobs):
         dataset = get_dataset(name, root)
+        # evaluate.py:72-94: zoom-in parameters and the predictor are rebuilt per dataset (cvpr: DAVIS runs at 672 x 672)
+        predictor = get_predictor(model, "NoBRS", device, prob_thresh=args.thresh,
+                                  zoom_in_params=get_zoom_in_params(args.eval_mode, name))
         all_ious, elapsed = evaluate_dataset(dataset, predictor, pred_thr=args.thresh, max_iou_thr=max_iou_thr,
                                              min_clicks=1, max_clicks=args.n_clicks,
                                              device_clicker=False if args.host_clicker else None)
         # the reference's table / log files (inference/utils.py:174-246,365-543); NoC thresholds up to target_iou
-        save_results(model.upsampler.__class__.__name__, name, logs, (all_ious, elapsed), eval_mode=args.eval_mode,
-                     n_clicks=args.n_clicks, target_iou=max_iou_thr if print_ious else args.target_iou, print_ious=print_ious,
-                     save_ious=True, print_header=i == 0)
+        res = save_results(model.upsampler.__class__.__name__, name, logs, (all_ious, elapsed), eval_mode=args.eval_mode,
+                           n_clicks=args.n_clicks, target_iou=max_iou_thr if print_ious else args.target_iou, print_ious=print_ious,
+                           save_ious=True, print_header=i == 0)
+        out.append((name, all_ious, res))
         save_iou_analysis_data(name, logs, (all_ious, elapsed), eval_mode=args.eval_mode, n_clicks=args.n_clicks)
         print(f"{name}: SPC {elapsed / max(sum(len(x) for x in all_ious), 1):.4f} s; logs, IoU pickles: {logs}")
     if tmp:
         tmp.cleanup()
+    return out
 
 
 if __name__ == "__main__":

@@ -148,7 +148,18 @@ int isp_attention_fwd_f16(const void* Q, const void* K, const void* V, void* O, 
                           long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
                           long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, float scale, void* stream);
 
-/* isp_attention_fwd_logit2 on IEEE-half Q, K, V, O (the ViT trunk's half-precision inference stream, head_dim 64) */
+/* Software-pipelined forward (csrc/attention_pipe.hip): one wave per SIMD, 64 queries per wave as two streams that share
+ * every K / V fragment read, QK^T of tile t+1 and the PV product of tile t interleaved with the softmax of tile t.
+ * head_dim 64 (Attention.forward, dinov2/layers/attention.py:54-71) or 128 (LoftUp's nn.MultiheadAttention,
+ * loftup/layers.py:182-198, head_dim 101 zero-padded).  Q carries softmax scale x log2(e) (as isp_attention_fwd_logit2);
+ * bf16 (f16 = 0) or IEEE-half operands.  Inference only.  isp_attention_pipe_supported tells whether a problem is taken
+ * (Lk >= 128, 32-bit addressable K / V slice, ISEGPROBE_ATT_PIPE != 0); isp_attention_fwd_logit2[_f16] route to it. */
+int isp_attention_pipe_supported(int head_dim, int Lq, int Lk, long kv_stride_l);
+int isp_attention_fwd_pipe(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, int head_dim,
+                           long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b, long kv_stride_l,
+                           long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h, int f16, void* stream);
+
+/* isp_attention_fwd_logit2 on IEEE-half Q, K, V, O (the ViT trunk's half-precision inference stream, head_dim 64; LoftUp's, head_dim 128 / 256) */
 int isp_attention_fwd_logit2_f16(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
                                  int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
                                  long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "libisegprobe_hip.so")  # env override: kernel A/B experiments
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 ISP_F32, ISP_BF16, ISP_F16 = 0, 1, 2
 EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16, EP_BIAS_QGELU_SAVE_BF16, EP_MUL_DQGELU_BF16 = range(14)
@@ -58,6 +58,8 @@ SIGNATURES = {
     "isp_attention_fwd_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
     "isp_attention_fwd_logit2_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_vp],
     "isp_attention_fwd_logit2": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_vp],
+    "isp_attention_pipe_supported": [_i, _i, _i, _l],
+    "isp_attention_fwd_pipe": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_i, _vp],
     "isp_attention_fwd_lse": [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
     "isp_attention_bwd": [_vp] * 7 + [_l] + [_vp] * 3 + [_i] * 5 + [_l] * 9 + [_f, _vp, _vp],
     "isp_conv3x3_wgrad_bf16_atomic": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -27,6 +27,20 @@ def compute_noc_metric(all_ious: List[np.ndarray], iou_thrs: List[float], max_cl
     return noc_list, noc_std, over_max
 
 
+def get_zoom_in_params(eval_mode: str, dataset_name: str = "") -> dict:
+    """Zoom-in parameters of an evaluation mode (core/inference/utils.py:288-316, the ``eval_ritm=False`` branch that
+    every experiment of the reference used): ``fixed<H>`` / ``fixed<H>,<W>`` -> zoom from the first click to H x W (W = H
+    when omitted); ``cvpr`` -> 448 x 448, DAVIS 672 x 672.  Anything else raises NotImplementedError, as the reference does."""
+    eval_mode = str(eval_mode)
+    if eval_mode == "cvpr":
+        return {"skip_clicks": -1, "target_size": (672, 672) if dataset_name == "DAVIS" else (448, 448)}
+    if eval_mode.startswith("fixed"):
+        parts = eval_mode.split(",")
+        h = int(parts[0][5:])
+        return {"skip_clicks": -1, "target_size": (h, int(parts[1]) if len(parts) == 2 else h)}
+    raise NotImplementedError(f"eval_mode={eval_mode!r}: 'cvpr', 'fixed<number>' or 'fixed<number>,<number>'")
+
+
 def get_time_metrics(all_ious: List[np.ndarray], elapsed_time: float) -> Tuple[float, float]:
     """Seconds per click / per image (core/inference/utils.py:149-161)."""
     return elapsed_time / sum(map(len, all_ious)), elapsed_time / len(all_ious)

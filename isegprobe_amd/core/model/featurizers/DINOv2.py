@@ -34,6 +34,7 @@ ARCHS = {  # DINOv2.py:413-449 (vit_giant2 uses SwiGLU: not built)
 }
 LN_EPS = 1e-6  # DINOv2.py:98
 VIT_F16 = os.environ.get("ISEGPROBE_VIT_F16", "1") != "0"  # IEEE-half 16-bit operands in the inference trunk (see _blocks)
+F16_PROBE_ALWAYS = os.environ.get("ISEGPROBE_F16_PROBE", "first") == "always"  # range-check every half forward (debug)
 
 
 def _pad64(k):
@@ -235,18 +236,43 @@ class DINOv2Featurizer(nn.Module):
         heads = self.model.num_heads
         L = T + 1
         nblk = len(P["blocks"])
-        if VIT_F16 and not want_last_keys and self.model.embed_dim // heads == 64:
+        if VIT_F16 and not want_last_keys and self.model.embed_dim // heads == 64 and P.get("f16_ok", True):
             H16 = ops.F16
+            # Range guard.  Half's largest finite value is 65504 and every 16-bit store of this stream saturates there
+            # (pack2h_sat) instead of producing inf -- but a saturated activation is a wrong activation.  Real DINOv2
+            # checkpoints carry a few outlier channels / tokens, so the FIRST half-precision forward of a set of packed
+            # weights (and every forward under ISEGPROBE_F16_PROBE=always) records the largest magnitude of each 16-bit
+            # intermediate; at >= half of the range the weights are marked bf16-only (bf16 has fp32's range) and this
+            # forward is redone in bf16 from a copy of the stream.  One device->host read per weight version.
+            probe = ("f16_ok" not in P or F16_PROBE_ALWAYS) and not torch.cuda.is_current_stream_capturing()
+            peak = torch.zeros((), device=x.device) if probe else None
+            x_in = x.clone() if probe else None
+
+            def seen(t):
+                if probe:
+                    torch.maximum(peak, t.abs().amax().float(), out=peak)
+                return t
             for blk in P["blocks"]:
-                hbuf = ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, out_dtype=H16)
-                qkv = ops.linear(hbuf, blk["h_qkv_w"], blk["qkv_b2"])
-                att = ops.attention_packed_qkv(qkv, B, L, heads, None, q_logit2=True)
+                hbuf = seen(ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, out_dtype=H16))
+                qkv = seen(ops.linear(hbuf, blk["h_qkv_w"], blk["qkv_b2"]))
+                att = seen(ops.attention_packed_qkv(qkv, B, L, heads, None, q_logit2=True))
                 ops.linear_residual_(x, att, blk["h_proj_w"], blk["proj_b"], blk["ls1"])
-                hbuf = ops.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, out_dtype=H16)
-                hid = ops.linear(hbuf, blk["h_fc1_w"], blk["fc1_b"], "gelu")
+                hbuf = seen(ops.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, out_dtype=H16))
+                hid = seen(ops.linear(hbuf, blk["h_fc1_w"], blk["fc1_b"], "gelu"))
                 ops.linear_residual_(x, hid, blk["h_fc2_w"], blk["fc2_b"], blk["ls2"])
-            return ops.layernorm(x, P["nw"], P["nb"], LN_EPS, group_out=T, skip=1, rows_out=B * T,
-                                 out_dtype=H16 if out_f16 else BF16)
+            out = ops.layernorm(x, P["nw"], P["nb"], LN_EPS, group_out=T, skip=1, rows_out=B * T,
+                                out_dtype=H16 if out_f16 else BF16)
+            if not probe:
+                return out
+            P["f16_peak"] = float(peak)
+            P["f16_ok"] = P["f16_peak"] < 0.5 * 65504.0
+            if P["f16_ok"]:
+                return out
+            logger.warning(f"DINOv2 trunk: half-precision stream peaks at {P['f16_peak']:.4g} (>= half of IEEE half's range); "
+                           "these weights run on the bf16 stream from now on (ISEGPROBE_VIT_F16=0 selects it up front)")
+            x.copy_(x_in)
+            if out_f16:  # the caller's consumer was promised half: bf16 -> half is exact up to range, and LayerNorm output is bounded
+                return self._blocks(x, B, T, want_last_keys, False).to(H16)
         for i, blk in enumerate(P["blocks"]):
             hbuf = ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS)
             qkv = ops.linear(hbuf, blk["qkv_w2"], blk["qkv_b2"])

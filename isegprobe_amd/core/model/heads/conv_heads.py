@@ -18,6 +18,8 @@ from .base_head import BaseClassifierHead
 
 HEAD_F16 = os.environ.get("ISEGPROBE_HEAD_F16", "1") != "0"  # f16 operands for the inference convolutions (see forward)
 HEAD_W_BITS = int(os.environ.get("ISEGPROBE_HEAD_W_BITS", "8"))  # significant bits kept in the half-format weights (8..11)
+if not 8 <= HEAD_W_BITS <= 11:
+    raise ValueError(f"ISEGPROBE_HEAD_W_BITS={HEAD_W_BITS}: the half-format head weights keep 8 (bf16-valued) to 11 (full half) bits")
 
 
 def _head_weight(w, dtype):
@@ -54,8 +56,9 @@ class ConvModule(nn.Module):
         return cache.get((self.conv.weight, self.conv.bias), build)
 
     def takes_f16(self):
-        """The f16 conv kernel exists for 3x3 layers whose output channels tile into 192-channel blocks."""
-        return self.conv.kernel_size == (3, 3) and self.conv.out_channels % 192 == 0 and self.conv.in_channels % 64 == 0  # (fused epilogues need 192-channel blocks)
+        """The f16 conv kernel exists for 3x3 layers whose output channels tile into 192- or (nearly) 128-channel blocks
+        (``ops.conv_takes_f16``: 384 / 768 / 1024-wide heads and the 128-wide fixture models)."""
+        return self.conv.kernel_size == (3, 3) and ops.conv_takes_f16(self.conv.out_channels) and self.conv.in_channels % 64 == 0
 
     def run(self, x_nhwc):
         if grad_mode(self.conv) or (torch.is_grad_enabled() and x_nhwc.requires_grad):

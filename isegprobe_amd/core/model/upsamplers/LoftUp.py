@@ -148,6 +148,11 @@ class LoftUpUpsampler(BaseUpsampler):
     def _bn_train(self):
         return self.upsampler.upsampler.first_conv[2].training
 
+    def _cp(self):
+        """Padded channel count of the pixel stream (n_dim + 20 PE channels, to a multiple of 64)."""
+        lu = self.upsampler.upsampler
+        return _pad64(lu.dim + lu.lr_pe_dim)
+
     # ---- weight packing (bf16, padded, BN folded unless the module is in training mode)
     def packed(self, train=False, half=False):
         """``half``: kernel-layout weights in IEEE half (from the fp32 parameters) for the half-precision inference stream."""
@@ -211,6 +216,11 @@ class LoftUpUpsampler(BaseUpsampler):
                 L = dict(nq_w=f32(ca.norm_q.weight), nq_b=f32(ca.norm_q.bias), nq_eps=ca.norm_q.eps,
                          nkv_w=f32(ca.norm_kv.weight), nkv_b=f32(ca.norm_kv.bias), nkv_eps=ca.norm_kv.eps)
                 L["wq"], L["bq"] = head_rows(ipw[:E], ipb[:E])
+                # inference copy of the query projection carrying softmax scale x log2(e) (nn.MultiheadAttention scales q by
+                # head_dim ** -0.5 after the projection: same product, rounded once): Q K^T are then base-2 logits, the form the
+                # software-pipelined attention kernel takes (csrc/attention_pipe.hip)
+                qs = (c // heads) ** -0.5 * 1.4426950408889634
+                L["wq2"], L["bq2"] = head_rows(ipw[:E].detach().float() * qs, ipb[:E].detach().float() * qs)
                 L["wk"], L["bk"] = head_rows(ipw[E:2 * E], ipb[E:2 * E])
                 L["wv"], L["bv"] = head_rows(ipw[2 * E:], ipb[2 * E:])
                 wo = torch.zeros(cp, heads, hdp, device=dev)  # out_proj: input index = head*hd + d
@@ -254,7 +264,7 @@ class LoftUpUpsampler(BaseUpsampler):
         return self._pe_cache[key]
 
     def forward(self, source: torch.Tensor, guidance: torch.Tensor) -> torch.Tensor:
-        src = to_nhwc_bf16(source, keep_f16=LOFTUP_F16 and not self._bn_train())  # (half tokens only for the half stream)
+        src = to_nhwc_bf16(source, keep_f16=LOFTUP_F16 and not self._bn_train() and ops.conv_takes_f16(self._cp()))  # (half tokens only for the half stream)
         if torch.is_grad_enabled() and src.requires_grad:
             # training with clicks injected before the upsampler (the reference's default): activation
             # gradients w.r.t. the LR features flow back through the K/V side of both cross-attention layers
@@ -267,7 +277,7 @@ class LoftUpUpsampler(BaseUpsampler):
         # inference runs the whole stream -- tokens, Fourier features, both convolutions, both cross-attention + feed-forward
         # layers, the final projection and LayerNorms -- on IEEE half: its maps are LayerNorm-bounded, and the twelve bf16
         # roundings between the ViT's tokens and the head were 2.5e-3 of the 2.7e-3 rms logit error of S/14 + LoftUp
-        half = save is None and not train and LOFTUP_F16
+        half = save is None and not train and LOFTUP_F16 and ops.conv_takes_f16(self._cp())  # (else bf16: no f16 conv for that width)
         dt = ops.F16 if half else BF16
         P = self.packed(train, half)
         B, h, w, C = src.shape
@@ -301,14 +311,17 @@ class LoftUpUpsampler(BaseUpsampler):
         for li, L in enumerate(P["layers"]):
             def project_q(x=x, L=L):
                 qn = ops.layernorm(x, L["nq_w"], L["nq_b"], L["nq_eps"], D=c, ld_out=cp, out_dtype=dt)
+                if save is None:  # inference: base-2-logit queries (scale folded into the projection)
+                    return ops.linear(qn, L["wq2"], L["bq2"]).view(B, H * W, heads, hdp)
                 return ops.linear(qn, L["wq"], L["bq"]).view(B, H * W, heads, hdp)
             # the first layer's queries see the image only (x is still x0)
-            q = self._gcache.get(guidance, id(P), "q0", project_q) if (li == 0 and not train) else project_q()
+            q = (self._gcache.get(guidance, id(P), "q0" if save is None else "q0_grad", project_q) if (li == 0 and not train)
+                 else project_q())  # (the inference projection carries the softmax scale: its own cache slot)
             kn = ops.layernorm(kv, L["nkv_w"], L["nkv_b"], L["nkv_eps"], D=c, ld_out=cp, out_dtype=dt)
             k = ops.linear(kn, L["wk"], L["bk"]).view(B, T, heads, hdp)
             v = ops.linear(kn, L["wv"], L["bv"]).view(B, T, heads, hdp)
             if save is None:
-                a = ops.attention(q, k, v, scale).view(M, heads * hdp)
+                a = ops.attention(q, k, v, None, q_logit2=True).view(M, heads * hdp)
             else:
                 a, lse = ops.attention_lse(q, k, v, scale)
                 a = a.view(M, heads * hdp)

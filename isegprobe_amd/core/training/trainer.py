@@ -2,8 +2,9 @@
 577-618), reduced to what sits on the dense-feature path:
 
   batch -> [0..max_num_next_clicks no-grad forwards that simulate corrective clicks] -> forward
-        -> NFL loss -> backward (HIP kernels through core/model/_autograd.py) -> ONE flat-bucket
-        all-reduce of the trainable gradients (RCCL over xGMI; utils/distributed.GradBucket)
+        -> NFL loss -> backward (HIP kernels through core/model/_autograd.py) -> flat-bucket all-reduce of the
+        trainable gradients (RCCL over xGMI; utils/distributed.GradBucket: the head's slice is issued
+        asynchronously inside backward, the click encoder's after it)
         -> Adam step.
 
 The reference wraps the net in DistributedDataParallel; here the collective is explicit and sits
@@ -47,7 +48,11 @@ class DataParallelTrainer:
         self.max_num_next_clicks = max_num_next_clicks
         self.prev_mask_drop_prob = prev_mask_drop_prob
         params = [p for p in model.parameters() if p.requires_grad]
-        self.bucket = D.GradBucket(params)
+        # the head's gradients are final before the upsampler / trunk data gradients start: their slice of the bucket is
+        # reduced while the rest of backward runs (GradBucket.arm_early)
+        head = [p for n, p in model.named_parameters() if n.startswith("head.") and p.requires_grad]
+        self.bucket = D.GradBucket(params, early=head)
+        self._has_bn = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules())
         self.optim = torch.optim.Adam(params, lr=lr, betas=betas, eps=eps)  # trainer.py:141, optimizer.py:14-35
 
     def _train_mode(self):
@@ -79,10 +84,15 @@ class DataParallelTrainer:
     def step(self, batch: Dict, num_iters=None):
         """One optimisation step; returns the (rank-local) loss as a 0-dim tensor."""
         self._train_mode()
+        if self._has_bn and self.frozen_bn_batch_stats:
+            # DDP(broadcast_buffers=True): rank 0's running statistics before every training forward, so the eval-mode
+            # click-simulation forwards of all replicas normalise with the same numbers
+            D.broadcast_buffers(self.net)
         self.bucket.zero()
         loss, _ = self.batch_forward(batch, num_iters)
+        self.bucket.arm_early()
         loss.backward()
         self.bucket.check_bound()     # a zero_grad(set_to_none=True) by the caller would have detached the views
-        self.bucket.all_reduce_mean()  # gradient step only: every gradient is needed, so there is nothing to overlap with
+        self.bucket.finish_overlapped()  # head slice was issued inside backward; the rest + wait + /world here
         self.optim.step()
         return loss.detach()

@@ -76,6 +76,30 @@ def shard_indices(n, rank=None, world=None):
     return [i % n for i in idx]
 
 
+def broadcast_buffers(module, src=0):
+    """DDP's ``broadcast_buffers=True`` (the reference wraps the net with the default, core/utils/distributed.py:66-78):
+    before every training forward rank ``src``'s module buffers replace every other rank's -- here the running
+    statistics of the frozen LiFT / LoftUp BatchNorms, which train-mode forwards update from each rank's own shard.
+    One flat broadcast of the floating-point buffers."""
+    if get_world_size() < 2:
+        return 0
+    bufs = [b for b in module.buffers() if b.is_floating_point() and b.numel() > 0]
+    if not bufs:
+        return 0
+    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    dist.broadcast(flat, src=src)
+    if get_rank() != src:
+        off = 0
+        with torch.no_grad():
+            for b in bufs:
+                n = b.numel()
+                new = flat[off:off + n].view_as(b).to(b.dtype)
+                if not torch.equal(new, b):  # leave the version counter alone when nothing changed (packed-weight caches key on it)
+                    b.copy_(new)
+                off += n
+    return len(bufs)
+
+
 class GradBucket:
     """Flat bucket of the trainable parameters' gradients: one all-reduce(sum) per step, then /world.
 
@@ -87,8 +111,19 @@ class GradBucket:
     ``set_to_none=True`` drops the views and the all-reduce would then average stale zeros): use ``zero()``, which
     also re-binds any view that was dropped; ``check_bound()`` raises if a gradient no longer aliases the bucket."""
 
-    def __init__(self, params, dtype=torch.float32):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, dtype=torch.float32, early=()):
+        """``early``: the parameters whose gradients are final first in backward (the seg head: its weight gradients are
+        complete before the upsampler's / trunk's data gradient starts).  They are laid out at the front of the bucket
+        and their slice is all-reduced asynchronously the moment the last of them has been accumulated
+        (``arm_early`` / ``finish``), overlapping the collective with the rest of backward -- what the reference's DDP
+        does with its bucketed hooks inside ``loss.backward()`` (core/utils/distributed.py:66-78)."""
+        early_ids = {id(p) for p in early if p.requires_grad}
+        params = [p for p in params if p.requires_grad]
+        self.params = [p for p in params if id(p) in early_ids] + [p for p in params if id(p) not in early_ids]
+        self.n_early = sum(1 for p in params if id(p) in early_ids)
+        self._early_numel = sum(p.numel() for p in self.params[:self.n_early])
+        self._pending = None   # (remaining early params, work handle) of the step in flight
+        self._hooks = []
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
@@ -134,3 +169,39 @@ class GradBucket:
         if work is not None:
             work.wait()
             self.flat.div_(get_world_size())
+
+    # ---- overlap of the early slice with the rest of backward
+    def arm_early(self):
+        """Call before ``loss.backward()``: when the last early parameter's gradient has been accumulated, the early
+        slice's all-reduce(sum) is issued with ``async_op=True`` (on RCCL it runs on the communicator's stream behind
+        an event of the compute stream).  No-op for a single process or without early parameters."""
+        if get_world_size() < 2 or not self.n_early:
+            self._pending = None
+            return
+        if not self._hooks:
+            for p in self.params[:self.n_early]:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_early_grad))
+        self._pending = [self.n_early, None]
+
+    def _on_early_grad(self, param):
+        if self._pending is None:
+            return
+        self._pending[0] -= 1
+        if self._pending[0] == 0:
+            self._pending[1] = dist.all_reduce(self.flat[:self._early_numel], op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish_overlapped(self):
+        """After backward: all-reduce what the early launch did not cover, wait for both, divide by the world size.
+        Equals ``all_reduce_mean()`` bit for bit on two ranks (the sum of two floats is order-independent) and up to
+        the collective's own reduction order beyond."""
+        world = get_world_size()
+        if world < 2:
+            return
+        pending, self._pending = self._pending, None
+        early_work = pending[1] if pending else None
+        lo = self._early_numel if early_work is not None else 0
+        if lo < self.flat.numel():
+            dist.all_reduce(self.flat[lo:], op=dist.ReduceOp.SUM)
+        if early_work is not None:
+            early_work.wait()
+        self.flat.div_(world)

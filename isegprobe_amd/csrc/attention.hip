@@ -229,8 +229,8 @@ __global__ __launch_bounds__(64 * NW) void attention_kernel(const bf16_t* __rest
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = db * 32 + 8 * g4 + 4 * hh;
                 *reinterpret_cast<uint2*>(op + d) =
-                    make_uint2(pack2o<!F16>(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv),
-                               pack2o<!F16>(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
+                    make_uint2(pack2o_sat<!F16>(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv),
+                               pack2o_sat<!F16>(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
             }
     }
 }
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + 16 * kk);
 
-    // ---- DMA: lane-constant offsets, the tile advances through the scalar offset
+    // ---- DMA: lane-constant offsets + the tile's offset, both in the range-checked vector offset
     const int kbytes = (int)(((long)(Lk - 1) * ksl + 64) * 2);  // (checked by the launcher: < 2^31)
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(K + (size_t)b * ksb + (size_t)h * ksh), 0, kbytes, 0x00020000);
@@ -356,12 +356,16 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
     }
     const int tile_stride = (int)(KB * ksl * 2);
     auto stage = [&](int tile, char* buf) {
-        const int so = tile * tile_stride;
+        // The tile offset goes into the VECTOR offset: the hardware range-checks voffset + inst_offset against
+        // num_records and leaves the scalar offset out of the check (LLVM AMDGPUUsage, raw buffer intrinsics: "soffset
+        // ... excluded from bounds checking"), and the rows past Lk of the last tile MUST read as zeros -- their P is 0,
+        // but 0 x NaN from whatever lies behind the last (batch, head) would poison the PV and ones products.
+        const unsigned so = (unsigned)(tile * tile_stride);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (ISP_LDS void*)(buf + (wid + NW * i) * 1024), 16, koff[i], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (ISP_LDS void*)(buf + G::TILE + (wid + NW * i) * 1024), 16, voff[i],
-                                                     so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (ISP_LDS void*)(buf + (wid + NW * i) * 1024), 16, koff[i] + so, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (ISP_LDS void*)(buf + G::TILE + (wid + NW * i) * 1024), 16, voff[i] + so,
+                                                     0, 0, 0);
         }
     };
 
@@ -533,8 +537,8 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = db * 32 + 8 * g4 + 4 * hh;
                 *reinterpret_cast<uint2*>(op + d) =
-                    make_uint2(pack2o<!F16>(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv),
-                               pack2o<!F16>(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
+                    make_uint2(pack2o_sat<!F16>(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv),
+                               pack2o_sat<!F16>(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv));
             }
     }
 }
@@ -561,6 +565,26 @@ int launch_attention64(const void* Q, const void* K, const void* V, void* O, int
 
 }  // namespace
 
+extern "C" int isp_attention_pipe_supported(int head_dim, int Lq, int Lk, long kv_stride_l);
+extern "C" int isp_attention_fwd_pipe(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
+                                      int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
+                                      long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
+                                      int f16, void* stream);
+
+// Base-2-logit problems the pipelined kernel takes (csrc/attention_pipe.hip: 256-query workgroups).  A short query
+// remainder (the ViT's 1025th token: Lq % 256 == 1) would cost a whole extra round of workgroups there; those queries go
+// to the 32-query kernel `rest` instead (one 128-query block per (batch, head), a few microseconds).
+template <class Rest>
+static int attention_pipe_split(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, int hd,
+                                long qsb, long qsl, long qsh, long ksb, long ksl, long ksh, long osb, long osl, long osh, int f16,
+                                void* stream, Rest&& rest) {
+    const int rem = Lq % 256;
+    const int main_q = (rem != 0 && rem <= 64 && Lq > 256) ? Lq - rem : Lq;
+    int rc = isp_attention_fwd_pipe(Q, K, V, O, B, H, main_q, Lk, hd, qsb, qsl, qsh, ksb, ksl, ksh, osb, osl, osh, f16, stream);
+    if (rc != ISP_OK || main_q == Lq) return rc;
+    return rest((const bf16_t*)Q + (size_t)main_q * qsl, (bf16_t*)O + (size_t)main_q * osl, Lq - main_q);
+}
+
 static int attention_fwd_impl(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
                               int head_dim, long q_stride_b, long q_stride_l, long q_stride_h, long kv_stride_b,
                               long kv_stride_l, long kv_stride_h, long o_stride_b, long o_stride_l, long o_stride_h,
@@ -573,7 +597,19 @@ static int attention_fwd_impl(const void* Q, const void* K, const void* V, void*
     ISP_CHECK_ARG(o_stride_b % 4 == 0 && o_stride_l % 4 == 0 && o_stride_h % 4 == 0);
     ISP_CHECK_ARG(!lse || lse_ld >= Lq);
     hipStream_t s = (hipStream_t)stream;
-    if (logit2 && head_dim != 64) return ISP_ERR_UNSUPPORTED;
+    if (logit2 && !lse && isp_attention_pipe_supported(head_dim, Lq, Lk, kv_stride_l)) {
+        auto rest = [&](const bf16_t* q2, bf16_t* o2, int lq2) {
+            if (head_dim == 64)
+                return launch_attention64<true>(q2, K, V, o2, B, H, lq2, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l,
+                                                kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, s);
+            return launch_attention<128>(q2, K, V, o2, B, H, lq2, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l,
+                                         kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 0.6931471805599453f, nullptr, 0, s);
+        };
+        return attention_pipe_split(Q, K, V, O, B, H, Lq, Lk, head_dim, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l,
+                                    kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 0, stream, rest);
+    }
+    // (generic kernels: their scale argument times log2(e) multiplies the scores; base-2 logits need 1 / log2(e))
+    if (logit2 && head_dim != 64) scale = 0.6931471805599453f;
     if (head_dim == 64) {
         // the 64-wide variant addresses keys through a 32-bit buffer range and assumes a key row >= its head slice
         static const bool generic64 = [] { const char* e = getenv("ISEGPROBE_ATT64"); return e && e[0] == '0'; }();
@@ -624,7 +660,8 @@ extern "C" int isp_attention_fwd_lse(const void* Q, const void* K, const void* V
                               kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, stream);
 }
 
-// head_dim 64 only: Q already carries softmax scale x log2(e) (Q K^T are base-2 logits) -- what the ViT trunk passes
+// Q already carries softmax scale x log2(e) (Q K^T are base-2 logits) -- what the ViT trunk (head_dim 64) and LoftUp's
+// inference stream (head_dim 128 / 256) pass
 // after folding that factor into the Q rows of its qkv weights (reference dinov2/layers/attention.py:62 applies the
 // scale to q after the projection; same product, one rounding).
 extern "C" int isp_attention_fwd_logit2(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
@@ -664,10 +701,32 @@ extern "C" int isp_attention_fwd_logit2_f16(const void* Q, const void* K, const 
                                             long kv_stride_b, long kv_stride_l, long kv_stride_h, long o_stride_b,
                                             long o_stride_l, long o_stride_h, void* stream) {
     ISP_CHECK_ARG(Q && K && V && O && B > 0 && H > 0 && Lq > 0 && Lk > 0);
-    if (head_dim != 64) return ISP_ERR_UNSUPPORTED;
+    ISP_CHECK_ARG((long)B * H <= 65535);
     ISP_CHECK_ARG(q_stride_b % 8 == 0 && q_stride_l % 8 == 0 && q_stride_h % 8 == 0);
     ISP_CHECK_ARG(kv_stride_b % 8 == 0 && kv_stride_l % 8 == 0 && kv_stride_h % 8 == 0);
     ISP_CHECK_ARG(o_stride_b % 4 == 0 && o_stride_l % 4 == 0 && o_stride_h % 4 == 0);
+    hipStream_t hs = (hipStream_t)stream;
+    const bool wide = (long)((Lq + 255) / 256) * B * H >= 2048;
+    auto generic = [&](const void* q2, void* o2, int lq2) -> int {  // base-2 logits on the generic kernel: scale = 1 / log2(e)
+#define ISP_ATT_F16G(HD, NW)                                                                                                     \
+    launch_attention<HD, NW, true>(q2, K, V, o2, B, H, lq2, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l, \
+                                   kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 0.6931471805599453f, nullptr, 0, hs)
+        if (head_dim == 128) return wide ? ISP_ATT_F16G(128, 8) : ISP_ATT_F16G(128, 4);
+        if (head_dim == 256) return wide ? ISP_ATT_F16G(256, 8) : ISP_ATT_F16G(256, 4);
+        return ISP_ERR_UNSUPPORTED;
+#undef ISP_ATT_F16G
+    };
+    if (isp_attention_pipe_supported(head_dim, Lq, Lk, kv_stride_l)) {
+        auto rest = [&](const bf16_t* q2, bf16_t* o2, int lq2) -> int {
+            if (head_dim == 64)
+                return launch_attention64<true, true>(q2, K, V, o2, B, H, lq2, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                                                      kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, hs);
+            return generic(q2, o2, lq2);
+        };
+        return attention_pipe_split(Q, K, V, O, B, H, Lq, Lk, head_dim, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l,
+                                    kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1, stream, rest);
+    }
+    if (head_dim != 64) return generic(Q, O, Lq);
     if (!(kv_stride_l >= 64 && ((long)(Lk - 1) * kv_stride_l + 64) * 2 < (1L << 31) &&
           (long)KB * kv_stride_l * 2 * ((Lk + KB - 1) / KB) < (1L << 31)))
         return ISP_ERR_UNSUPPORTED;

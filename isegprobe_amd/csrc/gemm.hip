@@ -303,7 +303,7 @@ struct EpAxpyResBf16 {  // out = res + alpha * (v + bias), bf16 (or half) in/out
         const float x2 = F16 ? h_lo(u.y) : __uint_as_float(u.y << 16), x3 = F16 ? h_hi(u.y) : __uint_as_float(u.y & 0xffff0000u);
         const float r0 = x0 + alpha * (v[0] + c.b.x), r1 = x1 + alpha * (v[1] + c.b.y);
         const float r2 = x2 + alpha * (v[2] + c.b.z), r3 = x3 + alpha * (v[3] + c.b.w);
-        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = make_uint2(pack2o<!F16>(r0, r1), pack2o<!F16>(r2, r3));
+        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = make_uint2(pack2o_sat<!F16>(r0, r1), pack2o_sat<!F16>(r2, r3));
     }
 };
 
@@ -342,8 +342,8 @@ struct EpBiasTapsReluBf16 {
                 }
             }
         }
-        return make_uint2(pack2o<!F16>(fmaxf(v[0] + b.x, 0.f), fmaxf(v[1] + b.y, 0.f)),
-                          pack2o<!F16>(fmaxf(v[2] + b.z, 0.f), fmaxf(v[3] + b.w, 0.f)));
+        return make_uint2(pack2o_sat<!F16>(fmaxf(v[0] + b.x, 0.f), fmaxf(v[1] + b.y, 0.f)),
+                          pack2o_sat<!F16>(fmaxf(v[2] + b.z, 0.f), fmaxf(v[3] + b.w, 0.f)));
     }
     __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c, unsigned outside) const {
         *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = pack(m, n, v, c, outside);
@@ -1381,13 +1381,20 @@ extern "C" int isp_conv3x3_nhwc_f16(const void* in, const void* Wt, int B, int H
     const long ldo = e->ldo > 0 ? e->ldo : N;
     if (ldo % 8 != 0 || (reinterpret_cast<size_t>(e->out) & 15) != 0) return ISP_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (N % 192 != 0) {  // 128-channel blocks (LoftUp's 448-channel maps): plain epilogues only
+    if (N % 192 != 0) {  // 128-channel blocks (LoftUp's 448-channel maps, 1024- and 128-wide heads)
         if (!patch128_ok(N)) return ISP_ERR_UNSUPPORTED;
         switch (e->kind) {
             case ISP_EP_BIAS_BF16:
                 return launch_conv_patch4<4, EpBiasActBf16<ACT_NONE, true>, true>(in, Wt, B, H, W, C, N, {(bf16_t*)e->out, e->bias, ldo}, s);
             case ISP_EP_BIAS_RELU_BF16:
                 return launch_conv_patch4<4, EpBiasActBf16<ACT_RELU, true>, true>(in, Wt, B, H, W, C, N, {(bf16_t*)e->out, e->bias, ldo}, s);
+            case ISP_EP_BIAS_TAPS_RELU_BF16:  // (heads of widths that tile into 128-channel blocks: ViT-L's 1024, the 128-wide fixtures)
+                if (!e->bias || !e->pos || e->img_h <= 0 || e->img_w <= 0 || ldo != N) return ISP_ERR_INVALID;
+                return launch_conv_patch4<4, EpBiasTapsReluBf16<true>, true>(in, Wt, B, H, W, C, N,
+                                                                             {(bf16_t*)e->out, e->bias, e->pos, e->img_h, e->img_w, ldo}, s);
+            case ISP_EP_RELU_DOT_PARTIAL_F32:
+                if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
+                return launch_conv_patch4<4, EpReluDotPartial, true>(in, Wt, B, H, W, C, N, {(float*)e->out, e->bias, e->gamma, M}, s);
             default:
                 return ISP_ERR_UNSUPPORTED;
         }

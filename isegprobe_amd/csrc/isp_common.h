@@ -51,6 +51,17 @@ __device__ __forceinline__ unsigned pack2o(float lo, float hi) {
     if constexpr (OUT_BF16) return pack2bf(lo, hi);
     else return pack2h(lo, hi);
 }
+// Output stores of the half-precision inference streams (ViT trunk, LoftUp, head convolutions): half's largest finite
+// value is 65504 and v_cvt_pk_f16_f32 overflows to inf beyond it, which the next LayerNorm / softmax turns into NaN.
+// Saturate instead (v_med3_f32, one instruction per value); bf16 has fp32's range and needs nothing.
+__device__ __forceinline__ unsigned pack2h_sat(float lo, float hi) {
+    return pack2h(__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f));
+}
+template <bool OUT_BF16>
+__device__ __forceinline__ unsigned pack2o_sat(float lo, float hi) {
+    if constexpr (OUT_BF16) return pack2bf(lo, hi);
+    else return pack2h_sat(lo, hi);
+}
 
 // 16-byte async global -> LDS copy.  LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {

@@ -26,7 +26,7 @@ __device__ __forceinline__ float4 load4_as_float(const T* p) {
 template <typename T>
 __device__ __forceinline__ void store4_from_float(T* p, float4 o) {
     if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(p) = o;
-    else if constexpr (std::is_same_v<T, f16_t>) *reinterpret_cast<uint2*>(p) = make_uint2(pack2h(o.x, o.y), pack2h(o.z, o.w));
+    else if constexpr (std::is_same_v<T, f16_t>) *reinterpret_cast<uint2*>(p) = make_uint2(pack2h_sat(o.x, o.y), pack2h_sat(o.z, o.w));
     else *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
 }
 

@@ -182,8 +182,7 @@ def vit_mlp_fused_supported(D, hid):
 
 
 def conv_takes_f16(N):
-    """Output-channel counts the f16 patch conv handles: 192-channel blocks, or 128-channel blocks wasting <= 15 %
-    (plain bias / ReLU epilogues only in that case)."""
+    """Output-channel counts the f16 patch conv handles: 192-channel blocks, or 128-channel blocks wasting <= 15 %."""
     return N % 192 == 0 or (N >= 128 and ((N + 127) // 128 * 128 - N) * 100 <= 15 * N)
 
 
@@ -455,8 +454,10 @@ def attention_lse(q, k, v, scale):
     return out, lse
 
 
-def attention(q, k, v, scale):
-    """q [B,Lq,H,hd], k/v [B,Lk,H,hd] bf16, hd in {64,128} (any strides with unit last-dim stride)."""
+def attention(q, k, v, scale, q_logit2=False):
+    """q [B,Lq,H,hd], k/v [B,Lk,H,hd] bf16 or f16, hd in {64,128,256} (any strides with unit last-dim stride).
+    q_logit2: q already carries scale * log2(e) (``ATTENTION_LOGIT2_SCALE`` at head_dim 64; LoftUp folds its own into the
+    query projection) -- the form the software-pipelined kernel takes; ``scale`` is then unused."""
     hd = q.shape[3]
     half = q.dtype == F16  # (LoftUp's inference stream)
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
@@ -468,9 +469,35 @@ def attention(q, k, v, scale):
     B, Lq, H, _ = q.shape
     Lk = k.shape[1]
     out = torch.empty(B, Lq, H, hd, device=q.device, dtype=q.dtype)
+    if q_logit2:
+        fn, name = ((_lib.lib().isp_attention_fwd_logit2_f16, "isp_attention_fwd_logit2_f16") if half
+                    else (_lib.lib().isp_attention_fwd_logit2, "isp_attention_fwd_logit2"))
+        check(fn(_p(q), _p(k), _p(v), _p(out), B, H, Lq, Lk, hd, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1),
+                 k.stride(2), out.stride(0), out.stride(1), out.stride(2), _stream()), name)
+        return out
     fn, name = (_lib.lib().isp_attention_fwd_f16, "isp_attention_fwd_f16") if half else (_lib.lib().isp_attention_fwd, "isp_attention_fwd")
     check(fn(_p(q), _p(k), _p(v), _p(out), B, H, Lq, Lk, hd, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1),
              k.stride(2), out.stride(0), out.stride(1), out.stride(2), float(scale), _stream()), name)
+    return out
+
+
+def attention_pipe(q, k, v):
+    """The software-pipelined forward (csrc/attention_pipe.hip; off by default in the dispatch, ISEGPROBE_ATT_PIPE=1) through
+    its own entry point: q [B,Lq,H,hd] carrying scale * log2(e), k/v [B,Lk,H,hd], bf16 or f16, hd 64 or 128, Lk >= 128."""
+    hd = q.shape[3]
+    half = q.dtype == F16
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _need(t, q.dtype if half else BF16, n, contiguous=False)
+        if t.stride(3) != 1 or t.shape[3] != hd:
+            raise IspError(f"{n}: unit last-dim stride and equal head_dim required")
+    if k.stride() != v.stride():
+        raise IspError("k and v must share strides")
+    B, Lq, H, _ = q.shape
+    Lk = k.shape[1]
+    out = torch.empty(B, Lq, H, hd, device=q.device, dtype=q.dtype)
+    check(_lib.lib().isp_attention_fwd_pipe(_p(q), _p(k), _p(v), _p(out), B, H, Lq, Lk, hd, q.stride(0), q.stride(1), q.stride(2),
+                                           k.stride(0), k.stride(1), k.stride(2), out.stride(0), out.stride(1), out.stride(2),
+                                           int(half), _stream()), "isp_attention_fwd_pipe")
     return out
 
 

@@ -633,6 +633,289 @@ def gen_inference():
     save("inference", **out)
 
 
+NOC_EVAL = dict(zoom={"skip_clicks": -1, "target_size": (56, 56)}, n_clicks=20, thresh=0.5, max_iou_thr=1.01, min_clicks=1)
+
+
+def _noc_scene(rng):
+    """One seeded scene of the NoC fixture: a cluster of 2-5 touching ellipses of different colours on a noise
+    background; the TARGET is a random subset of them, so only the clicks say which parts belong (the robot user needs
+    a positive click per missed part and a negative one per wrongly included neighbour).  Returns the uint8 image and
+    the object / ignore-band / distractor masks."""
+    from scipy.ndimage import binary_dilation
+    H, W = int(rng.integers(84, 151)), int(rng.integers(98, 201))
+    yy, xx = np.mgrid[:H, :W]
+    while True:
+        n = int(rng.integers(2, 6))
+        cen, rad = [(rng.uniform(0.4, 0.6) * H, rng.uniform(0.4, 0.6) * W)], [(rng.uniform(0.09, 0.2) * H, rng.uniform(0.08, 0.18) * W)]
+        for _ in range(n - 1):  # each further ellipse leans on an earlier one
+            j, a = int(rng.integers(len(cen))), rng.uniform(0, 2 * np.pi)
+            r = (rng.uniform(0.07, 0.17) * H, rng.uniform(0.06, 0.15) * W)
+            k = rng.uniform(0.75, 0.95)
+            cen.append((cen[j][0] + k * (rad[j][0] + r[0]) * np.sin(a), cen[j][1] + k * (rad[j][1] + r[1]) * np.cos(a)))
+            rad.append(r)
+        lab = np.zeros((H, W), np.int64)
+        for i in range(n):
+            lab[((yy - cen[i][0]) / rad[i][0]) ** 2 + ((xx - cen[i][1]) / rad[i][1]) ** 2 <= 1.0] = i + 1
+        member = rng.random(n) < 0.55
+        member[int(rng.integers(n))] = True
+        obj = np.isin(lab, 1 + np.nonzero(member)[0])
+        other = (lab > 0) & ~obj
+        band = binary_dilation(obj, iterations=2) & (lab == 0)
+        touches = obj[0].any() or obj[-1].any() or obj[:, 0].any() or obj[:, -1].any()
+        if obj.sum() > 150 and not touches and all((lab == i + 1).sum() > 40 for i in range(n)):
+            break
+    noise = rng.uniform(0, 64, ((H + 1) // 2, (W + 1) // 2, 3)).repeat(2, 0).repeat(2, 1)[:H, :W]  # 2x2 blocks: small PNGs
+    colours = np.concatenate([np.zeros((1, 3)), rng.uniform(90, 190, (n, 3))])
+    img = noise + colours[lab]
+    return img.clip(0, 255).astype(np.uint8), obj, band, other
+
+
+def _write_noc_tree(root, n=50, seed=12):
+    """BASELINE configs[0] / SURVEY.md 8(d) "Config 0": a 50-image tree in the GrabCut on-disk layout (grabcut.py:12-42:
+    data_GT/<name>.<ext>, boundary_GT/<name>.<ext>, mask values 0 / 128 = ignore band / 255 = object) of seeded scenes
+    -- a target (one or two overlapping ellipses), usually a distractor of the same brightness, a noise background,
+    image sizes 84..150 x 98..200.  Committed as data under tests/golden/noc_grabcut/."""
+    import shutil
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    shutil.rmtree(root, ignore_errors=True)
+    os.makedirs(os.path.join(root, "data_GT")), os.makedirs(os.path.join(root, "boundary_GT"))
+    for i in range(n):
+        img, obj, band, other = _noc_scene(rng)
+        mask = np.zeros(obj.shape, np.uint8)
+        mask[obj], mask[band] = 255, 128
+        ext_i, ext_m = ("png", "bmp") if i % 10 == 0 else ("png", "png")  # the real set mixes bmp / jpg / png
+        Image.fromarray(img).save(os.path.join(root, "data_GT", f"{i:03d}.{ext_i}"))
+        Image.fromarray(mask).save(os.path.join(root, "boundary_GT", f"{i:03d}.{ext_m}"))
+
+
+def _train_noc_model(model, steps, seed=71, S=56, P=12):
+    """CPU Adam training of the REFERENCE tiny model for the dataset-level fixture.  All parameters train here (in the
+    reference's experiments the backbone is a pretrained DINOv2; no pretrained weights exist offline, and a random frozen
+    4x4-token backbone cannot reach 90 % IoU) -- for the fixture the weights are data, stored in full.  Samples follow what
+    the predictor feeds the net during evaluation: the whole image or a zoom-in crop around the object resized to SxS
+    (bilinear, align_corners), click disks, previous prediction as the 4th channel; most samples take 1-6 no-grad
+    interaction rounds first (next click in the largest error region), as trainer.py:399-431 does."""
+    import torch.nn.functional as F
+    from scipy.ndimage import distance_transform_edt, label
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [int(steps * 0.6), int(steps * 0.85)], 0.3)
+    B = 16
+
+    def sample():
+        img, obj, band, other = _noc_scene(rng)
+        H, W = obj.shape
+        if rng.random() < 0.3:
+            r0, r1, c0, c1 = 0, H - 1, 0, W - 1
+        else:  # zoom-in crop: bounding box of (object, maybe the distractor) x 1.4 with jitter
+            m = obj | (other if rng.random() < 0.4 else False)
+            rr, cc = np.nonzero(m)
+            h, w = (rr.max() - rr.min() + 1) * rng.uniform(1.2, 1.7), (cc.max() - cc.min() + 1) * rng.uniform(1.2, 1.7)
+            cy, cx = 0.5 * (rr.min() + rr.max()) + rng.normal(0, 0.05 * h), 0.5 * (cc.min() + cc.max()) + rng.normal(0, 0.05 * w)
+            r0, r1 = int(max(0, round(cy - h / 2))), int(min(H - 1, round(cy + h / 2)))
+            c0, c1 = int(max(0, round(cx - w / 2))), int(min(W - 1, round(cx + w / 2)))
+        t = torch.from_numpy(np.concatenate([img.astype(np.float32) / 255, obj[..., None], band[..., None], other[..., None]], 2))
+        t = F.interpolate(t.permute(2, 0, 1)[None, :, r0:r1 + 1, c0:c1 + 1], size=(S, S), mode="bilinear", align_corners=True)[0]
+        return t[:3], (t[3] > 0.5).numpy(), (t[4] > 0.5).numpy() & ~(t[3] > 0.5).numpy(), (t[5] > 0.5).numpy()
+
+    def pick(region, centre):
+        if centre:  # the robot user's choice: the point furthest from the region's border
+            dt = distance_transform_edt(np.pad(region, 1))[1:-1, 1:-1]
+            r, c = np.unravel_index(np.argmax(dt), dt.shape)
+            return r, c
+        rr, cc = np.nonzero(region)
+        j = rng.integers(len(rr))
+        return rr[j], cc[j]
+
+    def add_click(pt, pol, rc):
+        k = int((pt[:, 2] >= 0).sum())
+        slot = np.nonzero(pt[pol * P:(pol + 1) * P, 2] < 0)[0]
+        if len(slot):
+            pt[pol * P + slot[0]] = (rc[0], rc[1], k)
+
+    def next_click(pt, pred, obj, band):
+        fn, fp = obj & ~pred, pred & ~obj & ~band
+        if max(fn.sum(), fp.sum()) == 0:
+            return
+        pol, err = (0, fn) if fn.sum() >= fp.sum() else (1, fp)
+        lab, n = label(err)
+        big = lab == (1 + np.argmax([(lab == i + 1).sum() for i in range(n)]))
+        add_click(pt, pol, pick(big, rng.random() < 0.7))
+
+    for step in range(steps):
+        imgs, pts, objs, bands = [], [], [], []
+        for _ in range(B):
+            im, obj, band, other = sample()
+            if obj.sum() < 10:
+                continue
+            pt = -np.ones((2 * P, 3), np.float32)
+            add_click(pt, 0, pick(obj, rng.random() < 0.7))
+            imgs.append(im), pts.append(pt), objs.append(obj), bands.append(band)
+        x = torch.cat([torch.stack(imgs), torch.zeros(len(imgs), 1, S, S)], 1)
+        rounds = rng.integers(0, 7, len(imgs)) * (rng.random(len(imgs)) < 0.7)
+        with torch.no_grad():
+            for it in range(int(rounds.max())):
+                prob = torch.sigmoid(model.eval()(x, torch.from_numpy(np.stack(pts)))["instances"])
+                for b in np.nonzero(rounds > it)[0]:
+                    x[b, 3] = prob[b, 0]
+                    next_click(pts[b], prob[b, 0].numpy() > 0.5, objs[b], bands[b])
+        model.train()
+        logits = model(x, torch.from_numpy(np.stack(pts)))["instances"]
+        tgt = torch.from_numpy(np.stack(objs)).float()[:, None]
+        wgt = torch.from_numpy(~np.stack(bands)).float()[:, None]
+        loss = (F.binary_cross_entropy_with_logits(logits, tgt, reduction="none") * wgt).sum() / wgt.sum()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step()
+        if step % 200 == 0 or step == steps - 1:
+            with torch.no_grad():
+                pm = logits > 0
+                iou = ((pm & (tgt > 0)).flatten(1).sum(1) / ((pm | (tgt > 0)) & (wgt > 0)).flatten(1).sum(1).clamp(min=1)).mean()
+            print(f"  noc-model training step {step}: bce {loss.item():.4f}  iou {iou.item():.3f}", flush=True)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model.eval()
+
+
+def gen_noc_dataset():
+    """The dataset-level half of BASELINE.json's metric ("NoC@90 parity on GrabCut"): the reference's OWN GrabCutDataset
+    (core/data/datasets/grabcut.py:12-42) + evaluate_dataset (core/inference/evaluation.py:22-40) + compute_noc_metric
+    (core/inference/utils.py:123-146) over a 50-image GrabCut-layout tree, driven the way evaluate.py:65-120 drives them
+    (NoBRS predictor, flip on, zoom-in from the first click with a fixed target size -- eval_mode "fixed56" for the 56x56
+    tiny model, get_predictor_and_zoomin_params utils.py:307-316 -- 20 clicks, thresh 0.5, print_ious -> target 1.01 so
+    every click runs, utils.py:254-255).  Model: the tiny bilinear model trained by _train_noc_model (weights stored here)."""
+    import cv2  # noqa: stub
+    from PIL import Image
+    cv2.COLOR_BGR2RGB = 4
+    cv2.imread = lambda path, flags=None: np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    cv2.cvtColor = lambda a, code: np.ascontiguousarray(a[:, :, ::-1])
+    from core.data.datasets.grabcut import GrabCutDataset
+    from core.inference.evaluation import evaluate_dataset
+    from core.inference.predictors import get_predictor
+    from core.inference.utils import compute_noc_metric
+    root = os.path.join(OUT, "noc_grabcut")
+    _write_noc_tree(root)
+    model = _train_noc_model(build_ref_model("bilinear", seed=70), steps=int(os.environ.get("NOC_TRAIN_STEPS", 3000)))
+    dataset = GrabCutDataset(root)
+    assert len(dataset) == 50
+    predictor = get_predictor(model, "NoBRS", torch.device("cpu"), prob_thresh=NOC_EVAL["thresh"], zoom_in_params=NOC_EVAL["zoom"])
+    clicks_all, near_all = [], []
+
+    def record(image_, gt_, pred_probs, sample_id, click_indx, clicks_list):
+        if click_indx == 0:
+            clicks_all.append(None), near_all.append([])
+        clicks_all[-1] = [(c.coords[0], c.coords[1], int(c.is_positive)) for c in clicks_list]
+        # pixels within the fp32 gate of the threshold (|logit| < 1e-3): see gen_inference
+        near_all[-1].append(int((np.abs(pred_probs.astype(np.float64) - 0.5) < 2.5e-4).sum()))
+
+    all_ious, _ = evaluate_dataset(dataset, predictor, pred_thr=NOC_EVAL["thresh"], max_iou_thr=NOC_EVAL["max_iou_thr"],
+                                   min_clicks=NOC_EVAL["min_clicks"], max_clicks=NOC_EVAL["n_clicks"], callback=record)
+    thrs = [0.8, 0.85, 0.9]
+    noc, noc_std, over = compute_noc_metric(all_ious, thrs, max_clicks=NOC_EVAL["n_clicks"])
+    ious = np.stack(all_ious)
+    assert ious.shape == (50, 20)
+    per_obj = np.array([[(np.argmax(a >= t) + 1) if (a >= t).any() else 20 for t in thrs] for a in all_ious])
+    print(f"  NoC@80/85/90 = {np.round(noc, 3)}  >=20: {over}  mIoU@1..20 = {np.round(ious.mean(0), 3)}")
+    print(f"  NoC@90 per object: {per_obj[:, 2].tolist()}")
+    mid = ((per_obj[:, 2] > 1) & (per_obj[:, 2] < 20)).sum()
+    assert mid >= 26, f"NoC@90 must be neither 1 nor 20 for most objects, got {mid}/50"
+    out = {"ious": ious.astype(np.float32), "noc": np.array(noc), "noc_std": np.array(noc_std), "noc_over": np.array(over),
+           "noc_per_object": per_obj.astype(np.int64), "clicks": np.array(clicks_all, dtype=np.int64),
+           "near_counts": np.array(near_all, dtype=np.int64), "names": np.array(dataset.dataset_samples)}
+    for k, v in sd_np(model).items():
+        out["w::" + k] = v
+    for i in range(len(dataset)):  # what the reference's reader returned: the test holds the product's reader to it
+        smp = dataset.get_sample(i)
+        out[f"shape_{i}"] = np.array(smp.image.shape)
+        out[f"image_sum_{i}"] = np.array(smp.image.astype(np.int64).sum())
+        out[f"gt_counts_{i}"] = np.array([(smp.gt_mask(1) == v).sum() for v in (-1, 0, 1)])
+    save("noc_dataset", **out)
+
+
+def seed_by_name_(module, seed, skip=()):
+    """Seeded weights that do not depend on the order modules were registered in: every parameter draws from its own
+    generator keyed on (crc32 of its name) ^ seed.  Same recipe in tests/helpers.py -- frozen tensors that are not stored
+    (the 22 M DINOv2-S/14 parameters) are regenerated on the test side and verified by checksum."""
+    import zlib
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if name in skip:
+                continue
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ seed) & 0x7FFFFFFF)
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) / p[0].numel() ** 0.5)
+            elif "gamma" in name or name.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+        for name, p in module.named_parameters():
+            if name.endswith("pos_embed") and name not in skip:
+                p.mul_(0.3)
+    return module
+
+
+def gen_checkpoint():
+    """SURVEY.md 8(b) "Checkpoint format": a file written by the REFERENCE's own save_checkpoint (core/utils/misc.py:36-68)
+    for a model built by the reference's own constructors -- iSegProbeModel(@serialize, iseg_probe_model.py:34-46) with the
+    real core.utils.model_builder.ModelBuilder (pickled into the config, serialization.py:10-38) -- the configs[0]
+    architecture: DINOv2-S/14, clicks before the backbone, bilinear upsampler, ConvSegHead, 224 x 224.  Only torch.hub.load
+    (DINOv2.py:491, no network) is replaced, by the same file's vit_small().  save_cfg keeps the click encoder and the
+    classifier (0.9 MB; the reference's own exclude mechanism drops head.convs, which -- like the frozen backbone -- are
+    regenerated from the name-keyed seed on both sides and checked by checksum).  Next to it: the reference's logits."""
+    import hashlib
+    from pathlib import Path
+    import core.model.featurizers.DINOv2 as refdv
+    from core.model.iseg_probe_model import iSegProbeModel
+    from core.utils.misc import save_checkpoint
+    from core.utils.model_builder import ModelBuilder
+    real_hub_load = torch.hub.load
+    torch.hub.load = lambda repo, arch, **kw: refdv.vit_small(patch_size=14, img_size=518, init_values=1.0, block_chunks=0)
+    try:
+        model = iSegProbeModel(
+            backbone_cfg=dict(type="dinov2", params=dict(feats_injection_mode="before_backbone")),
+            head_cfg=dict(type="convhead", params=dict(in_channels=384, num_layers=2, num_classes=1)),
+            embed_coords_cfg=dict(type="patchEmbed", params=dict(img_size=(224, 224), patch_size=(14, 14), embed_dim=384)),
+            neck_cfg=None,
+            upsampler_cfg=dict(type="bilinear", params=None),
+            save_cfg=dict(embed_coords=True, backbone=False, upsampler=False, head=dict(save=True, exclude=["convs"])),
+            architecture="backbone_upsampler_head",
+            model_builder=ModelBuilder(),
+            use_disks=True, norm_radius=5, with_prev_mask=True)
+    finally:
+        torch.hub.load = real_hub_load
+    seed_by_name_(model, 80)
+    model.eval()
+    ckpt_dir = Path(OUT) / "ref_checkpoint"
+    save_checkpoint(model, ckpt_dir, verbose=False)
+    path = ckpt_dir / "last_checkpoint.pth"
+    saved = torch.load(path, map_location="cpu", weights_only=False)
+    assert sorted(saved["state_dict"]) == ["embed_coords.proj.bias", "embed_coords.proj.weight", "head.classifier.bias", "head.classifier.weight"]
+    assert type(saved["config"]["params"]["model_builder"]["value"]).__module__ == "core.utils.model_builder"
+    rng = np.random.default_rng(13)
+    torch.manual_seed(13)
+    img = torch.rand(1, 4, 224, 224)
+    img[:, 3] = (img[:, 3] > 0.8).float()
+    pts = torch.from_numpy(rand_points(rng, 1, 6, 224, 224))
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        logits = model(img, pts)["instances"]
+    out = {"image": img.numpy(), "points": pts.numpy(), "logits": logits.numpy(), "seed": np.array(80)}
+    for k, v in saved["state_dict"].items():
+        out["saved::" + k] = v.numpy()
+    sha = lambda t: np.frombuffer(hashlib.sha256(t.detach().contiguous().numpy().tobytes()).digest(), np.uint8)
+    for k, v in model.state_dict().items():  # every tensor the file does NOT hold: checksum of the regenerated value
+        if k not in saved["state_dict"]:
+            out["sha256::" + k] = sha(v)
+    print(f"  {path} ({os.path.getsize(path) / 1024:.0f} KiB); logits {logits.min().item():.3f}..{logits.max().item():.3f}, "
+          f"positive fraction {(logits > 0).float().mean().item():.3f}")
+    save("checkpoint", **out)
+
+
 def gen_train_step():
     """the reference iSegProbeModel in .train() (trainer.py:214 -- the frozen upsamplers'
     BatchNorm2d layers then use BATCH statistics and update their running ones), one NormalizedFocalLossSigmoid step
@@ -832,9 +1115,9 @@ def gen_crops():
 def main():
     torch.set_num_threads(4)
     install_standins()
-    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "train_step", "datasets", "crops"]
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "noc_dataset", "checkpoint", "train_step", "datasets", "crops"]
     fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino, "simple_vit": gen_simple_vit, "maskclip": gen_maskclip,
-           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "train_step": gen_train_step, "datasets": gen_datasets, "crops": gen_crops}
+           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "noc_dataset": gen_noc_dataset, "checkpoint": gen_checkpoint, "train_step": gen_train_step, "datasets": gen_datasets, "crops": gen_crops}
     for w in which:
         fns[w]()
 

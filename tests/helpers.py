@@ -53,3 +53,26 @@ def rand_points(rng, B, P, H, W):
                 pts[b, pol * P + i] = (rng.integers(0, H), rng.integers(0, W), k)
                 k += 1
     return pts
+
+
+def seed_by_name_(module, seed, skip=()):
+    """tests/golden/gen_golden.py::seed_by_name_ (kept in sync by hand): every parameter draws from its own generator
+    keyed on (crc32 of its name) ^ seed, so the values do not depend on module registration order.  Used where a
+    fixture cannot hold the frozen tensors (22 M DINOv2-S/14 parameters): both sides regenerate them and the fixture
+    carries their sha256."""
+    import zlib
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if name in skip:
+                continue
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ seed) & 0x7FFFFFFF)
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) / p[0].numel() ** 0.5)
+            elif "gamma" in name or name.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+        for name, p in module.named_parameters():
+            if name.endswith("pos_embed") and name not in skip:
+                p.mul_(0.3)
+    return module

@@ -42,6 +42,29 @@ def _worker(rank, world, port, out):
     expected = sum(both) / world
     assert torch.allclose(bucket.flat, expected)
     assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in bucket.params)  # grads are views of the bucket
+    # 2b) the overlapped form: the "head" slice (model[2], last layer = first gradients of backward) is all-reduced from
+    # inside backward, the rest after it; same averages as the one-shot collective, early parameters first in the bucket
+    ob = D.GradBucket(model.parameters(), early=list(model[2].parameters()))
+    assert ob.params[0] is model[2].weight and ob.n_early == 2
+    fired = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t, **kw: (fired.append((t.numel(), kw.get("async_op", False))), orig(t, **kw))[1]
+    ob.zero()
+    ob.arm_early()
+    model(x).sum().backward()
+    assert fired == [(4 + 1, True)], fired           # issued by the accumulate hook of the last head parameter
+    ob.check_bound()
+    ob.finish_overlapped()
+    dist.all_reduce = orig
+    assert fired[1:] == [(3 * 4 * 9 + 4, False)]
+    by_param = {id(p): p.grad.clone() for p in ob.params}
+    for p, off in zip(bucket.params, bucket._offsets):
+        assert torch.allclose(by_param[id(p)].reshape(-1), expected[off:off + p.numel()])
+    # 2c) DDP's buffer broadcast: rank-local running statistics are replaced by rank 0's
+    bn = torch.nn.BatchNorm2d(4)
+    bn.running_mean.fill_(float(rank + 1)), bn.running_var.fill_(3.0 * (rank + 1))
+    assert D.broadcast_buffers(bn) == 2
+    assert torch.equal(bn.running_mean, torch.ones(4)) and torch.equal(bn.running_var, torch.full((4,), 3.0))
     # 3) loss reduce to rank 0 and max-over-ranks timing
     red = D.reduce_loss_dict({"a": torch.tensor(float(rank + 1)), "b": torch.tensor(10.0 * (rank + 1))})
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)

@@ -298,6 +298,78 @@ def test_attention_packed(ops, B, L, heads):
     assert rel_err(out2, ref2) < 2e-2
 
 
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("L", [97, 130, 1025])
+def test_attention_tail_rows_read_as_zeros(ops, half, L):
+    """The head_dim-64 kernel stages whole 64-key tiles; the rows past Lk of the last tile must come back as ZEROS
+    from the buffer range check (their P is 0, but 0 x NaN is NaN).  The packed qkv sits at the END of a NaN-filled
+    allocation, so for the last (batch, head) anything read behind the last key is NaN."""
+    torch.manual_seed(L)
+    B, heads, D = 2, 2, 128
+    dt = torch.float16 if half else BF
+    n = B * L * 3 * D
+    big = torch.full((n + 64 * 3 * D + 4096,), float("nan"), device="cuda", dtype=dt)
+    qkv = big[:n].view(B * L, 3 * D)
+    qkv.copy_(torch.randn(B * L, 3 * D, device="cuda").to(dt))
+    out = ops.attention_packed_qkv(qkv, B, L, heads, None, q_logit2=True)
+    assert torch.isfinite(out.float()).all()
+    q, k, v = qkv.float().view(B, L, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = ((q @ k.transpose(-2, -1) * math.log(2.0)).softmax(-1) @ v).transpose(1, 2).reshape(B * L, D)
+    assert (out.float() - ref).abs().max().item() < 2e-2
+    if not half:
+        out2 = ops.attention_packed_qkv(qkv, B, L, heads, 0.125)
+        ref2 = ((q * 0.125 @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B * L, D)
+        assert torch.isfinite(out2.float()).all() and (out2.float() - ref2).abs().max().item() < 2e-2
+
+
+def _attn_ref(q2, k, v):
+    """fp64 softmax over base-2 logits: q2 [B,Lq,H,hd] already carries scale * log2(e)."""
+    sc = q2.double().permute(0, 2, 1, 3) @ k.double().permute(0, 2, 3, 1) * math.log(2.0)
+    return (sc.softmax(-1) @ v.double().permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("hd,B,H,Lq,Lk", [(64, 2, 2, 1025, 1025), (64, 1, 3, 512, 192), (64, 1, 1, 300, 130), (64, 2, 1, 256, 128),
+                                          (128, 1, 2, 512, 1024), (128, 2, 1, 700, 257), (128, 1, 4, 256, 448), (128, 1, 1, 1030, 193)])
+def test_attention_pipelined_kernel(ops, hd, B, H, Lq, Lk, half):
+    """csrc/attention_pipe.hip (64 queries per wave as two streams, QK^T of tile t+1 / PV of tile t interleaved with the
+    softmax; an experiment that is off by default, called here through its own entry point): full and ragged last key
+    tiles, query counts that are / are not multiples of the 256-query workgroup, strided packed operands, both dtypes;
+    against an fp64 softmax."""
+    torch.manual_seed(hd + Lq + Lk)
+    dt = torch.float16 if half else BF
+    q = (torch.randn(B, Lq, H, hd, device="cuda") * (hd ** -0.5 * 1.4426950408889634) * 1.5).to(dt)
+    kv = torch.randn(B, Lk, 2, H, hd, device="cuda").to(dt)   # K and V interleaved: equal, non-trivial strides
+    k, v = kv[:, :, 0], kv[:, :, 1]
+    out = ops.attention_pipe(q, k, v)
+    ref = _attn_ref(q, k, v)
+    err = (out.double() - ref).abs().max().item()
+    assert torch.isfinite(out.float()).all() and err < 2e-2, err
+
+
+@pytest.mark.parametrize("hd", [64, 128])
+@pytest.mark.parametrize("spike_key,gain", [(3, 300.0), (70, 30.0), (200, 300.0), (200, 9.0), (319, 60.0), (320, 300.0)])
+def test_attention_pipelined_deferred_max(ops, hd, spike_key, gain):
+    """The pipelined kernel moves a row's reference maximum only when a tile exceeds it by more than 2^6 -- at the END of
+    the iteration that computed the tile, after the previous tile's PV product.  Spikes below, near and far above the
+    threshold in the first, a middle and the last (one-key) tile, for a query of either stream of a wave; and a row that is
+    ~ -90 in the first tile and ~ 0 later."""
+    torch.manual_seed(spike_key)
+    B, L, H = 1, 321, 1
+    q = torch.randn(B, L, H, hd, device="cuda") * 0.5
+    k = torch.randn(B, L, H, hd, device="cuda") * 0.5
+    v = torch.randn(B, L, H, hd, device="cuda")
+    for qi in (17, 45):  # stream 0 / stream 1 of wave 0
+        k[0, spike_key, 0] += q[0, qi, 0] * gain / q[0, qi, 0].square().sum() / 2
+    u = torch.zeros(hd, device="cuda")
+    u[5] = 1.0
+    k[0, :64, 0] += 3 * u
+    q[0, 40, 0] = -30 * u
+    out = ops.attention_pipe(bf(q), bf(k), bf(v))
+    ref = _attn_ref(bf(q), bf(k), bf(v))
+    assert (out.double() - ref).abs().max().item() < 2e-2
+
+
 def test_attention_online_softmax_rescale(ops):
     """A key whose score dwarfs the rest in a LATE tile forces the running-max rescale."""
     B, L, heads = 1, 256, 1

@@ -72,3 +72,15 @@ def test_jbu_resize_fusion_condition():
         assert (y0 // 8 == grp).all() and (y1 // 8 == grp).all(), m
         # and the 16-column group of a 14-pixel strip
         assert (y0 // 16 == np.arange(OH) // 14).all() and (y1 // 16 == np.arange(OH) // 14).all(), m
+
+
+def test_eval_mode_zoom_in_params():
+    """core/inference/utils.py:301-316 (eval_ritm=False): fixed<H>, fixed<H>,<W>, cvpr (448 / DAVIS 672)."""
+    import pytest
+    from isegprobe_amd.core.inference.utils import get_zoom_in_params
+    assert get_zoom_in_params("fixed224") == {"skip_clicks": -1, "target_size": (224, 224)}
+    assert get_zoom_in_params("fixed400,600", "SBD") == {"skip_clicks": -1, "target_size": (400, 600)}
+    assert get_zoom_in_params("cvpr", "GrabCut") == {"skip_clicks": -1, "target_size": (448, 448)}
+    assert get_zoom_in_params("cvpr", "DAVIS") == {"skip_clicks": -1, "target_size": (672, 672)}
+    with pytest.raises(NotImplementedError):
+        get_zoom_in_params("original")

@@ -505,3 +505,77 @@ def test_cfg4_vitb14_loftup_forward_and_gradients_vs_oracle():
         print(f"cfg4 grad {k:32s} rms-rel {rms:.3e}  cos {cos:.6f}")
         assert cos > 0.975 and rms < 0.25, (k, cos, rms)
     assert all(p.grad is None for n, p in named.items() if n.startswith(("backbone.", "upsampler.")))
+
+
+@pytest.mark.parametrize("outlier", ["moderate", "extreme"])
+def test_f16_trunk_with_outlier_channels(outlier):
+    """Real DINOv2 checkpoints carry a few large-norm channels / LayerScale entries; every fixture so far had O(1)
+    activations.  A 4-block S-width trunk whose fc1 bias, fc2 rows and LayerScale entries are blown up on a few channels:
+    "moderate" (x40: hidden activations of a few hundred, stream entries of a few thousand) must stay on the IEEE-half
+    stream and beat the bf16 stream's error; "extreme" (hidden pre-activations beyond half's 65504) must be caught by
+    the range probe of the first half forward and rerouted to the bf16 stream -- never inf / NaN, same output as
+    ISEGPROBE_VIT_F16=0 would give."""
+    from isegprobe_amd.core.model.featurizers import DINOv2 as dv
+    from oracle import vit as ovit
+    torch.manual_seed(3)
+    vit = dict(img_size=224, patch_size=14, embed_dim=384, depth=4, num_heads=6)
+    f = seeded_(dv.DINOv2Featurizer("custom", "no_injection", vit_kwargs=vit), 17)
+    gain = 40.0 if outlier == "moderate" else 4000.0
+    with torch.no_grad():
+        f.model.pos_embed.mul_(0.3)
+        for blk in f.model.blocks:
+            blk.mlp.fc1.bias[5:9] += gain / 8          # a few hidden units far from zero
+            blk.mlp.fc1.weight[5:9] *= gain / 4
+            blk.mlp.fc2.weight[:, 5:9] *= 0.05          # (their contribution to the stream stays finite)
+            blk.ls2.gamma[100:103] *= gain / 4          # outlier channels of the residual stream
+            blk.attn.qkv.weight[384 + 100:384 + 103] *= 4
+    w = {k: v.clone() for k, v in f.model.state_dict().items()}
+    x = torch.randn(2, 3, 112, 112)
+    torch.set_num_threads(16)
+    ref = ovit.dinov2_features(x, w, patch=14, depth=4, heads=6)
+    f = f.cuda().eval()
+    assert dv.VIT_F16
+    with torch.no_grad():
+        y16 = f(x.cuda()).float().cpu()
+        P = f.packed()
+        dv.VIT_F16 = False
+        try:
+            ybf = f(x.cuda()).float().cpu()
+        finally:
+            dv.VIT_F16 = True
+    assert torch.isfinite(y16).all() and torch.isfinite(ybf).all()
+    e16, ebf = (y16 - ref).abs().max().item(), (ybf - ref).abs().max().item()
+    print(f"{outlier}: half-stream peak {P['f16_peak']:.4g} f16_ok {P['f16_ok']}; max err f16 path {e16:.3g}, bf16 path {ebf:.3g}, ref max {ref.abs().max():.3g}")
+    if outlier == "moderate":
+        assert P["f16_ok"] and 100 < P["f16_peak"] < 0.5 * 65504
+        assert e16 <= ebf and e16 < 3e-2 * max(1.0, ref.abs().max().item())
+    else:
+        assert not P["f16_ok"] and P["f16_peak"] >= 0.5 * 65504
+        assert torch.equal(y16, ybf)  # rerouted: the bf16 stream's result, bit for bit
+        assert ebf < 6e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_reference_checkpoint_logits(golden):
+    """The checkpoint the REFERENCE wrote (tests/golden/ref_checkpoint/, gen_golden.py::gen_checkpoint: DINOv2-S/14, clicks
+    before the backbone, bilinear, ConvSegHead, 224 x 224 = BASELINE configs[0]'s model) loaded by load_is_model; the tensors
+    the file does not hold regenerated from the name-keyed seed (checksums: tests/test_checkpoint_cpu.py).  Logits against
+    the reference's own: 1e-2 on the 16-bit path, 1e-3 in the fp32 mode."""
+    import os
+    from conftest import GOLDEN
+    from helpers import seed_by_name_
+    from isegprobe_amd.core.inference.utils import load_is_model
+    g = golden("checkpoint")
+    path = os.path.join(GOLDEN, "ref_checkpoint", "last_checkpoint.pth")
+    model = load_is_model(path, torch.device("cuda"))
+    seed_by_name_(model, int(g["seed"]), skip={k[len("saved::"):] for k in g if k.startswith("saved::")})
+    image, points, ref = (torch.from_numpy(g[k]) for k in ("image", "points", "logits"))
+    with torch.no_grad():
+        y = model(image.cuda(), points.cuda())["instances"].cpu()
+        y32 = model.forward_fp32(image.cuda(), points.cuda())["instances"].cpu()
+    e, e32 = (y - ref).abs(), (y32 - ref).abs()
+    print(f"reference checkpoint: 16-bit path max {e.max():.3g} rms {e.pow(2).mean().sqrt():.3g}; fp32 mode max {e32.max():.3g}; "
+          f"logits {ref.min():.3f}..{ref.max():.3f}")
+    assert e32.max().item() < 1e-3
+    assert e.max().item() < 1e-2
+    decided = ref.abs() > 1e-2
+    assert ((y > 0) == (ref > 0))[decided].all()

@@ -1,0 +1,88 @@
+"""GPU: the dataset-level half of BASELINE.json's metric -- "NoC@90 parity on GrabCut" (configs[0]).
+
+tests/golden/noc_dataset.npz holds what the REFERENCE's own GrabCutDataset + evaluate_dataset + compute_noc_metric
+produced over the committed 50-image GrabCut-layout tree tests/golden/noc_grabcut/ (gen_golden.py::gen_noc_dataset:
+NoBRS predictor, flip, zoom-in from the first click at the tiny model's 56 x 56, 20 clicks, thresh 0.5, every click run).
+Here the same evaluation goes through THIS repo's evaluate.py (checkpoint -> load_is_model -> get_predictor ->
+evaluate_dataset -> results table), on the HIP path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, weights_from
+from helpers import build_model
+
+pytestmark = pytest.mark.gpu
+THRS = (0.8, 0.85, 0.9)
+
+
+def _checkpoint(golden, tmp_path):
+    from isegprobe_amd.core.utils.misc import save_checkpoint
+    g = golden("noc_dataset")
+    model = build_model("bilinear")
+    missing, unexpected = model.load_state_dict(weights_from(g, "w"), strict=False)
+    assert not unexpected and all("mask_token" in k for k in missing), (missing, unexpected)
+    return g, save_checkpoint(model, tmp_path / "ckpt", verbose=False)
+
+
+def _run(golden, tmp_path, extra):
+    import evaluate
+    g, ckpt = _checkpoint(golden, tmp_path)
+    res = evaluate.main(["--checkpoint", str(ckpt), "--dataset", os.path.join(GOLDEN, "noc_grabcut"), "--dataset-name", "GrabCut",
+                         "--eval-mode", "fixed56", "--n-clicks", "20", "--thresh", "0.5", "--logs", str(tmp_path / "logs")] + extra)
+    (name, all_ious, table), = res
+    assert name == "GrabCut" and len(all_ious) == 50 and all(len(a) == 20 for a in all_ious)
+    return g, np.stack(all_ious), table
+
+
+def _noc(ious):
+    return np.array([[(np.argmax(a >= t) + 1) if (a >= t).any() else 20 for t in THRS] for a in ious])
+
+
+def test_fixture_is_not_degenerate(golden):
+    g = golden("noc_dataset")
+    per = g["noc_per_object"][:, 2]
+    assert ((per > 1) & (per < 20)).sum() >= 26           # NoC@90 neither 1 nor 20 for most objects
+    assert np.array_equal(_noc(g["ious"]), g["noc_per_object"])
+    assert (g["clicks"][:, :, 2] == 0).any()              # negative clicks occur
+
+
+@pytest.mark.parametrize("clicker", ["device", "host"])
+def test_noc_dataset_identical_to_reference_fp32(golden, tmp_path, clicker):
+    """Under the fp32-accurate forward the 50-object evaluation reproduces the reference's: NoC@80/85/90 per object and
+    in the mean identical; the per-object IoU arrays identical wherever no prediction had a pixel within the fp32 gate of
+    the threshold (|logit| < 1e-3; the generator stored those counts), and within a few pixels' worth of IoU elsewhere."""
+    g, ious, table = _run(golden, tmp_path, ["--fp32"] + (["--host-clicker"] if clicker == "host" else []))
+    ref = g["ious"]
+    noc = _noc(ious)
+    diff_obj = np.nonzero((noc != g["noc_per_object"]).any(1))[0]
+    exact = np.array([np.array_equal(a, b) for a, b in zip(ious, ref)])
+    clean = g["near_counts"].sum(1) == 0                  # objects none of whose 20 predictions had a near-threshold pixel
+    print(f"[{clicker}] NoC@80/85/90 = {noc.mean(0)} (reference {g['noc']}); objects with identical IoU arrays {int(exact.sum())}/50 "
+          f"({int(clean.sum())} have no near-threshold pixel at all); max |dIoU| {np.abs(ious - ref).max():.2e}; NoC differs on {diff_obj.tolist()}")
+    assert exact[clean].all()
+    assert np.abs(ious - ref).max() < 5e-3
+    assert len(diff_obj) == 0, (diff_obj, noc[diff_obj], g["noc_per_object"][diff_obj])
+    assert np.allclose(noc.mean(0), g["noc"]) and np.array_equal((noc == 20).sum(0), g["noc_over"])
+    for k, t in enumerate(("NoC@80%", "NoC@85%", "NoC@90%")):   # the printed table row carries the same numbers
+        assert abs(table[t] - g["noc"][k]) < 1e-12
+
+
+def test_noc_dataset_16bit_path(golden, tmp_path):
+    """The product (16-bit operand) path on the same evaluation.  Logits carry <= 1e-2 of rounding noise, which moves
+    mask pixels near the threshold and, through the robot user's argmax of a distance transform, sometimes a click.
+    Required: mean NoC within 0.25 click of the reference at every threshold; the objects whose NoC differs are printed
+    with the first click at which their IoU sequence leaves the reference's."""
+    g, ious, table = _run(golden, tmp_path, [])
+    ref, noc = g["ious"], _noc(ious)
+    rows = []
+    for i in np.nonzero((noc != g["noc_per_object"]).any(1))[0]:
+        first = int(np.argmax(np.abs(ious[i] - ref[i]) > 5e-3)) + 1 if (np.abs(ious[i] - ref[i]) > 5e-3).any() else 0
+        rows.append((int(i), noc[i].tolist(), g["noc_per_object"][i].tolist(), first))
+    print(f"NoC@80/85/90 = {noc.mean(0)} (reference {g['noc']}); mIoU@20 {ious[:, -1].mean():.4f} (reference {ref[:, -1].mean():.4f}); "
+          f"{len(rows)} objects differ: (object, NoC here, NoC reference, first click with |dIoU| > 5e-3) {rows}")
+    assert np.abs(noc.mean(0) - g["noc"]).max() <= 0.25
+    assert len(rows) <= 8
+    assert abs(ious.mean() - ref.mean()) < 5e-3

@@ -302,3 +302,24 @@ def test_loftup_768_vs_oracle():
     rms = (got - want).pow(2).mean().sqrt().item() / want.pow(2).mean().sqrt().item()
     print(f"loftup768 grad: cos {cos:.6f} rms-rel {rms:.3e}")
     assert cos > 0.995 and rms < 0.1
+
+
+@pytest.mark.parametrize("n_dim", [44, 240])
+def test_loftup_odd_widths_fall_back_to_bf16(n_dim):
+    """Pixel-stream widths whose padded count (64 for n_dim 44, 320 for n_dim 240) does not tile into the f16 conv's 192- /
+    128-channel blocks must take the bf16 stream at inference instead of raising (the half stream is selected per width)."""
+    from isegprobe_amd import hip_ops as ops
+    from isegprobe_amd.core.model.upsamplers import LoftUpUpsampler
+    from oracle import upsamplers as oups
+    torch.manual_seed(n_dim)
+    up = seeded_(LoftUpUpsampler(None, n_dim=n_dim), 13)
+    assert not ops.conv_takes_f16(up._cp())
+    w = {"upsampler." + k: v.clone() for k, v in up.upsampler.state_dict().items()}
+    src, gd = torch.randn(2, n_dim, 3, 2), torch.rand(2, 3, 42, 28)
+    ref = oups.loftup(src, gd, w, "upsampler.")
+    with torch.no_grad():
+        y = _f32(up.cuda().eval()(src.cuda(), gd.cuda()))
+    err = (y - ref).abs()
+    print(f"loftup n_dim {n_dim}: max {err.max().item():.3g} rms {err.pow(2).mean().sqrt().item():.3g}")
+    assert err.max().item() < 6e-2 * max(1.0, ref.abs().max().item())
+    assert err.pow(2).mean().sqrt().item() < 1e-2 * max(1.0, ref.pow(2).mean().sqrt().item())
