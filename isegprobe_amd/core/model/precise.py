@@ -384,6 +384,7 @@ def forward_fp32(model, image, points):
             not isinstance(head, _StackedHead):
         raise IspError("forward_fp32 covers the identity / bilinear / LiFT / LoftUp / FeatUp-JBU upsamplers and the stacked conv heads")
     cache = model.__dict__.setdefault("_fp32_splits", _WeightSplits())
+    save = getattr(model, "_fp32_save", None)  # (set by click_head_gradients_fp32 for the duration of its forward)
     with torch.no_grad():
         image, prev_mask = model.prepare_input(image)
         coord = coord_after = None
@@ -416,6 +417,8 @@ def forward_fp32(model, image, points):
             Ac = F.unfold(coord_after, p_, stride=p_).transpose(1, 2).reshape(B * T, -1).contiguous()
             cw, cb = model.embed_coords.proj.weight, model.embed_coords.proj.bias
             feats = feats + _linear(Ac, _w3(cache, "embed_after", lambda: cw.flatten(1), cw), f32(cb))
+            if save is not None:
+                save["Ac"] = Ac
         y = feats.view(B, h, w, D)
         if isinstance(up, LiFTUpsampler):
             y = _lift(up, cache, y, image)
@@ -430,7 +433,11 @@ def forward_fp32(model, image, points):
             y = planes.permute(0, 2, 3, 1).contiguous()
         Bh, Hh, Wh, C = y.shape
         act = None
+        if save is not None:
+            save.update(geom=(B, h, w, H, W), layer_in=[], lowres=(Hh, Wh) != (h, w))
         for j, layer in enumerate(head.convs):
+            if save is not None:
+                save["layer_in"].append((y, act))  # pre-activation input of layer j and the activation applied on the way in
             cw_ = layer.conv.weight
             N = cw_.shape[0]
             k = head.kernel_size
@@ -442,6 +449,8 @@ def forward_fp32(model, image, points):
                 w3 = _w3(cache, ("conv", j), lambda: cw_.flatten(1), cw_)
                 y = _linear(y.reshape(-1, C), w3, f32(layer.conv.bias), act=act).view(Bh, Hh, Wh, N)
             C, act = N, "relu"
+        if save is not None:
+            save["cls_in"] = (y, act)
         clw, clb = head.classifier.weight, head.classifier.bias
         ncls = clw.shape[0]
         npad = (ncls + 3) // 4 * 4
@@ -451,3 +460,84 @@ def forward_fp32(model, image, points):
         logits = logits.reshape(Bh, Hh, Wh, ncls).permute(0, 3, 1, 2).contiguous()
         logits = model._to_image_size(logits, (H, W))
     return {"instances": logits, "instances_aux": None}
+
+
+def _mm(a, b):
+    """fp32 [M, K] x fp32 [N, K]^T -> fp32 [M, N] as three bf16 products (N is padded to a multiple of 4 and cut back)."""
+    n = b.shape[0]
+    npad = (n + 3) // 4 * 4
+    if npad != n:
+        b = F.pad(b, (0, 0, 0, npad - n))
+    out = ops.linear(ops.split3(a.contiguous()), ops.split3(b.contiguous(), weights=True), None, None, out_dtype=torch.float32)
+    return out[:, :n]
+
+
+def click_head_gradients_fp32(model, image, points, grad_logits, relu_masks=None):
+    """Gradients of  sum(logits * grad_logits)  w.r.t. every trainable tensor of a clicks-after-the-backbone model --
+    ``embed_coords.proj.{weight,bias}``, ``head.convs.{j}.conv.{weight,bias}``, ``head.classifier.{weight,bias}`` -- in
+    fp32-accurate arithmetic: what autograd does for iSegProbeModel.forward (iseg_probe_model.py:110-134,
+    heads/conv_heads.py:48-73, featurizers/DINOv2.py:509-516 -- the after_backbone branch, where the frozen trunk is not on
+    the gradient's path), with every contraction (the 3x3 convolutions' weight and data gradients, the classifier, the
+    click patch-embedding) as "three bf16 products" on the MFMA GEMM (``_mm``) and everything else -- ReLU masks, bias
+    sums, the adjoint of the align_corners resize -- in fp32.  The product path's backward runs on bf16 operands and is
+    held to cos > 0.99 against autograd of the oracle (a bf16 ReLU-mask flip moves a weight gradient by whole terms); this
+    mode separates that rounding noise from an indexing error: it is held to 1e-3 relative
+    (tests/test_training_gpu.py::test_gradients_fp32_mode_vs_oracle).  A checking mode: torch does the layout work
+    (unfold, transposes), nothing here is fast.  Upsampler: identity or bilinear; head: ConvSegHead.
+    ``relu_masks`` (optional, one bool NHWC tensor per conv layer): use these ReLU masks instead of this forward's own --
+    a pre-activation within fp32 rounding of zero may fall on either side in two correct fp32 implementations, and one
+    flipped entry moves a bias gradient by a whole term (1e-2 relative on 6 272-pixel sums); the test imposes the
+    oracle's masks and separately bounds how many entries differ.  Returns (grads, this forward's own masks)."""
+    from .heads.conv_heads import ConvSegHead
+    from .upsamplers.basic_upsamplers import BilinearUpsampler, IdentityUpsampler
+    fz, up, head = model.backbone, model.upsampler, model.head
+    if getattr(fz, "feats_injection_mode", None) != "after_backbone" or not isinstance(up, (BilinearUpsampler, IdentityUpsampler)) \
+            or not isinstance(head, ConvSegHead) or head.num_classes != 1:
+        raise IspError("click_head_gradients_fp32 covers clicks after the backbone, identity / bilinear upsampling and ConvSegHead")
+    save = {}
+    model._fp32_save = save
+    try:
+        logits = forward_fp32(model, image, points)["instances"]
+    finally:
+        del model._fp32_save
+    B, h, w, H, W = save["geom"]
+    grads = {}
+    with torch.no_grad():
+        y_last, act_last = save["cls_in"]
+        Hh, Wh = y_last.shape[1:3]
+        gl = grad_logits.float().contiguous()
+        if tuple(logits.shape[2:]) != (Hh, Wh):  # identity upsampler: the logits were resized to the image size
+            gl = ops.resize_bilinear_nchw_f32_bwd(gl, Hh, Wh)                         # (iseg_base_model.py:75-80, adjoint)
+        M = B * Hh * Wh
+        g = gl.permute(0, 2, 3, 1).reshape(M, 1).contiguous()
+        a = y_last.reshape(M, -1)
+        a = torch.relu(a) if act_last == "relu" else a
+        clw = head.classifier.weight.detach().float().flatten(1)                      # [1, C]
+        grads["head.classifier.weight"] = _mm(g.t().contiguous(), a.t().contiguous()).view_as(head.classifier.weight)
+        grads["head.classifier.bias"] = g.sum(0)
+        g_a = g * clw                                                                  # [M, C]: rank one, no contraction
+        used_masks = [None] * len(head.convs)
+        for j in reversed(range(len(head.convs))):
+            y_out = save["layer_in"][j + 1][0] if j + 1 < len(head.convs) else y_last  # this layer's pre-activation output
+            mask = (y_out > 0) if relu_masks is None else relu_masks[j].to(y_out.device)
+            used_masks[j] = y_out > 0
+            g_z = (g_a * mask.reshape(M, -1)).contiguous()                             # ReLU behind every layer (ConvModule)
+            y_in, act_in = save["layer_in"][j]
+            x_in = torch.relu(y_in) if act_in == "relu" else y_in                      # [B, Hh, Wh, Cin] fp32
+            Cin, N = x_in.shape[3], g_z.shape[1]
+            conv = head.convs[j].conv
+            U = F.unfold(x_in.permute(0, 3, 1, 2), 3, padding=1).transpose(1, 2).reshape(M, Cin * 9)   # (c, ky, kx) order
+            grads[f"head.convs.{j}.conv.weight"] = _mm(g_z.t().contiguous(), U.t().contiguous()).view_as(conv.weight)
+            grads[f"head.convs.{j}.conv.bias"] = g_z.sum(0)
+            # data gradient: g_x[m, c] = sum_{n, tap} g_z[m - tap, n] w[n, c, tap]  = unfold(g_z) . rot180(w)
+            Ug = F.unfold(g_z.view(B, Hh, Wh, N).permute(0, 3, 1, 2), 3, padding=1).transpose(1, 2).reshape(M, N * 9)
+            wr = conv.weight.detach().float().flip(2, 3).permute(1, 0, 2, 3).reshape(Cin, N * 9)  # [c, (n, ky, kx)]
+            g_a = _mm(Ug, wr)
+        g_map = g_a.view(B, Hh, Wh, -1).permute(0, 3, 1, 2).contiguous()             # gradient of the head's input, NCHW
+        if (Hh, Wh) != (h, w):  # adjoint of the bilinear (align_corners) upsampling to the image size
+            g_map = ops.resize_bilinear_nchw_f32_bwd(g_map, h, w)
+        g_tok = g_map.permute(0, 2, 3, 1).reshape(B * h * w, -1).contiguous()          # [B*T, D]: d features = d click tokens
+        cw = model.embed_coords.proj.weight
+        grads["embed_coords.proj.weight"] = _mm(g_tok.t().contiguous(), save["Ac"].t().contiguous()).view_as(cw)
+        grads["embed_coords.proj.bias"] = g_tok.sum(0)
+    return grads, used_masks

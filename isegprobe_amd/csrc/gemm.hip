@@ -45,6 +45,11 @@ using Cfg64 = TileCfg<64, 128, 1, 4, 2>;      // 4 waves, 48 KiB LDS: twice the 
 #endif
 using CfgConv192 = ISP_CONV192;                    // N % 192 == 0
 using CfgConv128 = TileCfg<256, 128, 4, 2, 2, 2>;  // 96 KiB LDS
+// Full-row tiles for the M = 1.6 M, N = 384 / 448 GEMMs of LoftUp's half-precision stream (8 waves as 2 x 4, 1 block / CU):
+// on 256 x 192 tiles N = 448 takes three column tiles (192, 192, 64), i.e. the activation rows are staged three times
+// and the third pass wastes two thirds of its MFMAs; here they are staged once per output row tile.
+using CfgWide448 = TileCfg<128, 448, 2, 4, 2, 2>;  // 144 KiB LDS
+using CfgWide384 = TileCfg<128, 384, 2, 4, 2, 2>;  // 128 KiB LDS
 
 // ------------------------------------------------------------------------------ A loaders
 // Contract: init(slot i, global row m, 16-B source chunk) once per lane per DMA row slot;
@@ -1343,6 +1348,11 @@ extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int
                 return (int)ISP_ERR_UNSUPPORTED;
         }
     };
+    static const bool wide_off = [] { const char* e = getenv("ISEGPROBE_GEMM_WIDE"); return e && e[0] == '0'; }();
+    if ((M + 127) / 128 >= 1024 && !wide_off) {  // (row tiles fill the chip four times over)
+        if (N > 256 && N <= 384) return run(CfgWide384{});
+        if (N > 384 && N <= 448) return run(CfgWide448{});
+    }
     if ((M + 255) / 256 >= 512 && N >= 384) return run(CfgConv192{});
     if (((M + 127) / 128) * ((N + 127) / 128) < 256) return run(Cfg64{});
     return run(Cfg128{});

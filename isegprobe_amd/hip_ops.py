@@ -967,7 +967,8 @@ def split3(x, weights=False, act=None, scale=1.0, K=None):
     K = x.shape[1] if K is None else K
     Kpad = (K + 63) // 64 * 64
     out = torch.empty(rows, 3 * Kpad, device=x.device, dtype=BF16)
-    check(_lib.lib().isp_split_bf16x3(_p(x), x.stride(0), _p(out), rows, K, Kpad, int(weights),
+    ld = x.stride(0) if rows > 1 else max(x.stride(0), x.shape[1])  # (torch reports any stride for a size-1 dimension)
+    check(_lib.lib().isp_split_bf16x3(_p(x), ld, _p(out), rows, K, Kpad, int(weights),
                                       {None: 0, "relu": 1, "gelu": 2, "quick_gelu": 3}[act], float(scale), _stream()), "isp_split_bf16x3")
     return out
 
