@@ -79,6 +79,14 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
 #define ISP_EP_MUL_DGELU_BF16 11 /* backward of GELU fused into the fc2 data-gradient GEMM: out bf16 = v * gelu'(res),
                                   * res bf16 = the saved pre-activation (row stride ldo) */
 
+#define ISP_EP_AXPY_RES_STATS_BF16 14 /* isp_gemm_f16, N <= 448: ISP_EP_AXPY_RES_BF16 that also writes, per output row, the sum and the sum of
+                                       * squares of the stored values: out2 f32 [isp_gemm_stats_slots()][M][2] (partial per wave column group) */
+#define ISP_EP_LNFOLD_BF16 15      /* isp_gemm_f16: out = rstd[m] * (v - mean[m] * gamma[n]) + bias[n]: a LayerNorm over the first
+                                    * tokens_per_image (= D) columns of A folded into this GEMM (weights carry the LayerNorm gain, gamma[n]
+                                    * = their row sums, bias = c + W b); row statistics from res = the producer's partial sums
+                                    * [img_h slots][M][2], alpha = the LayerNorm epsilon (loftup/layers.py:186-228, 53-58) */
+#define ISP_EP_LNFOLD_GELU_BF16 16 /* the same followed by gelu_erf (FeedForward's first layer) */
+
 typedef struct isp_epilogue {
     int kind;             /* ISP_EP_* */
     void* out;            /* bf16 or f32 per kind */
@@ -101,6 +109,7 @@ int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, int N, int K,
  * kinds ISP_EP_BIAS_BF16, ISP_EP_BIAS_GELU_BF16 (half outputs saturate at +-65504), ISP_EP_AXPY_RES_BF16 (res and out half)
  * and ISP_EP_RESIDUAL_F32 (the ViT's fp32 residual stream); others ISP_ERR_UNSUPPORTED. */
 int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* ep, void* stream);
+int isp_gemm_stats_slots(void); /* partial-statistics slots of ISP_EP_AXPY_RES_STATS_BF16 */
 
 /* ---- 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on NHWC bf16.
  * in [B,H,W,C] (C % 64 == 0), Wt [N][9*C] with K index = ((ky*3+kx)*C + c), i.e.

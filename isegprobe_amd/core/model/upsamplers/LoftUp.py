@@ -34,6 +34,7 @@ from . import BaseUpsampler
 
 
 LOFTUP_F16 = os.environ.get("ISEGPROBE_LOFTUP_F16", "1") != "0"  # IEEE-half inference stream (see _run)
+LOFTUP_LNFOLD = os.environ.get("ISEGPROBE_LOFTUP_LNFOLD", "1") != "0"  # LayerNorms folded into the consuming GEMMs (half stream)
 
 
 def _pad64(n):
@@ -231,12 +232,25 @@ class LoftUpUpsampler(BaseUpsampler):
                 hid_p = _pad64(hid)
                 L["ff1_w"], L["ff1_b"] = padded(ff.net[1].weight.detach().float(), hid_p, cp), padvec(f32(ff.net[1].bias), hid_p)
                 L["ff2_w"], L["ff2_b"] = padded(ff.net[4].weight.detach().float(), cp, hid_p), padvec(f32(ff.net[4].bias), cp)
+                if half:  # LayerNorm folded into the consuming GEMM (csrc/gemm.hip, EpLnFold): W diag(g), its row sums, c + W b
+                    def fold(w_pad, b_pad, ln_w, ln_b):
+                        wf = w_pad.float().clone()
+                        wf[:, :c] *= ln_w.detach().float()[None, :]
+                        wh = wf.to(ops.F16).contiguous()
+                        return wh, wh.float().sum(1).contiguous(), (b_pad + w_pad.float()[:, :c] @ ln_b.detach().float()).contiguous()
+                    L["ff1_fold"] = fold(L["ff1_w"], L["ff1_b"], ff.net[0].weight, ff.net[0].bias)
+                    L["wq2_fold"] = fold(L["wq2"], L["bq2"], ca.norm_q.weight, ca.norm_q.bias)
                 layers.append(L)
             P["layers"] = layers
             nrm = lu.ca_transformer.norm
             P["tn_w"], P["tn_b"], P["tn_eps"] = f32(nrm.weight), f32(nrm.bias), nrm.eps
             fc = lu.final_conv[0]
             P["fin_w"], P["fin_b"] = padded(fc.weight.detach().float().flatten(1), _pad64(C), cp), padvec(f32(fc.bias), _pad64(C))
+            if half:
+                wf = P["fin_w"].float().clone()
+                wf[:, :c] *= nrm.weight.detach().float()[None, :]
+                wh = wf.to(ops.F16).contiguous()
+                P["fin_fold"] = (wh, wh.float().sum(1).contiguous(), (P["fin_b"] + P["fin_w"].float()[:, :c] @ nrm.bias.detach().float()).contiguous())
             P["fln_w"], P["fln_b"], P["fln_eps"] = f32(lu.final_conv[1].weight), f32(lu.final_conv[1].bias), lu.final_conv[1].eps
             self._pe_cache.clear()
             return P
@@ -308,8 +322,17 @@ class LoftUpUpsampler(BaseUpsampler):
         scale = P["hd"] ** -0.5
         if save is not None:
             save.update(kv=kv, layers=[], geom=(B, h, w, C, H, W), train=train)
+        # Half stream with <= 448 padded channels: the LayerNorms in front of the feed-forward, of the second layer's query
+        # projection and of the final 1x1 conv are FOLDED into those GEMMs (weights carry the gain, a per-row correction in
+        # the epilogue), with the row statistics emitted by the residual GEMM that produced the rows -- four of the six
+        # passes over the [B*H*W, 448] pixel map per forward disappear (csrc/gemm.hip: EpAxpyResStats / EpLnFold)
+        fold = half and cp <= 448 and LOFTUP_LNFOLD
+        stats = None  # row statistics of the current x (None: x came from the convolutions)
         for li, L in enumerate(P["layers"]):
-            def project_q(x=x, L=L):
+            def project_q(x=x, L=L, stats=stats):
+                if fold and stats is not None:
+                    wf, sf, bf = L["wq2_fold"]
+                    return ops.linear_lnfold(x, stats, wf, sf, bf, c, L["nq_eps"]).view(B, H * W, heads, hdp)
                 qn = ops.layernorm(x, L["nq_w"], L["nq_b"], L["nq_eps"], D=c, ld_out=cp, out_dtype=dt)
                 if save is None:  # inference: base-2-logit queries (scale folded into the projection)
                     return ops.linear(qn, L["wq2"], L["bq2"]).view(B, H * W, heads, hdp)
@@ -325,6 +348,12 @@ class LoftUpUpsampler(BaseUpsampler):
             else:
                 a, lse = ops.attention_lse(q, k, v, scale)
                 a = a.view(M, heads * hdp)
+            if fold:
+                x_mid, st_mid = ops.linear_axpy_res_stats(a, L["wo"], L["bo"], x, 1.0)   # cross-attention + residual (+ row statistics)
+                wf, sf, bf = L["ff1_fold"]
+                f = ops.linear_lnfold(x_mid, st_mid, wf, sf, bf, c, L["ff_eps"], "gelu")  # LayerNorm + Linear + GELU
+                x, stats = ops.linear_axpy_res_stats(f, L["ff2_w"], L["ff2_b"], x_mid, 1.0)  # feed-forward + residual
+                continue
             x_mid = ops.linear_axpy_res(a, L["wo"], L["bo"], x, 1.0)        # cross-attention + residual
             f = ops.layernorm(x_mid, L["ff_nw"], L["ff_nb"], L["ff_eps"], D=c, ld_out=cp, out_dtype=dt)
             if save is None:
@@ -333,8 +362,12 @@ class LoftUpUpsampler(BaseUpsampler):
                 f, pre = ops.linear_gelu_save(f, L["ff1_w"], L["ff1_b"])
                 save["layers"].append(dict(x_in=x, q=q, k=k, v=v, a=a, lse=lse, x_mid=x_mid, pre=pre))
             x = ops.linear_axpy_res(f, L["ff2_w"], L["ff2_b"], x_mid, 1.0)  # feed-forward + residual
-        xn = ops.layernorm(x, P["tn_w"], P["tn_b"], P["tn_eps"], D=c, ld_out=cp, out_dtype=dt)
-        y = ops.linear(xn, P["fin_w"], P["fin_b"])                           # 1x1 conv c -> C
+        if fold and stats is not None:
+            wf, sf, bf = P["fin_fold"]
+            y = ops.linear_lnfold(x, stats, wf, sf, bf, c, P["tn_eps"])     # LayerNorm + 1x1 conv c -> C
+        else:
+            xn = ops.layernorm(x, P["tn_w"], P["tn_b"], P["tn_eps"], D=c, ld_out=cp, out_dtype=dt)
+            y = ops.linear(xn, P["fin_w"], P["fin_b"])                       # 1x1 conv c -> C
         out = ops.layernorm(y, P["fln_w"], P["fln_b"], P["fln_eps"], D=C, ld_out=C, out_dtype=dt)  # channel LayerNorm
         if save is not None:
             save.update(x_fin=x, y=y)

@@ -312,6 +312,85 @@ struct EpAxpyResBf16 {  // out = res + alpha * (v + bias), bf16 (or half) in/out
     }
 };
 
+// LayerNorm folded into the NEXT GEMM (LoftUp's half-precision inference stream, loftup/layers.py:186-228: every
+// cross-attention / feed-forward / final projection reads LayerNorm(x)).  With g = LN's gain and b its bias,
+//     W LN(x) + c  =  rstd * ( (W diag(g)) x  -  mean * s )  +  (c + W b),      s[n] = sum_k (W diag(g))[n][k],
+// so the consumer multiplies the RAW row x by the folded weights and corrects per row in its epilogue: the LayerNorm
+// pass over the 1.6 M x 448 pixel map (read + write, 0.6 ms at batch 8, nine per forward = 15 % of the stage) disappears.
+// The row statistics come from the PRODUCER of x: EpAxpyResStats is EpAxpyResBf16 that also emits, per output row and
+// wave column group, sum(r) and sum(r^2) of what it stores -- partial[slot][m][2], slot = n-tile * WN + n-wave (the
+// padded columns of LoftUp's 404 -> 448 channel map are exact zeros and drop out).  No atomics, no extra pass.
+template <bool F16 = false>
+struct EpAxpyResStats {
+    static constexpr bool kRowStats = true;
+    bf16_t* out;
+    const bf16_t* res;
+    const float* bias;
+    float alpha;
+    long ldo;
+    float* stats;  // [slots][M][2]
+    long M;
+    using Cols = ColsBias;
+    using Pre = uint2;
+    __device__ __forceinline__ Cols cols(int n) const { return load_bias(bias, n); }
+    __device__ __forceinline__ Pre pre(long m, int n) const { return *reinterpret_cast<const uint2*>(res + (size_t)m * ldo + n); }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c, const Pre& u, float& s1, float& s2) const {
+        const float x0 = F16 ? h_lo(u.x) : __uint_as_float(u.x << 16), x1 = F16 ? h_hi(u.x) : __uint_as_float(u.x & 0xffff0000u);
+        const float x2 = F16 ? h_lo(u.y) : __uint_as_float(u.y << 16), x3 = F16 ? h_hi(u.y) : __uint_as_float(u.y & 0xffff0000u);
+        const float r0 = x0 + alpha * (v[0] + c.b.x), r1 = x1 + alpha * (v[1] + c.b.y);
+        const float r2 = x2 + alpha * (v[2] + c.b.z), r3 = x3 + alpha * (v[3] + c.b.w);
+        const uint2 q = make_uint2(pack2o_sat<!F16>(r0, r1), pack2o_sat<!F16>(r2, r3));
+        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = q;
+        // statistics of the values AS STORED (what the consumer GEMM multiplies)
+        const float q0 = F16 ? h_lo(q.x) : __uint_as_float(q.x << 16), q1 = F16 ? h_hi(q.x) : __uint_as_float(q.x & 0xffff0000u);
+        const float q2 = F16 ? h_lo(q.y) : __uint_as_float(q.y << 16), q3 = F16 ? h_hi(q.y) : __uint_as_float(q.y & 0xffff0000u);
+        s1 += (q0 + q1) + (q2 + q3);
+        s2 += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+    }
+};
+
+// The consumer side: out = act( rstd[m] * (v - mean[m] * s[n]) + bias[n] ), 16-bit out.
+template <int ACT, bool F16 = false>
+struct EpLnFold {
+    bf16_t* out;
+    const float* bias;   // c + W b
+    const float* ssum;   // s[n]
+    const float* stats;  // [slots][M][2] from the producer
+    long M;
+    int slots;
+    float inv_d, eps;    // 1 / (channels the LayerNorm runs over), its epsilon
+    long ldo;
+    struct Cols {
+        float4 b, s;
+    };
+    struct RowCtx {
+        float mean, rstd;
+    };
+    __device__ __forceinline__ Cols cols(int n) const {
+        return Cols{*reinterpret_cast<const float4*>(bias + n), *reinterpret_cast<const float4*>(ssum + n)};
+    }
+    __device__ __forceinline__ RowCtx row_begin(long m) const {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < slots; ++k) {
+            const float2 p = *reinterpret_cast<const float2*>(stats + ((size_t)k * M + m) * 2);
+            s1 += p.x, s2 += p.y;
+        }
+        const float mean = s1 * inv_d;
+        return RowCtx{mean, rsqrtf(fmaxf(s2 * inv_d - mean * mean, 0.f) + eps)};
+    }
+    __device__ __forceinline__ uint2 pack(long, int, const float* v, const Cols& c, const RowCtx& r) const {
+        float o[4] = {r.rstd * (v[0] - r.mean * c.s.x) + c.b.x, r.rstd * (v[1] - r.mean * c.s.y) + c.b.y,
+                      r.rstd * (v[2] - r.mean * c.s.z) + c.b.z, r.rstd * (v[3] - r.mean * c.s.w) + c.b.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ACT == ACT_GELU) o[j] = gelu_erf(o[j]);
+        return make_uint2(pack2o_sat<!F16>(o[0], o[1]), pack2o_sat<!F16>(o[2], o[3]));
+    }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c, const RowCtx& r) const {
+        *reinterpret_cast<uint2*>(out + (size_t)m * ldo + n) = pack(m, n, v, c, r);
+    }
+};
+
 // relu(v + bias[n] - sum over the 3x3 taps that fall OUTSIDE the image of taps[t][n]), bf16 out.
 // Used when a per-pixel affine map z = (I + aW)x + a*b in front of a zero-padded 3x3 conv is folded
 // into the conv weights: the constant part a*b only contributes through taps inside the image.
@@ -442,23 +521,46 @@ __device__ __forceinline__ void run_epilogue(const EP& ep, f32x4 (&acc)[TM][TN],
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
                     pp[ni] = ep.pre(FULL || m >= 0 ? m : 0, FULL || ncol[ni] < N ? ncol[ni] : N - 4);
+                if constexpr (requires { EP::kRowStats; }) {
+                    // stores + per-row sum / sum of squares of the stored values over the wave's columns; the four lanes
+                    // that share a row (fq = 0..3) reduce, lane fq == 0 writes partial[slot][m]
+                    float s1 = 0.f, s2 = 0.f;
+                    const bool row_ok = FULL || m >= 0;
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        if (!row_ok || (!FULL && ncol[ni] >= N)) continue;
+                        const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                        ep(m, ncol[ni], v, cc[ni], pp[ni], s1, s2);
+                    }
+                    s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
+                    s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+                    if (fq == 0 && row_ok) *reinterpret_cast<float2*>(ep.stats + ((size_t)slot * ep.M + m) * 2) = make_float2(s1, s2);
+                    continue;
+                }
                 if (!FULL && m < 0) continue;
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) {
                     if (!FULL && ncol[ni] >= N) continue;
                     const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-                    ep(m, ncol[ni], v, cc[ni], pp[ni]);
+                    if constexpr (!requires { EP::kRowStats; }) ep(m, ncol[ni], v, cc[ni], pp[ni]);
                 }
             } else {
                 if (!FULL && m < 0) continue;
-                [[maybe_unused]] unsigned ctx = 0;
-                if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
+                if constexpr (requires { ep.row_begin(m); }) {
+                    const auto ctx = ep.row_begin(m);
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) {
-                    if (!FULL && ncol[ni] >= N) continue;
-                    const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-                    if constexpr (requires { ep.row_begin(m); }) ep(m, ncol[ni], v, cc[ni], ctx);
-                    else ep(m, ncol[ni], v, cc[ni]);
+                    for (int ni = 0; ni < TN; ++ni) {
+                        if (!FULL && ncol[ni] >= N) continue;
+                        const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                        ep(m, ncol[ni], v, cc[ni], ctx);
+                    }
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) {
+                        if (!FULL && ncol[ni] >= N) continue;
+                        const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                        ep(m, ncol[ni], v, cc[ni]);
+                    }
                 }
             }
         }
@@ -474,7 +576,8 @@ template <class EP>
 constexpr bool kStagedStore = requires(const EP& e) { e.out; e.ldo; typename EP::Cols; } &&
                               !requires { EP::kRowReduce; } && !requires { typename EP::Pre; } &&
                               (requires(const EP& e, const float* v, const typename EP::Cols& c) { e.pack(0L, 0, v, c); } ||
-                               requires(const EP& e, const float* v, const typename EP::Cols& c) { e.pack(0L, 0, v, c, 0u); });
+                               requires(const EP& e, const float* v, const typename EP::Cols& c) { e.pack(0L, 0, v, c, 0u); } ||
+                               requires { typename EP::RowCtx; });
 template <int TM, int TN>
 constexpr int kStageBytes = TM * 16 * (TN * 32 + 16);  // per wave
 
@@ -497,15 +600,20 @@ __device__ __forceinline__ void staged_epilogue(const EP& ep, f32x4 (&acc)[TM][T
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         [[maybe_unused]] const long m = row_in(row_base + mi * 16 + fr);
-        [[maybe_unused]] unsigned ctx = 0;
-        if constexpr (requires { ep.row_begin(m); }) ctx = ep.row_begin(m);
+        auto put = [&](int ni, const uint2& o) { *reinterpret_cast<uint2*>(stg + (mi * 16 + fr) * SP + ni * 32 + fq * 8) = o; };
+        if constexpr (requires { ep.row_begin(m); }) {
+            const auto ctx = ep.row_begin(m);
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
-            uint2 o;
-            if constexpr (requires { ep.row_begin(m); }) o = ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni], ctx);
-            else o = ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni]);
-            *reinterpret_cast<uint2*>(stg + (mi * 16 + fr) * SP + ni * 32 + fq * 8) = o;
+            for (int ni = 0; ni < TN; ++ni) {
+                const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                put(ni, ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni], ctx));
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                put(ni, ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni]));
+            }
         }
     }
     // (written and read by the same wave: the compiler's lgkmcnt wait orders them)
@@ -1344,10 +1452,29 @@ extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int
                                               EpAxpyResBf16<true>{(bf16_t*)e->out, (const bf16_t*)e->res, e->bias, e->alpha, ldo}, s);
             case ISP_EP_RESIDUAL_F32:  // the ViT's fp32 residual stream: x += gamma * (A W^T + bias) with half operands
                 return launch_gemm<CFG, true>(al, Wt, M, N, K, EpResidual{(float*)e->out, e->bias, e->gamma, ldo}, s);
+            case ISP_EP_LNFOLD_BF16:
+            case ISP_EP_LNFOLD_GELU_BF16: {
+                if (!e->bias || !e->gamma || !e->res || e->tokens_per_image <= 0 || e->img_h <= 0) return (int)ISP_ERR_INVALID;
+                const float inv_d = 1.0f / (float)e->tokens_per_image;
+                if (e->kind == ISP_EP_LNFOLD_BF16)
+                    return launch_gemm<CFG, true>(al, Wt, M, N, K,
+                                                  EpLnFold<ACT_NONE, true>{(bf16_t*)e->out, e->bias, e->gamma, (const float*)e->res, M, e->img_h, inv_d, e->alpha, ldo}, s);
+                return launch_gemm<CFG, true>(al, Wt, M, N, K,
+                                              EpLnFold<ACT_GELU, true>{(bf16_t*)e->out, e->bias, e->gamma, (const float*)e->res, M, e->img_h, inv_d, e->alpha, ldo}, s);
+            }
             default:
                 return (int)ISP_ERR_UNSUPPORTED;
         }
     };
+    if (e->kind == ISP_EP_AXPY_RES_STATS_BF16) {  // full-row tiles whatever M is: the statistics' slot count is then fixed
+        if (!e->res || !e->out2 || N > CfgWide448::BN) return ISP_ERR_INVALID;
+        DenseA<CfgWide448::PA> al;
+        al.A = (const bf16_t*)A;
+        al.lda = lda;
+        al.M = M;
+        return launch_gemm<CfgWide448, true>(al, Wt, M, N, K,
+                                             EpAxpyResStats<true>{(bf16_t*)e->out, (const bf16_t*)e->res, e->bias, e->alpha, ldo, (float*)e->out2, M}, s);
+    }
     static const bool wide_off = [] { const char* e = getenv("ISEGPROBE_GEMM_WIDE"); return e && e[0] == '0'; }();
     if ((M + 127) / 128 >= 1024 && !wide_off) {  // (row tiles fill the chip four times over)
         if (N > 256 && N <= 384) return run(CfgWide384{});
@@ -1357,6 +1484,9 @@ extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int
     if (((M + 127) / 128) * ((N + 127) / 128) < 256) return run(Cfg64{});
     return run(Cfg128{});
 }
+
+// partial-statistics slots isp_gemm_f16 writes with ISP_EP_AXPY_RES_STATS_BF16 ([slots][M][2] floats)
+extern "C" int isp_gemm_stats_slots(void) { return CfgWide448::WN; }
 
 // A/B switch for experiments: ISEGPROBE_CONV_ENGINE=tile selects the generic tile engine for every conv
 static bool ep_forces_tile_engine() {

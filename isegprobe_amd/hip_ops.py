@@ -735,6 +735,39 @@ def linear_axpy_res(A, Wt, bias, res, alpha):
     return out
 
 
+def linear_axpy_res_stats(A, Wt, bias, res, alpha):
+    """linear_axpy_res on IEEE-half operands (N <= 448) that also returns the per-row partial sums of the stored values:
+    (out [M,N] f16, stats f32 [slots, M, 2] = (sum, sum of squares) per wave column group) -- the row statistics a
+    LayerNorm of `out` needs, handed to ``linear_lnfold`` instead of running that LayerNorm (csrc/gemm.hip, EpAxpyResStats)."""
+    _need(A, F16, "A")
+    _need(res, F16, "res")
+    N = Wt.shape[0]
+    M = A.shape[0]
+    out = torch.empty(M, N, device=A.device, dtype=F16)
+    stats = torch.empty(_lib.lib().isp_gemm_stats_slots(), M, 2, device=A.device, dtype=torch.float32)
+    ep = _epilogue(_lib.EP_AXPY_RES_STATS_BF16, out, N, bias, res=res, alpha=alpha)
+    ep.out2 = stats.data_ptr()
+    gemm(A, Wt, ep)
+    return out, stats
+
+
+def linear_lnfold(x, stats, Wfold, ssum, bias, D, eps, act=None):
+    """act(Linear(LayerNorm_D(x))) WITHOUT the LayerNorm pass: x [M, K] f16 raw rows, stats from ``linear_axpy_res_stats``
+    (the producer of x), Wfold = W diag(gain) in f16, ssum[n] = sum_k Wfold[n, k], bias = c + W ln_bias; D = channels the
+    LayerNorm runs over (the remaining columns of x are zero padding).  act: None | 'gelu'."""
+    _need(x, F16, "x")
+    _need(stats, torch.float32, "stats")
+    if stats.shape[1] != x.shape[0] or stats.shape[2] != 2:
+        raise IspError("linear_lnfold: stats must be [slots, M, 2]")
+    N = Wfold.shape[0]
+    out = torch.empty(x.shape[0], N, device=x.device, dtype=F16)
+    ep = _epilogue({None: _lib.EP_LNFOLD_BF16, "gelu": _lib.EP_LNFOLD_GELU_BF16}[act], out, N, bias, gamma=ssum, res=stats, alpha=float(eps))
+    ep.tokens_per_image = int(D)
+    ep.img_h = int(stats.shape[0])
+    gemm(x, Wfold, ep)
+    return out
+
+
 def fuse_flip_sigmoid(logits, with_flip):
     """logits [2n,1,H,W] (second half: mirrored image) -> sigmoid(0.5*(a + flip(b))) [n,1,H,W];
     with_flip=False: sigmoid(logits)."""

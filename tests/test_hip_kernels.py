@@ -564,3 +564,41 @@ def test_f16_trunk_kernels(ops):
     big = torch.full((64, 64), 300.0, device="cuda")
     h = ops.linear(big.half(), torch.full((64, 64), 200.0, device="cuda").half(), None, "gelu")  # 64 * 300 * 200 = 3.8e6
     assert torch.isfinite(h.float()).all() and h.float().max().item() == 65504.0
+
+
+@pytest.mark.parametrize("M", [300, 4096 + 77])
+@pytest.mark.parametrize("act", [None, "gelu"])
+def test_layernorm_folded_into_gemm(ops, M, act):
+    """LoftUp's half stream (csrc/gemm.hip, EpAxpyResStats / EpLnFold): the residual GEMM emits per-row partial sums of what
+    it stores, the next GEMM multiplies the RAW rows by W diag(g) and applies rstd * (acc - mean * s) + (c + W b) in its
+    epilogue -- against LayerNorm + Linear (+ GELU) in fp32 on the same 16-bit-rounded rows.  404 real channels padded to
+    448 (zero columns), ragged M."""
+    torch.manual_seed(M)
+    c, cp, Kin, N = 404, 448, 512, 384
+    H16 = torch.float16
+    A = torch.randn(M, Kin, device="cuda").to(H16)
+    W0 = torch.zeros(cp, Kin, device="cuda")
+    W0[:c] = torch.randn(c, Kin, device="cuda") / math.sqrt(Kin)
+    b0 = torch.zeros(cp, device="cuda")
+    b0[:c] = torch.randn(c, device="cuda")
+    res = torch.zeros(M, cp, device="cuda")
+    res[:, :c] = torch.randn(M, c, device="cuda") * 2 + 0.7            # (a mean far from zero: the correction term matters)
+    x, stats = ops.linear_axpy_res_stats(A, W0.to(H16), b0, res.to(H16), 1.0)
+    x_ref = res.to(H16).float() + A.float() @ W0.to(H16).float().t() + b0
+    assert (x.float() - x_ref).abs().max().item() < 2e-2 and torch.equal(x[:, c:], torch.zeros(M, cp - c, device="cuda", dtype=H16))
+    xs = x.float()
+    assert torch.allclose(stats.sum(0)[:, 0], xs.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(stats.sum(0)[:, 1], xs.pow(2).sum(1), rtol=1e-5, atol=1e-3)
+    g, beta = 1 + 0.2 * torch.randn(c, device="cuda"), 0.3 * torch.randn(c, device="cuda")
+    W1 = torch.zeros(N, cp, device="cuda")
+    W1[:, :c] = torch.randn(N, c, device="cuda") / math.sqrt(c)
+    b1 = torch.randn(N, device="cuda")
+    wf = W1.clone()
+    wf[:, :c] *= g
+    wh = wf.to(H16)
+    y = ops.linear_lnfold(x, stats, wh, wh.float().sum(1).contiguous(), (b1 + W1[:, :c] @ beta).contiguous(), c, 1e-5, act)
+    ref = F.layer_norm(xs[:, :c], (c,), g, beta, 1e-5) @ W1[:, :c].t() + b1
+    ref = F.gelu(ref) if act == "gelu" else ref
+    err = (y.float() - ref).abs().max().item()
+    print(f"lnfold M={M} act={act}: max err {err:.3g} (ref max {ref.abs().max().item():.3g})")
+    assert err < 2e-2
