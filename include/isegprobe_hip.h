@@ -87,6 +87,10 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
                                     * [img_h slots][M][2], alpha = the LayerNorm epsilon (loftup/layers.py:186-228, 53-58) */
 #define ISP_EP_LNFOLD_GELU_BF16 16 /* the same followed by gelu_erf (FeedForward's first layer) */
 
+#define ISP_EP_RESIDUAL_STATS_F32 17 /* isp_gemm_f16: ISP_EP_RESIDUAL_F32 that also writes out3 = IEEE-half copy of the updated rows (row stride
+                                      * ldo) and out2 = their per-row partial sums f32 [isp_gemm_f16_stats_slots(M, N)][M][2]: the ViT block's
+                                      * LayerNorms (block.py:92-117) are then folded into the qkv / fc1 GEMMs (ISP_EP_LNFOLD_*) */
+
 typedef struct isp_epilogue {
     int kind;             /* ISP_EP_* */
     void* out;            /* bf16 or f32 per kind */
@@ -98,7 +102,8 @@ typedef struct isp_epilogue {
     const void* res;      /* bf16 [M, ldo] residual (AXPY_RES) */
     float alpha;          /* (AXPY_RES) */
     int img_h, img_w;     /* image extent (BIAS_TAPS) */
-    void* out2;           /* second output (BIAS_GELU_SAVE), row stride ldo */
+    void* out2;           /* second output (BIAS_GELU_SAVE), row stride ldo; row statistics (..._STATS) */
+    void* out3;           /* third output: the 16-bit copy of RESIDUAL_STATS */
 } isp_epilogue;
 
 /* ---- C = A . Wt^T with a fused epilogue.  A [M, lda>=K] bf16, Wt [N,K] bf16, K % 64 == 0,
@@ -110,6 +115,7 @@ int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, int N, int K,
  * and ISP_EP_RESIDUAL_F32 (the ViT's fp32 residual stream); others ISP_ERR_UNSUPPORTED. */
 int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* ep, void* stream);
 int isp_gemm_stats_slots(void); /* partial-statistics slots of ISP_EP_AXPY_RES_STATS_BF16 */
+int isp_gemm_f16_stats_slots(long M, int N); /* ... of ISP_EP_RESIDUAL_STATS_F32 for an M x N problem */
 
 /* ---- 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on NHWC bf16.
  * in [B,H,W,C] (C % 64 == 0), Wt [N][9*C] with K index = ((ky*3+kx)*C + c), i.e.

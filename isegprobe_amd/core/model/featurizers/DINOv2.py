@@ -34,6 +34,12 @@ ARCHS = {  # DINOv2.py:413-449 (vit_giant2 uses SwiGLU: not built)
 }
 LN_EPS = 1e-6  # DINOv2.py:98
 VIT_F16 = os.environ.get("ISEGPROBE_VIT_F16", "1") != "0"  # IEEE-half 16-bit operands in the inference trunk (see _blocks)
+# The blocks' LayerNorms folded into the qkv / fc1 GEMMs (half stream; csrc/gemm.hip EpResidualStats / EpLnFold).  OFF by
+# default: measured at batch 32 x 448^2 it LOSES (4.61 ms against 4.19 ms per forward; batch 2: 1.03 against 0.83 ms) -- the
+# 24 LayerNorm launches it removes cost ~12 us each here, less than what the extra 8-byte stores of the half copy and
+# the per-row statistics loads add to the epilogues of GEMMs that are already epilogue-bound (K = 384: six K-steps).  The
+# same fold pays on LoftUp's 1.6 M-row maps, where a LayerNorm pass is 0.6 ms (upsamplers/LoftUp.py).
+VIT_LNFOLD = os.environ.get("ISEGPROBE_VIT_LNFOLD", "0") == "1"
 F16_PROBE_ALWAYS = os.environ.get("ISEGPROBE_F16_PROBE", "first") == "always"  # range-check every half forward (debug)
 
 
@@ -167,10 +173,15 @@ class DINOv2Featurizer(nn.Module):
                     qw[:D] *= ops.ATTENTION_LOGIT2_SCALE
                     qb[:D] *= ops.ATTENTION_LOGIT2_SCALE
                 half = lambda t: t.detach().to(ops.F16).contiguous()  # (from the fp32 parameters, not from their bf16 copies)
+
+                def fold(w, b, ln):  # LayerNorm folded into the consuming GEMM: W diag(g) in half, its row sums, c + W b
+                    wh = (w.float() * ln.weight.detach().float()[None, :]).to(ops.F16).contiguous()
+                    return wh, wh.float().sum(1).contiguous(), (b.float() + w.float() @ ln.bias.detach().float()).contiguous()
                 blocks.append(dict(
                     qkv_w2=qw.to(BF16).contiguous(), qkv_b2=qb.contiguous(),
                     h_qkv_w=qw.to(ops.F16).contiguous(), h_proj_w=half(blk.attn.proj.weight),
                     h_fc1_w=half(blk.mlp.fc1.weight), h_fc2_w=half(blk.mlp.fc2.weight),
+                    qkv_fold=fold(qw, qb, blk.norm1), fc1_fold=fold(blk.mlp.fc1.weight.detach(), blk.mlp.fc1.bias.detach(), blk.norm2),
                     n1w=f32(blk.norm1.weight), n1b=f32(blk.norm1.bias),
                     qkv_w=b16(blk.attn.qkv.weight), qkv_b=f32(blk.attn.qkv.bias),
                     proj_w=b16(blk.attn.proj.weight), proj_b=f32(blk.attn.proj.bias),
@@ -252,10 +263,25 @@ class DINOv2Featurizer(nn.Module):
                 if probe:
                     torch.maximum(peak, t.abs().amax().float(), out=peak)
                 return t
+            D = self.model.embed_dim
+            x16 = stats = None  # half copy + row statistics of the stream, emitted by the residual GEMMs (VIT_LNFOLD)
             for blk in P["blocks"]:
-                hbuf = seen(ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, out_dtype=H16))
-                qkv = seen(ops.linear(hbuf, blk["h_qkv_w"], blk["qkv_b2"]))
+                if VIT_LNFOLD and stats is not None:  # norm1 folded into the qkv GEMM
+                    qkv = seen(ops.linear_lnfold(x16, stats, *blk["qkv_fold"], D, LN_EPS))
+                else:
+                    hbuf = seen(ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, out_dtype=H16))
+                    qkv = seen(ops.linear(hbuf, blk["h_qkv_w"], blk["qkv_b2"]))
                 att = seen(ops.attention_packed_qkv(qkv, B, L, heads, None, q_logit2=True))
+                if VIT_LNFOLD:
+                    # The residual GEMMs also write a half copy of the updated stream and its per-row sums; the next
+                    # GEMM multiplies that RAW copy by W diag(gain) and applies rstd (acc - mean s) + (c + W b) in its
+                    # epilogue: no LayerNorm launch between the GEMMs of a block (24 of the 25 per forward)
+                    x16, stats = ops.linear_residual_stats_(x, att, blk["h_proj_w"], blk["proj_b"], blk["ls1"])
+                    seen(x16)
+                    hid = seen(ops.linear_lnfold(x16, stats, *blk["fc1_fold"], D, LN_EPS, "gelu"))
+                    x16, stats = ops.linear_residual_stats_(x, hid, blk["h_fc2_w"], blk["fc2_b"], blk["ls2"])
+                    seen(x16)
+                    continue
                 ops.linear_residual_(x, att, blk["h_proj_w"], blk["proj_b"], blk["ls1"])
                 hbuf = seen(ops.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, out_dtype=H16))
                 hid = seen(ops.linear(hbuf, blk["h_fc1_w"], blk["fc1_b"], "gelu"))

@@ -50,6 +50,7 @@ using CfgConv128 = TileCfg<256, 128, 4, 2, 2, 2>;  // 96 KiB LDS
 // and the third pass wastes two thirds of its MFMAs; here they are staged once per output row tile.
 using CfgWide448 = TileCfg<128, 448, 2, 4, 2, 2>;  // 144 KiB LDS
 using CfgWide384 = TileCfg<128, 384, 2, 4, 2, 2>;  // 128 KiB LDS
+using CfgWide512 = TileCfg<128, 512, 2, 4, 2, 2>;  // 160 KiB LDS: all of a CU's (the query projection, 4 heads x 128)
 
 // ------------------------------------------------------------------------------ A loaders
 // Contract: init(slot i, global row m, 16-B source chunk) once per lane per DMA row slot;
@@ -289,6 +290,40 @@ struct EpResidual {  // x[m][n] += gamma[n] * (v + bias[n])   (LayerScale + resi
         o.z += c.g.z * (v[2] + c.b.z);
         o.w += c.g.w * (v[3] + c.b.w);
         *reinterpret_cast<float4*>(x + (size_t)m * ldx + n) = o;
+    }
+};
+
+// EpResidual that also hands the NEXT GEMM what it needs to fold the following LayerNorm in (EpLnFold below): a 16-bit
+// copy of the updated fp32 rows and, per row and wave column group, the sum / sum of squares of that copy.  The ViT
+// block then has no LayerNorm launch between its GEMMs (block.py:92-117: x + ls(attn(norm1 x)), x + ls(mlp(norm2 x))).
+struct EpResidualStats {
+    static constexpr bool kRowStats = true;
+    float* x;
+    const float* bias;
+    const float* gamma;  // may be null
+    long ldx;
+    unsigned short* x16;  // [M][ldx] IEEE half copy of the updated rows
+    float* stats;         // [slots][M][2]
+    long M;
+    using Cols = EpResidual::Cols;
+    using Pre = float4;
+    __device__ __forceinline__ Cols cols(int n) const {
+        return Cols{bias ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0, 0, 0, 0),
+                    gamma ? *reinterpret_cast<const float4*>(gamma + n) : make_float4(1, 1, 1, 1)};
+    }
+    __device__ __forceinline__ Pre pre(long m, int n) const { return *reinterpret_cast<const float4*>(x + (size_t)m * ldx + n); }
+    __device__ __forceinline__ void operator()(long m, int n, const float* v, const Cols& c, const Pre& old, float& s1, float& s2) const {
+        float4 o = old;
+        o.x += c.g.x * (v[0] + c.b.x);
+        o.y += c.g.y * (v[1] + c.b.y);
+        o.z += c.g.z * (v[2] + c.b.z);
+        o.w += c.g.w * (v[3] + c.b.w);
+        *reinterpret_cast<float4*>(x + (size_t)m * ldx + n) = o;
+        const uint2 q = make_uint2(pack2h_sat(o.x, o.y), pack2h_sat(o.z, o.w));
+        *reinterpret_cast<uint2*>(x16 + (size_t)m * ldx + n) = q;
+        const float q0 = h_lo(q.x), q1 = h_hi(q.x), q2 = h_lo(q.y), q3 = h_hi(q.y);
+        s1 += (q0 + q1) + (q2 + q3);
+        s2 += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
     }
 };
 
@@ -1452,6 +1487,9 @@ extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int
                                               EpAxpyResBf16<true>{(bf16_t*)e->out, (const bf16_t*)e->res, e->bias, e->alpha, ldo}, s);
             case ISP_EP_RESIDUAL_F32:  // the ViT's fp32 residual stream: x += gamma * (A W^T + bias) with half operands
                 return launch_gemm<CFG, true>(al, Wt, M, N, K, EpResidual{(float*)e->out, e->bias, e->gamma, ldo}, s);
+            case ISP_EP_RESIDUAL_STATS_F32:
+                if (!e->out2 || !e->out3) return (int)ISP_ERR_INVALID;
+                return launch_gemm<CFG, true>(al, Wt, M, N, K, EpResidualStats{(float*)e->out, e->bias, e->gamma, ldo, (unsigned short*)e->out3, (float*)e->out2, M}, s);
             case ISP_EP_LNFOLD_BF16:
             case ISP_EP_LNFOLD_GELU_BF16: {
                 if (!e->bias || !e->gamma || !e->res || e->tokens_per_image <= 0 || e->img_h <= 0) return (int)ISP_ERR_INVALID;
@@ -1479,6 +1517,7 @@ extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int
     if ((M + 127) / 128 >= 1024 && !wide_off) {  // (row tiles fill the chip four times over)
         if (N > 256 && N <= 384) return run(CfgWide384{});
         if (N > 384 && N <= 448) return run(CfgWide448{});
+        if (N > 448 && N <= 512) return run(CfgWide512{});
     }
     if ((M + 255) / 256 >= 512 && N >= 384) return run(CfgConv192{});
     if (((M + 127) / 128) * ((N + 127) / 128) < 256) return run(Cfg64{});
@@ -1487,6 +1526,20 @@ extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int
 
 // partial-statistics slots isp_gemm_f16 writes with ISP_EP_AXPY_RES_STATS_BF16 ([slots][M][2] floats)
 extern "C" int isp_gemm_stats_slots(void) { return CfgWide448::WN; }
+// ... and with ISP_EP_RESIDUAL_STATS_F32, where the tile configuration follows the problem size (same rules as isp_gemm_f16)
+template <class CFG>
+static int stats_slots_of(int N) { return ((N + CFG::BN - 1) / CFG::BN) * CFG::WN; }
+extern "C" int isp_gemm_f16_stats_slots(long M, int N) {
+    static const bool wide_off = [] { const char* e = getenv("ISEGPROBE_GEMM_WIDE"); return e && e[0] == '0'; }();
+    if ((M + 127) / 128 >= 1024 && !wide_off) {
+        if (N > 256 && N <= 384) return stats_slots_of<CfgWide384>(N);
+        if (N > 384 && N <= 448) return stats_slots_of<CfgWide448>(N);
+        if (N > 448 && N <= 512) return stats_slots_of<CfgWide512>(N);
+    }
+    if ((M + 255) / 256 >= 512 && N >= 384) return stats_slots_of<CfgConv192>(N);
+    if (((M + 127) / 128) * ((N + 127) / 128) < 256) return stats_slots_of<Cfg64>(N);
+    return stats_slots_of<Cfg128>(N);
+}
 
 // A/B switch for experiments: ISEGPROBE_CONV_ENGINE=tile selects the generic tile engine for every conv
 static bool ep_forces_tile_engine() {

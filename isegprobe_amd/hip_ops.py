@@ -89,6 +89,7 @@ def _epilogue(kind, out, ldo=0, bias=None, gamma=None, pos=None, tokens=0, res=N
     ep.res = res.data_ptr() if res is not None else None
     ep.alpha = alpha
     ep.out2 = None
+    ep.out3 = None
     return ep
 
 
@@ -150,6 +151,21 @@ def linear_residual_(x, A, Wt, bias=None, gamma=None):
     _need(x, torch.float32, "x")
     gemm(A, Wt, _epilogue(_lib.EP_RESIDUAL_F32, x, x.shape[-1], bias, gamma))
     return x
+
+
+def linear_residual_stats_(x, A, Wt, bias=None, gamma=None):
+    """linear_residual_ on IEEE-half operands that also returns (x16, stats): the half copy of the updated fp32 rows and their
+    per-row partial sums f32 [slots, M, 2] -- what ``linear_lnfold`` needs to run the block's next LayerNorm + Linear as one
+    GEMM (csrc/gemm.hip, EpResidualStats / EpLnFold)."""
+    _need(x, torch.float32, "x")
+    _need(A, F16, "A")
+    M, N = x.shape
+    x16 = torch.empty(M, N, device=x.device, dtype=F16)
+    stats = torch.empty(_lib.lib().isp_gemm_f16_stats_slots(M, N), M, 2, device=x.device, dtype=torch.float32)
+    ep = _epilogue(_lib.EP_RESIDUAL_STATS_F32, x, N, bias, gamma)
+    ep.out2, ep.out3 = stats.data_ptr(), x16.data_ptr()
+    gemm(A, Wt, ep)
+    return x16, stats
 
 
 def vit_mlp_pack(norm_w, norm_b, fc1_w, fc1_b, fc2_w, fc2_b, ls=None):

@@ -800,7 +800,18 @@ def gen_noc_dataset():
     from core.inference.utils import compute_noc_metric
     root = os.path.join(OUT, "noc_grabcut")
     _write_noc_tree(root)
-    model = _train_noc_model(build_ref_model("bilinear", seed=70), steps=int(os.environ.get("NOC_TRAIN_STEPS", 3000)))
+    steps = int(os.environ.get("NOC_TRAIN_STEPS", 2500))
+    model = build_ref_model("bilinear", seed=70)
+    cache = os.environ.get("NOC_MODEL_CACHE")  # developer convenience only: re-running the evaluation half without the 15-45 min of CPU training
+    if cache and os.path.exists(cache):
+        model.load_state_dict(torch.load(cache))
+        for p_ in model.parameters():
+            p_.requires_grad_(False)
+        model.eval()
+    else:
+        model = _train_noc_model(model, steps=steps)
+        if cache:
+            torch.save(model.state_dict(), cache)
     dataset = GrabCutDataset(root)
     assert len(dataset) == 50
     predictor = get_predictor(model, "NoBRS", torch.device("cpu"), prob_thresh=NOC_EVAL["thresh"], zoom_in_params=NOC_EVAL["zoom"])
@@ -833,7 +844,7 @@ def gen_noc_dataset():
         smp = dataset.get_sample(i)
         out[f"shape_{i}"] = np.array(smp.image.shape)
         out[f"image_sum_{i}"] = np.array(smp.image.astype(np.int64).sum())
-        out[f"gt_counts_{i}"] = np.array([(smp.gt_mask(1) == v).sum() for v in (-1, 0, 1)])
+        out[f"gt_counts_{i}"] = np.array([(smp.gt_mask(smp.objects_ids[0]) == v).sum() for v in (-1, 0, 1)])
     save("noc_dataset", **out)
 
 
