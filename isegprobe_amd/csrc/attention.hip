@@ -305,17 +305,20 @@ __device__ __forceinline__ f32x16 att_mfma(const bf16x8& a, const bf16x8& b, con
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <bool PRESCALED, bool F16 = false>  // F16: Q, K, V, P and O are IEEE half
-__global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                             const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H,
-                                                             int Lq, int Lk, long qsb, long qsl, long qsh, long ksb,
-                                                             long ksl, long ksh, long osb, long osl, long osh,
-                                                             float c_arg /* scale*log2e */, float* __restrict__ lse,
-                                                             long lse_ld, int nbh, int nqb) {
-    using G = Geo<64>;
+// HD / NW: written for head_dim 64 with 4 waves (the ViT); instantiated as well for head_dim 128 with 8 waves = 256 queries
+// per workgroup (LoftUp's cross-attention, 200 k pixel queries x 1 k keys: half the K / V bytes staged per query), where
+// the deferred maximum removes the per-tile rescale of 64 accumulator registers the generic kernel pays.
+template <bool PRESCALED, bool F16 = false, int HD = 64, int NW_ = 4>  // F16: Q, K, V, P and O are IEEE half
+__device__ __forceinline__ void attention64_body(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                 const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H, int Lq, int Lk,
+                                                 long qsb, long qsl, long qsh, long ksb, long ksl, long ksh, long osb, long osl,
+                                                 long osh, float c_arg /* scale*log2e */, float* __restrict__ lse, long lse_ld,
+                                                 int nbh, int nqb) {
+    using G = Geo<HD>;
     const float c = PRESCALED ? 1.f : c_arg;  // scores, m_run and the threshold are in units of 1/c base-2 logits
     const float thr = PRESCALED ? ISP_ATT_THR : ISP_ATT_THR / c_arg;
-    constexpr int NW = 4, KK = 4, DB = 2, QB = 32 * NW, PPW = G::PIECES / NW;  // 2 K + 2 V pieces per wave and tile
+    constexpr int NW = NW_, KK = HD / 16, DB = HD / 32, QB = 32 * NW, PPW = G::PIECES / NW;  // 2 K + 2 V pieces per wave and tile
+    static_assert(G::PIECES % NW == 0, "pieces per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
     for (int kk = 0; kk < KK; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + 16 * kk);
 
     // ---- DMA: lane-constant offsets + the tile's offset, both in the range-checked vector offset
-    const int kbytes = (int)(((long)(Lk - 1) * ksl + 64) * 2);  // (checked by the launcher: < 2^31)
+    const int kbytes = (int)(((long)(Lk - 1) * ksl + HD) * 2);  // (checked by the launcher: < 2^31)
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(K + (size_t)b * ksb + (size_t)h * ksh), 0, kbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
@@ -402,7 +405,9 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
 #endif
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        o[0][i] = 0.f, o[1][i] = 0.f, negm[i] = 0.f;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[db][i] = 0.f;
+        negm[i] = 0.f;
 #if ISP_ATT_ONES
         lacc[i] = 0.f;
 #endif
@@ -471,7 +476,8 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             s0[i] -= d, s1[i] -= d;
-            o[0][i] *= alpha, o[1][i] *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) o[db][i] *= alpha;
 #if ISP_ATT_ONES
             lacc[i] *= alpha;
 #endif
@@ -543,27 +549,61 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(const bf16_t* __res
     }
 }
 
+// (thin non-template kernels: a __global__ template whose launch bounds depend on a template parameter loses its host-side
+// handle under hipcc 7.2 -- the library then fails to load with an undefined symbol)
+#define ISP_ATT64_KERNEL(NAME, PRE, F16, HD, NW)                                                                                  \
+    __global__ __launch_bounds__(64 * NW, 2) void NAME(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,                \
+                                                       const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int H, int Lq, int Lk, \
+                                                       long qsb, long qsl, long qsh, long ksb, long ksl, long ksh, long osb,       \
+                                                       long osl, long osh, float c_arg, float* __restrict__ lse, long lse_ld,     \
+                                                       int nbh, int nqb) {                                                        \
+        attention64_body<PRE, F16, HD, NW>(Q, K, V, O, H, Lq, Lk, qsb, qsl, qsh, ksb, ksl, ksh, osb, osl, osh, c_arg, lse, lse_ld, \
+                                           nbh, nqb);                                                                             \
+    }
+ISP_ATT64_KERNEL(attention64_kernel_scale_bf16, false, false, 64, 4)
+ISP_ATT64_KERNEL(attention64_kernel_bf16, true, false, 64, 4)
+ISP_ATT64_KERNEL(attention64_kernel_f16, true, true, 64, 4)
+ISP_ATT64_KERNEL(attention128_kernel_bf16, true, false, 128, 8)
+ISP_ATT64_KERNEL(attention128_kernel_f16, true, true, 128, 8)
+#undef ISP_ATT64_KERNEL
+
 constexpr int kAtt64Lds = Geo<64>::LDS;  // (K + V) x 2 buffers
 
-template <bool PRESCALED, bool F16 = false>
+template <bool PRESCALED, bool F16 = false, int HD = 64, int NW = 4>
 int launch_attention64(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk, long qsb,
                        long qsl, long qsh, long ksb, long ksl, long ksh, long osb, long osl, long osh, float scale,
                        float* lse, long lse_ld, hipStream_t s) {
     static bool attr_done = false;
-    auto kern = attention64_kernel<PRESCALED, F16>;
+    void (*kern)(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, long, long, long, long, long, long, long, long, long,
+                 float, float*, long, int, int);
+    if constexpr (HD == 128) {
+        static_assert(PRESCALED && NW == 8, "head_dim 128: base-2-logit queries, 8 waves");
+        kern = F16 ? attention128_kernel_f16 : attention128_kernel_bf16;
+    } else {
+        static_assert(HD == 64 && NW == 4 && (PRESCALED || !F16));
+        kern = !PRESCALED ? attention64_kernel_scale_bf16 : (F16 ? attention64_kernel_f16 : attention64_kernel_bf16);
+    }
+    constexpr int kLds = Geo<HD>::LDS;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kAtt64Lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
             return ISP_ERR_LAUNCH;
         attr_done = true;
     }
-    const int nqb = (Lq + 127) / 128;
-    kern<<<(unsigned)(nqb * B * H), 256, kAtt64Lds, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, H, Lq,
+    const int nqb = (Lq + 32 * NW - 1) / (32 * NW);
+    kern<<<(unsigned)(nqb * B * H), 64 * NW, kLds, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)O, H, Lq,
                                                             Lk, qsb, qsl, qsh, ksb, ksl, ksh, osb, osl, osh,
                                                             scale * 1.4426950408889634f, lse, lse_ld, B * H, nqb);
     return isp_launch_status();
 }
 
 }  // namespace
+
+// head_dim 128 on the deferred-maximum kernel: 32-bit addressable K / V slice (ISEGPROBE_ATT128_DM=0: the generic kernel)
+static bool dm128_ok(int Lk, long kv_stride_l) {
+    static const bool off = [] { const char* e = getenv("ISEGPROBE_ATT128_DM"); return e && e[0] == '0'; }();
+    return !off && kv_stride_l >= 128 && ((long)(Lk - 1) * kv_stride_l + 128) * 2 < (1L << 31) &&
+           (long)KB * kv_stride_l * 2 * ((Lk + KB - 1) / KB) < (1L << 31);
+}
 
 extern "C" int isp_attention_pipe_supported(int head_dim, int Lq, int Lk, long kv_stride_l);
 extern "C" int isp_attention_fwd_pipe(const void* Q, const void* K, const void* V, void* O, int B, int H, int Lq, int Lk,
@@ -627,6 +667,9 @@ static int attention_fwd_impl(const void* Q, const void* K, const void* V, void*
     }
     if (head_dim == 128) {
         // 256-query blocks once they still fill the chip several times over
+        if (logit2 && !lse && (long)((Lq + 255) / 256) * B * H >= 2048 && dm128_ok(Lk, kv_stride_l))
+            return launch_attention64<true, false, 128, 8>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                                                           kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, s);
         if ((long)((Lq + 255) / 256) * B * H >= 2048)
             return launch_attention<128, 8>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
                                             kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, scale, lse, lse_ld, s);
@@ -711,6 +754,9 @@ extern "C" int isp_attention_fwd_logit2_f16(const void* Q, const void* K, const 
 #define ISP_ATT_F16G(HD, NW)                                                                                                     \
     launch_attention<HD, NW, true>(q2, K, V, o2, B, H, lq2, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l, \
                                    kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 0.6931471805599453f, nullptr, 0, hs)
+        if (head_dim == 128 && wide && dm128_ok(Lk, kv_stride_l))  // deferred-maximum kernel, 8 waves (see attention64_kernel)
+            return launch_attention64<true, true, 128, 8>(q2, K, V, o2, B, H, lq2, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                                                          kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, hs);
         if (head_dim == 128) return wide ? ISP_ATT_F16G(128, 8) : ISP_ATT_F16G(128, 4);
         if (head_dim == 256) return wide ? ISP_ATT_F16G(256, 8) : ISP_ATT_F16G(256, 4);
         return ISP_ERR_UNSUPPORTED;

@@ -370,6 +370,28 @@ def test_attention_pipelined_deferred_max(ops, hd, spike_key, gain):
     assert (out.double() - ref).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("Lk", [257, 1024])
+def test_attention_deferred_max_head_dim_128(ops, half, Lk):
+    """LoftUp's shape class (many queries, few keys, head_dim 128, base-2-logit queries): routed to the deferred-maximum
+    kernel with 8 waves (attention64_kernel<..., 128, 8>) once 256-query blocks fill the chip; ragged and full last key
+    tiles, a spike that forces the rescale late in the key sequence; against an fp32 softmax on the GPU."""
+    torch.manual_seed(Lk)
+    dt = torch.float16 if half else BF
+    B, H, hd, Lq = 1, 4, 128, 131072
+    q = (torch.randn(B, Lq, H, hd, device="cuda") * (101 ** -0.5 * 1.4426950408889634)).to(dt)
+    k = torch.randn(B, Lk, H, hd, device="cuda").to(dt)
+    v = torch.randn(B, Lk, H, hd, device="cuda").to(dt)
+    k[0, Lk - 3, 1] = (q[0, 777, 1].float() * 40).to(dt)  # score(777, Lk-3) in head 1 far above the running maximum
+    out = ops.attention(q, k, v, None, q_logit2=True)
+    worst = 0.0
+    for h in range(H):
+        sc = (q[0, :, h].float() @ k[0, :, h].float().t()) * math.log(2.0)
+        ref = sc.softmax(-1) @ v[0, :, h].float()
+        worst = max(worst, (out[0, :, h].float() - ref).abs().max().item())
+    assert torch.isfinite(out.float()).all() and worst < 2e-2, worst
+
+
 def test_attention_online_softmax_rescale(ops):
     """A key whose score dwarfs the rest in a LATE tile forces the running-max rescale."""
     B, L, heads = 1, 256, 1
