@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from ... import hip_ops as ops
+from ..model._guidance_cache import guidance_scope
 from ..utils import distributed as D
 from .losses import NormalizedFocalLossSigmoid
 
@@ -53,6 +54,7 @@ class DataParallelTrainer:
         head = [p for n, p in model.named_parameters() if n.startswith("head.") and p.requires_grad]
         self.bucket = D.GradBucket(params, early=head)
         self._has_bn = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules())
+        self._sim_scope = 0
         self.optim = torch.optim.Adam(params, lr=lr, betas=betas, eps=eps)  # trainer.py:141, optimizer.py:14-35
 
     def _train_mode(self):
@@ -64,7 +66,10 @@ class DataParallelTrainer:
         """trainer.py:377-477 (training branch)."""
         image, gt_mask, points = batch["images"], batch["instances"], batch["points"]
         prev_output = torch.zeros_like(image[:, :1], dtype=torch.float32)
-        with torch.no_grad():
+        # the simulated-click forwards see one image: what the upsampler derives from the guidance alone (LoftUp's image
+        # branch = 42 % of its FLOPs, FeatUp-JBU's records, LiFT's pyramid) is computed by the first and reused by the others
+        self._sim_scope += 1
+        with torch.no_grad(), guidance_scope(("sim_clicks", id(self), self._sim_scope)):
             if num_iters is None:
                 num_iters = random.randint(0, self.max_num_next_clicks)
             for click_indx in range(num_iters):

@@ -415,3 +415,32 @@ def test_simple_vit_click_encoder_weight_gradients(golden):
         worst = min(worst, (cos, name))
         assert rms < 5e-2, (name, rms)
     assert worst[0] > 0.999, worst
+
+
+@pytest.mark.parametrize("up", ["loftup", "jbu_featup", "lift"])
+def test_simulated_click_forwards_share_guidance_work(up, monkeypatch):
+    """trainer.py:392-427: the no-grad simulated-click forwards of one step see the same image, so the trainer runs them
+    inside one guidance scope (the upsampler's image-only work is computed by the first, reused by the rest).  The loss of
+    the step must be bit-identical to the run that recomputes everything."""
+    import random as _random
+    from isegprobe_amd.core.model import _guidance_cache as gc
+    from isegprobe_amd.core.training.trainer import DataParallelTrainer
+
+    def run(disabled):
+        monkeypatch.setattr(gc, "_DISABLED", disabled)
+        model, image, points = _setup(up, injection="before_backbone")
+        model = model.cuda()
+        torch.manual_seed(5)
+        gt = (torch.rand(2, 1, 56, 56) > 0.5).float()
+        trainer = DataParallelTrainer(model, lr=1e-3)
+        np.random.seed(3)
+        _random.seed(3)
+        losses = []
+        for _ in range(2):  # second step: the slot of the first step's token is replaced in place
+            batch = {"images": image.cuda(), "instances": gt.cuda(), "points": points.cuda().float()}
+            losses.append(trainer.step(batch, num_iters=3).item())
+        return losses
+
+    a, b = run(True), run(False)
+    print(up, a, b)
+    assert a == b

@@ -81,6 +81,38 @@ for r in range(rounds):
         o = ops.attention(q.to(dt), k.to(dt), v.to(dt), hd ** -0.5)
         p = ((q.to(dt).float().permute(0, 2, 1, 3) @ k.to(dt).float().permute(0, 2, 3, 1)) * hd ** -0.5).softmax(-1)
         check(f"attention {dt} hd{hd} Lq{Lq} Lk{Lk} H{Hh}", o, (p @ v.to(dt).float().permute(0, 2, 1, 3)).permute(0, 2, 1, 3), tol)
+    # ---- base-2-logit queries (deferred-maximum kernels at head_dim 64 / 128; generic kernel at 256), with a spike row
+    hd2 = pick([64, 128, 256])
+    q2l = q if hd2 == hd else torch.randn(2, Lq, Hh, hd2, device="cuda")
+    k2l, v2l = (k, v) if hd2 == hd else (torch.randn(2, Lk, Hh, hd2, device="cuda"), torch.randn(2, Lk, Hh, hd2, device="cuda"))
+    q2l = q2l * (hd2 ** -0.5 * math.log2(math.e))
+    if Lq > 3:
+        q2l[0, ri(0, Lq - 1)] *= 40.0  # logits far above the deferred-maximum threshold
+    for dt, tol in ((BF, 2e-2), (H16, 4e-3)):
+        o = ops.attention(q2l.to(dt), k2l.to(dt), v2l.to(dt), None, q_logit2=True)
+        p = ((q2l.to(dt).float().permute(0, 2, 1, 3) @ k2l.to(dt).float().permute(0, 2, 3, 1)) * math.log(2.0)).softmax(-1)
+        check(f"attention logit2 {dt} hd{hd2} Lq{Lq} Lk{Lk} H{Hh}", o, (p @ v2l.to(dt).float().permute(0, 2, 1, 3)).permute(0, 2, 1, 3), tol)
+    # ---- LayerNorm folded into the next GEMM: residual GEMM with row statistics -> LN-folded GEMM (LoftUp's half stream)
+    Dl = 4 * ri(8, 112)            # channels the LayerNorm runs over
+    cpad = (Dl + 63) // 64 * 64    # padded row width (zero columns behind Dl)
+    Ml, Kl, Nl = ri(1, 4000), 64 * ri(1, 8), 4 * ri(1, 128)
+    al = torch.randn(Ml, Kl, device="cuda").to(H16)
+    wo = torch.zeros(cpad, Kl, device="cuda"); wo[:Dl] = torch.randn(Dl, Kl, device="cuda") / math.sqrt(Kl)
+    bo = torch.zeros(cpad, device="cuda"); bo[:Dl] = torch.randn(Dl, device="cuda")
+    res = torch.zeros(Ml, cpad, device="cuda"); res[:, :Dl] = torch.randn(Ml, Dl, device="cuda") * 2 + 0.5
+    res = res.to(H16)
+    xo, st = ops.linear_axpy_res_stats(al, wo.to(H16), bo, res, 1.0)
+    xr = res.float() + al.float() @ wo.to(H16).float().t() + bo
+    check(f"axpy_res_stats M{Ml} K{Kl} N{cpad}", xo, xr, 4e-3 * 1.5)
+    gl, bl = torch.randn(Dl, device="cuda"), torch.randn(Dl, device="cuda")
+    w2 = torch.randn(Nl, Dl, device="cuda") / math.sqrt(Dl)
+    c2 = torch.randn(Nl, device="cuda")
+    wf = torch.zeros(Nl, cpad, device="cuda"); wf[:, :Dl] = w2 * gl[None, :]
+    wf = wf.to(H16)
+    for act, fn in ((None, lambda t: t), ("gelu", F.gelu)):
+        y = ops.linear_lnfold(xo, st, wf, wf.float().sum(1), c2 + w2 @ bl, Dl, 1e-5, act)
+        ref = fn(F.layer_norm(xo.float()[:, :Dl], (Dl,), gl, bl, 1e-5) @ w2.t() + c2)
+        check(f"lnfold {act} M{Ml} D{Dl}/{cpad} N{Nl}", y, ref, 8e-3)
     # ---- LayerNorm dtypes
     rows, Dn = ri(1, 3000), 4 * ri(4, 300)
     xx = torch.randn(rows, Dn, device="cuda") * 3 + 1
