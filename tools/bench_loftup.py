@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Stage timing of the LoftUp upsampler at 448^2 (C=384)."""
-import sys, logging
+import os, sys, logging
 import torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
 logging.getLogger("root").setLevel(logging.WARNING)
 from helpers import seeded_
 from isegprobe_amd.core.model.upsamplers import LoftUpUpsampler
