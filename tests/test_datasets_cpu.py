@@ -158,3 +158,21 @@ def test_readers_vs_reference_readers(golden, tmp_path, name, sub):
                 assert got.shape == ref.shape and np.array_equal(got.astype(np.int32), ref), (name, i, j)
     if name == "SBD":
         assert (root / "val_images_and_ids_list.pkl").exists()
+
+
+def test_noc_tree_read_like_the_reference(golden):
+    """tests/golden/noc_grabcut is the 50-image tree the dataset-level NoC fixture was generated on: this repo's reader must
+    hand the evaluation what the reference's GrabCutDataset did (grabcut.py:12-42) -- same order, image bytes, and object /
+    background / ignore pixel counts (recorded by gen_golden.py::gen_noc_dataset from the reference's DSample)."""
+    import os
+    from isegprobe_amd.core.inference.datasets import GrabCutDataset
+    g = golden("noc_dataset")
+    ds = GrabCutDataset(os.path.join(os.path.dirname(__file__), "golden", "noc_grabcut"))
+    assert len(ds) == 50 and [n for n in ds.dataset_samples] == [str(n) for n in g["names"]]
+    for i in range(50):
+        smp = ds.get_sample(i)
+        assert tuple(smp.image.shape) == tuple(g[f"shape_{i}"]) and smp.image.dtype == np.uint8
+        assert int(smp.image.astype(np.int64).sum()) == int(g[f"image_sum_{i}"])
+        gt = smp.gt_mask(0)
+        assert [int((gt == v).sum()) for v in (-1, 0, 1)] == g[f"gt_counts_{i}"].tolist()
+        assert smp.objects_ids == [0]
