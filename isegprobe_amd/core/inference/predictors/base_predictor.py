@@ -77,7 +77,8 @@ class BasePredictor(object):
     @staticmethod
     def to_tensor(image: np.ndarray) -> torch.Tensor:
         """torchvision ToTensor semantics: HWC uint8 -> CHW float in [0,1]."""
-        t = torch.from_numpy(np.ascontiguousarray(image))
+        image = np.ascontiguousarray(image)
+        t = torch.from_numpy(image if image.flags.writeable else image.copy())  # (read-only arrays: decoded image buffers)
         if t.dim() == 2:
             t = t[:, :, None]
         t = t.permute(2, 0, 1)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise tools/bench_pmc.sh: per-kernel launch durations (kernel-stats) and fabric traffic (PMC passes) of bench.py's
-own launches -> profiles/r02_bench_kernel_stats.csv, profiles/r02_bench_pmc.json, profiles/r02_conv_pmc.json."""
+own launches -> profiles/<round>_bench_jbu448_b32_kernel_stats.csv, <round>_bench_pmc.json, <round>_conv_pmc.json (ROUND env, default r03)."""
 import csv
 import glob
 import json
@@ -9,6 +9,7 @@ import shutil
 import sys
 
 out = sys.argv[1] if len(sys.argv) > 1 else "profiles"
+R = os.environ.get("ROUND", "r03")
 
 
 def latest(pattern):
@@ -21,11 +22,11 @@ def short(name):
     return n[:n.index("(")] if "(" in n else n
 
 
-ks = latest("gpurun_out/r02_kstats/**/*kernel_stats.csv")
+ks = latest(f"gpurun_out/{R}_kstats/**/*kernel_stats.csv")
 if ks:
-    shutil.copy(ks, os.path.join(out, "r02_bench_jbu448_b32_kernel_stats.csv"))
+    shutil.copy(ks, os.path.join(out, f"{R}_bench_jbu448_b32_kernel_stats.csv"))
 per = {}
-for d, counters in (("r02_pmc_fetch", ("FETCH_SIZE",)), ("r02_pmc_write", ("WRITE_SIZE",)), ("r02_pmc_l2", ("TCC_HIT_sum", "TCC_MISS_sum"))):
+for d, counters in ((f"{R}_pmc_fetch", ("FETCH_SIZE",)), (f"{R}_pmc_write", ("WRITE_SIZE",)), (f"{R}_pmc_l2", ("TCC_HIT_sum", "TCC_MISS_sum"))):
     f = latest(f"gpurun_out/{d}/**/*counter_collection.csv")
     if not f:
         continue
@@ -52,7 +53,7 @@ for k, cs in sorted(per.items()):
         h, m = cs["TCC_HIT_sum"]["per_launch_mean"], cs["TCC_MISS_sum"]["per_launch_mean"]
         e["l2_hit_rate"] = h / (h + m) if h + m else None
     res["kernels"][k] = e
-json.dump(res, open(os.path.join(out, "r02_bench_pmc.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out, f"{R}_bench_pmc.json"), "w"), indent=1)
 conv = {k: v for k, v in res["kernels"].items() if "conv3x3_patch4_kernel_192" in k and "traffic_bytes_per_launch" in v}
 if conv:
     mean = sum(v["traffic_bytes_per_launch"] for v in conv.values()) / len(conv)
@@ -60,7 +61,7 @@ if conv:
                "derived": {"traffic_bytes_per_launch": mean, "algorithmic_bytes_per_launch": 9867657216,
                            "note": "mean over the two head-conv launches of a bench step (folded-affine first conv, classifier-fused "
                                    "second conv); " + res["units"]}},
-              open(os.path.join(out, "r02_conv_pmc.json"), "w"), indent=1)
+              open(os.path.join(out, f"{R}_conv_pmc.json"), "w"), indent=1)
     print("conv traffic per launch:", {k[-60:]: round(v["traffic_bytes_per_launch"] / 1e9, 2) for k, v in conv.items()})
 jbu = {k: v for k, v in res["kernels"].items() if k.startswith(("jbu_", "adaptive_avg_pool")) and "traffic_bytes_per_launch" in v}
 print("JBU kernels GB per launch x launches:", {k[:40]: (round(v["traffic_bytes_per_launch"] / 1e9, 3), v["FETCH_SIZE"]["launches"]) for k, v in jbu.items()})
