@@ -81,6 +81,12 @@ class DataParallelTrainer:
             if self.net.with_prev_mask and self.prev_mask_drop_prob > 0 and num_iters > 0:
                 zero = torch.from_numpy(np.random.random(size=prev_output.size(0)) < self.prev_mask_drop_prob)
                 prev_output[zero.to(prev_output.device)] = 0
+        # release what the scope memoised: the next step has another image, and the eval-mode packed weights (the cache's
+        # geometry key) are rebuilt after every train forward -- kept slots would pile up (8 x 6 GB at configs[4])
+        for m in self.net.modules():
+            gc = getattr(m, "_gcache", None)
+            if gc is not None:
+                gc.clear()
         net_input = torch.cat((image, prev_output), dim=1) if self.net.with_prev_mask else image
         output = self.net(net_input, points)
         loss = self.loss_fn(output["instances"], gt_mask).mean()
