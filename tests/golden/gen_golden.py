@@ -794,10 +794,6 @@ def gen_noc_dataset():
     cv2.COLOR_BGR2RGB = 4
     cv2.imread = lambda path, flags=None: np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
     cv2.cvtColor = lambda a, code: np.ascontiguousarray(a[:, :, ::-1])
-    from core.data.datasets.grabcut import GrabCutDataset
-    from core.inference.evaluation import evaluate_dataset
-    from core.inference.predictors import get_predictor
-    from core.inference.utils import compute_noc_metric
     root = os.path.join(OUT, "noc_grabcut")
     _write_noc_tree(root)
     steps = int(os.environ.get("NOC_TRAIN_STEPS", 2500))
@@ -812,6 +808,21 @@ def gen_noc_dataset():
         model = _train_noc_model(model, steps=steps)
         if cache:
             torch.save(model.state_dict(), cache)
+    out, dataset = _noc_evaluate(model, root, min_mid=26)
+    for i in range(len(dataset)):  # what the reference's reader returned: the test holds the product's reader to it
+        smp = dataset.get_sample(i)
+        out[f"shape_{i}"] = np.array(smp.image.shape)
+        out[f"image_sum_{i}"] = np.array(smp.image.astype(np.int64).sum())
+        out[f"gt_counts_{i}"] = np.array([(smp.gt_mask(smp.objects_ids[0]) == v).sum() for v in (-1, 0, 1)])
+    save("noc_dataset", **out)
+
+
+def _noc_evaluate(model, root, min_mid):
+    """The reference's dataset evaluation of `model` over the tree at `root` (see gen_noc_dataset) -> (arrays, dataset)."""
+    from core.data.datasets.grabcut import GrabCutDataset
+    from core.inference.evaluation import evaluate_dataset
+    from core.inference.predictors import get_predictor
+    from core.inference.utils import compute_noc_metric
     dataset = GrabCutDataset(root)
     assert len(dataset) == 50
     predictor = get_predictor(model, "NoBRS", torch.device("cpu"), prob_thresh=NOC_EVAL["thresh"], zoom_in_params=NOC_EVAL["zoom"])
@@ -834,18 +845,47 @@ def gen_noc_dataset():
     print(f"  NoC@80/85/90 = {np.round(noc, 3)}  >=20: {over}  mIoU@1..20 = {np.round(ious.mean(0), 3)}")
     print(f"  NoC@90 per object: {per_obj[:, 2].tolist()}")
     mid = ((per_obj[:, 2] > 1) & (per_obj[:, 2] < 20)).sum()
-    assert mid >= 26, f"NoC@90 must be neither 1 nor 20 for most objects, got {mid}/50"
+    assert mid >= min_mid, f"NoC@90 must be neither 1 nor 20 for at least {min_mid} objects, got {mid}/50"
     out = {"ious": ious.astype(np.float32), "noc": np.array(noc), "noc_std": np.array(noc_std), "noc_over": np.array(over),
            "noc_per_object": per_obj.astype(np.int64), "clicks": np.array(clicks_all, dtype=np.int64),
            "near_counts": np.array(near_all, dtype=np.int64), "names": np.array(dataset.dataset_samples)}
     for k, v in sd_np(model).items():
         out["w::" + k] = v
-    for i in range(len(dataset)):  # what the reference's reader returned: the test holds the product's reader to it
-        smp = dataset.get_sample(i)
-        out[f"shape_{i}"] = np.array(smp.image.shape)
-        out[f"image_sum_{i}"] = np.array(smp.image.astype(np.int64).sum())
-        out[f"gt_counts_{i}"] = np.array([(smp.gt_mask(smp.objects_ids[0]) == v).sum() for v in (-1, 0, 1)])
-    save("noc_dataset", **out)
+    return out, dataset
+
+
+def gen_noc_dataset_upsamplers():
+    """The same dataset-level evaluation with the LEARNED upsamplers of BASELINE configs[2] / [3] (LoftUp, LiFT) in the tiny
+    model: backbone / click encoder / head start from the bilinear NoC model's weights (noc_dataset.npz), the upsampler from
+    its seeded initialisation, and everything is fine-tuned for NOC_FT_STEPS steps by the same recipe; then the reference's
+    evaluate_dataset + compute_noc_metric run over the same 50-image tree -> noc_dataset_<upsampler>.npz."""
+    import cv2  # noqa: stub
+    from PIL import Image
+    cv2.COLOR_BGR2RGB = 4
+    cv2.imread = lambda path, flags=None: np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    cv2.cvtColor = lambda a, code: np.ascontiguousarray(a[:, :, ::-1])
+    root = os.path.join(OUT, "noc_grabcut")
+    assert os.path.isdir(root), "run `gen_golden.py noc_dataset` first"
+    base = np.load(os.path.join(OUT, "noc_dataset.npz"))
+    steps = int(os.environ.get("NOC_FT_STEPS", 900))
+    for up in os.environ.get("NOC_UPSAMPLERS", "loftup,lift").split(","):
+        model = build_ref_model(up, seed=70)
+        sd = {k[3:]: torch.from_numpy(base[k]) for k in base.files if k.startswith("w::")}
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.startswith("upsampler.") for k in missing), (missing[:5], unexpected[:5])
+        cache = os.environ.get("NOC_MODEL_CACHE")
+        cache = cache and f"{cache}.{up}"
+        if cache and os.path.exists(cache):
+            model.load_state_dict(torch.load(cache))
+            for p_ in model.parameters():
+                p_.requires_grad_(False)
+            model.eval()
+        else:
+            model = _train_noc_model(model, steps=steps, seed=72)
+            if cache:
+                torch.save(model.state_dict(), cache)
+        out, _ = _noc_evaluate(model, root, min_mid=15)
+        save(f"noc_dataset_{up}", **out)
 
 
 def seed_by_name_(module, seed, skip=()):
@@ -1126,9 +1166,9 @@ def gen_crops():
 def main():
     torch.set_num_threads(4)
     install_standins()
-    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "noc_dataset", "checkpoint", "train_step", "datasets", "crops"]
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "noc_dataset", "noc_upsamplers", "checkpoint", "train_step", "datasets", "crops"]
     fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino, "simple_vit": gen_simple_vit, "maskclip": gen_maskclip,
-           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "noc_dataset": gen_noc_dataset, "checkpoint": gen_checkpoint, "train_step": gen_train_step, "datasets": gen_datasets, "crops": gen_crops}
+           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "noc_dataset": gen_noc_dataset, "noc_upsamplers": gen_noc_dataset_upsamplers, "checkpoint": gen_checkpoint, "train_step": gen_train_step, "datasets": gen_datasets, "crops": gen_crops}
     for w in which:
         fns[w]()
 

@@ -16,20 +16,25 @@ from helpers import build_model
 
 pytestmark = pytest.mark.gpu
 THRS = (0.8, 0.85, 0.9)
+# upsampler of the tiny model -> fixture.  "bilinear" is BASELINE configs[0]'s evaluation; the LoftUp / LiFT fixtures put the
+# learned upsamplers of configs[2] / [3] through the same dataset-level evaluation (gen_golden.py::gen_noc_dataset_upsamplers)
+FIXTURES = {"bilinear": "noc_dataset", "loftup": "noc_dataset_loftup", "lift": "noc_dataset_lift"}
+UP_PARAMS = {"lift": {"lift_path": None, "n_dim": 128, "patch": 14}, "loftup": {"upsampler_path": None, "n_dim": 128}}
+MIN_MID = {"bilinear": 26, "loftup": 15, "lift": 15}
 
 
-def _checkpoint(golden, tmp_path):
+def _checkpoint(golden, tmp_path, up):
     from isegprobe_amd.core.utils.misc import save_checkpoint
-    g = golden("noc_dataset")
-    model = build_model("bilinear")
+    g = golden(FIXTURES[up])
+    model = build_model(up, upsampler_params=UP_PARAMS.get(up))
     missing, unexpected = model.load_state_dict(weights_from(g, "w"), strict=False)
-    assert not unexpected and all("mask_token" in k for k in missing), (missing, unexpected)
+    assert not unexpected and all(("mask_token" in k or "num_batches_tracked" in k) for k in missing), (missing, unexpected)
     return g, save_checkpoint(model, tmp_path / "ckpt", verbose=False)
 
 
-def _run(golden, tmp_path, extra):
+def _run(golden, tmp_path, extra, up="bilinear"):
     import evaluate
-    g, ckpt = _checkpoint(golden, tmp_path)
+    g, ckpt = _checkpoint(golden, tmp_path, up)
     res = evaluate.main(["--checkpoint", str(ckpt), "--dataset", os.path.join(GOLDEN, "noc_grabcut"), "--dataset-name", "GrabCut",
                          "--eval-mode", "fixed56", "--n-clicks", "20", "--thresh", "0.5", "--logs", str(tmp_path / "logs")] + extra)
     (name, all_ious, table), = res
@@ -41,10 +46,11 @@ def _noc(ious):
     return np.array([[(np.argmax(a >= t) + 1) if (a >= t).any() else 20 for t in THRS] for a in ious])
 
 
-def test_fixture_is_not_degenerate(golden):
-    g = golden("noc_dataset")
+@pytest.mark.parametrize("up", list(FIXTURES))
+def test_fixture_is_not_degenerate(golden, up):
+    g = golden(FIXTURES[up])
     per = g["noc_per_object"][:, 2]
-    assert ((per > 1) & (per < 20)).sum() >= 26           # NoC@90 neither 1 nor 20 for most objects
+    assert ((per > 1) & (per < 20)).sum() >= MIN_MID[up]  # NoC@90 neither 1 nor 20 for most objects
     assert np.array_equal(_noc(g["ious"]), g["noc_per_object"])
     assert (g["clicks"][:, :, 2] == 0).any()              # negative clicks occur
 
