@@ -21,6 +21,7 @@ THRS = (0.8, 0.85, 0.9)
 FIXTURES = {"bilinear": "noc_dataset", "loftup": "noc_dataset_loftup", "lift": "noc_dataset_lift"}
 UP_PARAMS = {"lift": {"lift_path": None, "n_dim": 128, "patch": 14}, "loftup": {"upsampler_path": None, "n_dim": 128}}
 MIN_MID = {"bilinear": 26, "loftup": 15, "lift": 15}
+FIXTURES = {up: name for up, name in FIXTURES.items() if os.path.exists(os.path.join(GOLDEN, name + ".npz"))}
 
 
 def _checkpoint(golden, tmp_path, up):
@@ -55,18 +56,19 @@ def test_fixture_is_not_degenerate(golden, up):
     assert (g["clicks"][:, :, 2] == 0).any()              # negative clicks occur
 
 
-@pytest.mark.parametrize("clicker", ["device", "host"])
-def test_noc_dataset_identical_to_reference_fp32(golden, tmp_path, clicker):
+@pytest.mark.parametrize("up,clicker", [(u, c) for u, c in (("bilinear", "device"), ("bilinear", "host"), ("lift", "device"), ("loftup", "device"))
+                                        if u in FIXTURES])
+def test_noc_dataset_identical_to_reference_fp32(golden, tmp_path, up, clicker):
     """Under the fp32-accurate forward the 50-object evaluation reproduces the reference's: NoC@80/85/90 per object and
     in the mean identical; the per-object IoU arrays identical wherever no prediction had a pixel within the fp32 gate of
     the threshold (|logit| < 1e-3; the generator stored those counts), and within a few pixels' worth of IoU elsewhere."""
-    g, ious, table = _run(golden, tmp_path, ["--fp32"] + (["--host-clicker"] if clicker == "host" else []))
+    g, ious, table = _run(golden, tmp_path, ["--fp32"] + (["--host-clicker"] if clicker == "host" else []), up)
     ref = g["ious"]
     noc = _noc(ious)
     diff_obj = np.nonzero((noc != g["noc_per_object"]).any(1))[0]
     exact = np.array([np.array_equal(a, b) for a, b in zip(ious, ref)])
     clean = g["near_counts"].sum(1) == 0                  # objects none of whose 20 predictions had a near-threshold pixel
-    print(f"[{clicker}] NoC@80/85/90 = {noc.mean(0)} (reference {g['noc']}); objects with identical IoU arrays {int(exact.sum())}/50 "
+    print(f"[{up}, {clicker}] NoC@80/85/90 = {noc.mean(0)} (reference {g['noc']}); objects with identical IoU arrays {int(exact.sum())}/50 "
           f"({int(clean.sum())} have no near-threshold pixel at all); max |dIoU| {np.abs(ious - ref).max():.2e}; NoC differs on {diff_obj.tolist()}")
     assert exact[clean].all()
     assert np.abs(ious - ref).max() < 5e-3
@@ -76,15 +78,17 @@ def test_noc_dataset_identical_to_reference_fp32(golden, tmp_path, clicker):
         assert abs(table[t] - g["noc"][k]) < 1e-12
 
 
-def test_noc_dataset_16bit_path(golden, tmp_path):
+@pytest.mark.parametrize("up", list(FIXTURES))
+def test_noc_dataset_16bit_path(golden, tmp_path, up):
     """The product (16-bit operand) path on the same evaluation.  Logits carry <= 1e-2 of rounding noise, which moves mask
     pixels near the threshold and, through the robot user's argmax of a distance transform, sometimes a click.  Measured
     (MI355X, this fixture): NoC@80/85/90 5.80 / 8.22 / 12.54 against the reference's 5.82 / 8.22 / 12.26; 4 of 50 objects
     differ -- three are knife edges (the IoU sequences agree within 5e-3 at every click, and the reference's IoU sits within
     5e-3 of the threshold at the click where one side crosses it: object 10 hovers at 0.90 from click 6 on), one diverges
     at click 18 of 20.  Required: every differing (object, threshold) is one of those two kinds and is printed with its
-    margin; mean NoC within half a click at every threshold; at most 8 objects differ; mean IoU within 5e-3."""
-    g, ious, table = _run(golden, tmp_path, [])
+    margin; mean NoC within half a click at every threshold; at most 8 objects differ; mean IoU within 5e-3.
+    LiFT fixture (measured): 2.94 / 4.00 / 7.18 against 2.94 / 4.10 / 7.18, one knife-edge object."""
+    g, ious, table = _run(golden, tmp_path, [], up)
     ref, noc = g["ious"], _noc(ious)
     thrs = (0.80, 0.85, 0.90)
     rows, unexplained = [], []
@@ -101,7 +105,7 @@ def test_noc_dataset_16bit_path(golden, tmp_path):
             rows.append((int(i), f"NoC@{int(thr * 100)}", a, b, f"ref IoU at click {c} is {margin:.1e} from the threshold", f"first |dIoU| > 5e-3 at click {first}", kind))
             if kind == "unexplained":
                 unexplained.append(rows[-1])
-    print(f"NoC@80/85/90 = {noc.mean(0)} (reference {g['noc']}); mIoU@20 {ious[:, -1].mean():.4f} (reference {ref[:, -1].mean():.4f}); "
+    print(f"[{up}] NoC@80/85/90 = {noc.mean(0)} (reference {g['noc']}); mIoU@20 {ious[:, -1].mean():.4f} (reference {ref[:, -1].mean():.4f}); "
           f"{len(set(r[0] for r in rows))} objects differ (object, metric, here, reference, margin, divergence, kind):")
     for r in rows:
         print("   ", r)
