@@ -38,6 +38,10 @@ def main(argv=None):
     ap.add_argument("--n-clicks", type=int, default=20)
     ap.add_argument("--thresh", type=float, default=0.5)
     ap.add_argument("--target-iou", type=float, default=0.90)
+    ap.add_argument("--clicks-limit", type=int, default=None,
+                    help="feed the network at most this many clicks of each polarity (-1 = n_clicks; eval_cfg.yaml clicks_limit, "
+                         "inference/utils.py:286-289 -> predictor net_clicks_limit)")
+    ap.add_argument("--min-n-clicks", type=int, default=1, help="clicks before the IoU target may stop an object (eval_cfg.yaml min_n_clicks)")
     ap.add_argument("--logs", default=None, help="directory for the results table / IoU pickles (default: a temp dir)")
     ap.add_argument("--host-clicker", action="store_true",
                     help="robot user + IoU on the host (numpy/scipy) as in the reference, instead of the device clicker")
@@ -47,7 +51,7 @@ def main(argv=None):
     overrides, rest = split_overrides(argv)
     args = ap.parse_args(rest)
     jobs = None  # [(dataset name, root)]
-    print_ious = True
+    print_ious, iou_analysis = True, False
     if overrides:
         cfg = apply_overrides(EVAL_DEFAULTS, overrides)
         given = {k for k, _, _ in overrides}
@@ -58,6 +62,8 @@ def main(argv=None):
         args.checkpoint = cfg["checkpoint"] if "checkpoint" in given else args.checkpoint
         args.eval_mode, args.n_clicks, args.thresh = str(cfg["eval_mode"]), int(cfg["n_clicks"]), float(cfg["thresh"])
         args.target_iou, print_ious = float(cfg["target_iou"]), bool(cfg["print_ious"])
+        args.clicks_limit = None if cfg["clicks_limit"] is None else int(cfg["clicks_limit"])
+        args.min_n_clicks, iou_analysis = int(cfg["min_n_clicks"]), bool(cfg["iou_analysis"])
         if cfg["logs_path"]:
             args.logs = str(cfg["logs_path"])
         if "datasets" in given and not args.dataset and not args.synthetic:
@@ -68,7 +74,7 @@ def main(argv=None):
             roots = (yaml.safe_load(open(str(cfg["main_cfg_path"]))) or {}).get("DATASETS", {})
             jobs = [(n, roots[DATASET_PATH_KEYS[n]]) for n in str(cfg["datasets"]).split(",")]
     # inference/utils.py:254-257: printing the per-click IoUs forces every click to run; otherwise stop at target_iou >= 0.8
-    max_iou_thr = 1.01 if print_ious else max(0.8, args.target_iou)
+    max_iou_thr = 1.01 if ((iou_analysis or print_ious) and args.min_n_clicks <= 1) else max(0.8, args.target_iou)
 
     import isegprobe_amd
     from isegprobe_amd.core.inference.datasets import get_dataset, write_synthetic_grabcut
@@ -112,10 +118,13 @@ def main(argv=None):
     for i, (name, root) in enumerate(jobs):
         dataset = get_dataset(name, root)
         # evaluate.py:72-94: zoom-in parameters and the predictor are rebuilt per dataset (cvpr: DAVIS runs at 672 x 672)
-        predictor = get_predictor(model, "NoBRS", device, prob_thresh=args.thresh,
+        predictor_params = {}
+        if args.clicks_limit is not None:  # inference/utils.py:286-289
+            predictor_params["net_clicks_limit"] = args.n_clicks if args.clicks_limit == -1 else args.clicks_limit
+        predictor = get_predictor(model, "NoBRS", device, prob_thresh=args.thresh, predictor_params=predictor_params,
                                   zoom_in_params=get_zoom_in_params(args.eval_mode, name))
         all_ious, elapsed = evaluate_dataset(dataset, predictor, pred_thr=args.thresh, max_iou_thr=max_iou_thr,
-                                             min_clicks=1, max_clicks=args.n_clicks,
+                                             min_clicks=args.min_n_clicks, max_clicks=args.n_clicks,
                                              device_clicker=False if args.host_clicker else None)
         # the reference's table / log files (inference/utils.py:174-246,365-543); NoC thresholds up to target_iou
         res = save_results(model.upsampler.__class__.__name__, name, logs, (all_ious, elapsed), eval_mode=args.eval_mode,

@@ -809,6 +809,16 @@ def gen_noc_dataset():
         if cache:
             torch.save(model.state_dict(), cache)
     out, dataset = _noc_evaluate(model, root, min_mid=26)
+    # eval_cfg.yaml `clicks_limit` (inference/utils.py:286-289 -> BasePredictor.net_clicks_limit): the network sees at most 3
+    # clicks of each polarity while the robot user keeps clicking -- 8 clicks per object, same tree, same model
+    from core.inference.evaluation import evaluate_dataset
+    from core.inference.predictors import get_predictor
+    lim = get_predictor(model, "NoBRS", torch.device("cpu"), prob_thresh=NOC_EVAL["thresh"], zoom_in_params=NOC_EVAL["zoom"],
+                        predictor_params={"net_clicks_limit": 3})
+    lim_ious, _ = evaluate_dataset(dataset, lim, pred_thr=NOC_EVAL["thresh"], max_iou_thr=NOC_EVAL["max_iou_thr"],
+                                   min_clicks=NOC_EVAL["min_clicks"], max_clicks=8)
+    out["limit3_ious"] = np.stack(lim_ious).astype(np.float32)
+    assert out["limit3_ious"].shape == (50, 8) and np.abs(out["limit3_ious"] - out["ious"][:, :8]).max() > 0.02  # the limit bites
     for i in range(len(dataset)):  # what the reference's reader returned: the test holds the product's reader to it
         smp = dataset.get_sample(i)
         out[f"shape_{i}"] = np.array(smp.image.shape)

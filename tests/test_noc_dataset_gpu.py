@@ -113,3 +113,20 @@ def test_noc_dataset_16bit_path(golden, tmp_path, up):
     assert np.abs(noc.mean(0) - g["noc"]).max() <= 0.5
     assert len(set(r[0] for r in rows)) <= 8
     assert abs(ious.mean() - ref.mean()) < 5e-3
+
+
+def test_clicks_limit_through_evaluate(golden, tmp_path):
+    """eval_cfg.yaml `clicks_limit` (inference/utils.py:286-289): the network is fed at most 3 clicks of each polarity while
+    the robot user keeps clicking.  The reference's own run of that setting (8 clicks per object, same tree and model) is in
+    the fixture; here it goes through evaluate.py's --clicks-limit / --n-clicks in the fp32-accurate mode."""
+    import evaluate
+    g, ckpt = _checkpoint(golden, tmp_path, "bilinear")
+    (name, all_ious, table), = evaluate.main(["--checkpoint", str(ckpt), "--dataset", os.path.join(GOLDEN, "noc_grabcut"), "--dataset-name", "GrabCut",
+                                              "--eval-mode", "fixed56", "--n-clicks", "8", "--clicks-limit", "3", "--thresh", "0.5", "--fp32",
+                                              "--logs", str(tmp_path / "logs")])
+    ious, ref = np.stack(all_ious), g["limit3_ious"]
+    assert ious.shape == ref.shape == (50, 8)
+    exact = int(sum(np.array_equal(a, b) for a, b in zip(ious, ref)))
+    print(f"clicks_limit=3: identical IoU arrays {exact}/50, max |dIoU| {np.abs(ious - ref).max():.2e}; "
+          f"against the unlimited run the limit moves IoUs by up to {np.abs(ref - g['ious'][:, :8]).max():.2f}")
+    assert np.abs(ious - ref).max() < 5e-3 and exact >= 45
