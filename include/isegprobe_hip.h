@@ -91,6 +91,11 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
                                       * ldo) and out2 = their per-row partial sums f32 [isp_gemm_f16_stats_slots(M, N)][M][2]: the ViT block's
                                       * LayerNorms (block.py:92-117) are then folded into the qkv / fc1 GEMMs (ISP_EP_LNFOLD_*) */
 
+#define ISP_EP_LNFOLD_LAYERNORM_BF16 18 /* isp_gemm_f16, N <= 512: ISP_EP_LNFOLD_BF16 followed by a LayerNorm over the N output
+                                      * channels of the row (gain `pos`, bias `out2` as const float*, epsilon `alpha2`), computed in the
+                                      * epilogue of a tile that spans the whole row: LoftUp's tail LayerNorm -> 1x1 conv -> channel
+                                      * LayerNorm (loftup/loftup.py:139-149) as ONE GEMM */
+
 typedef struct isp_epilogue {
     int kind;             /* ISP_EP_* */
     void* out;            /* bf16 or f32 per kind */
@@ -104,6 +109,7 @@ typedef struct isp_epilogue {
     int img_h, img_w;     /* image extent (BIAS_TAPS) */
     void* out2;           /* second output (BIAS_GELU_SAVE), row stride ldo; row statistics (..._STATS) */
     void* out3;           /* third output: the 16-bit copy of RESIDUAL_STATS */
+    float alpha2;         /* second scalar: epsilon of the output LayerNorm (LNFOLD_LAYERNORM) */
 } isp_epilogue;
 
 /* ---- C = A . Wt^T with a fused epilogue.  A [M, lda>=K] bf16, Wt [N,K] bf16, K % 64 == 0,

@@ -9,10 +9,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "libisegprobe_hip.so")  # env override: kernel A/B experiments
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 ISP_F32, ISP_BF16, ISP_F16 = 0, 1, 2
-EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16, EP_BIAS_QGELU_SAVE_BF16, EP_MUL_DQGELU_BF16, EP_AXPY_RES_STATS_BF16, EP_LNFOLD_BF16, EP_LNFOLD_GELU_BF16, EP_RESIDUAL_STATS_F32 = range(18)
+EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16, EP_BIAS_QGELU_SAVE_BF16, EP_MUL_DQGELU_BF16, EP_AXPY_RES_STATS_BF16, EP_LNFOLD_BF16, EP_LNFOLD_GELU_BF16, EP_RESIDUAL_STATS_F32, EP_LNFOLD_LAYERNORM_BF16 = range(19)
 
 _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed"}
 
@@ -36,6 +36,7 @@ class Epilogue(ctypes.Structure):
         ("img_w", ctypes.c_int),
         ("out2", ctypes.c_void_p),
         ("out3", ctypes.c_void_p),
+        ("alpha2", ctypes.c_float),
     ]
 
 

@@ -35,6 +35,7 @@ from . import BaseUpsampler
 
 LOFTUP_F16 = os.environ.get("ISEGPROBE_LOFTUP_F16", "1") != "0"  # IEEE-half inference stream (see _run)
 LOFTUP_LNFOLD = os.environ.get("ISEGPROBE_LOFTUP_LNFOLD", "1") != "0"  # LayerNorms folded into the consuming GEMMs (half stream)
+LOFTUP_TAIL_FUSED = os.environ.get("ISEGPROBE_LOFTUP_TAIL_FUSED", "1") != "0"  # final channel LayerNorm in the 1x1 conv's epilogue
 
 
 def _pad64(n):
@@ -364,6 +365,8 @@ class LoftUpUpsampler(BaseUpsampler):
             x = ops.linear_axpy_res(f, L["ff2_w"], L["ff2_b"], x_mid, 1.0)  # feed-forward + residual
         if fold and stats is not None:
             wf, sf, bf = P["fin_fold"]
+            if C <= 512 and LOFTUP_TAIL_FUSED:  # LayerNorm + 1x1 conv c -> C + channel LayerNorm: one GEMM, the map is written once
+                return ops.linear_lnfold_layernorm(x, stats, wf, sf, bf, c, P["tn_eps"], P["fln_w"], P["fln_b"], P["fln_eps"]).view(B, H, W, C)
             y = ops.linear_lnfold(x, stats, wf, sf, bf, c, P["tn_eps"])     # LayerNorm + 1x1 conv c -> C
         else:
             xn = ops.layernorm(x, P["tn_w"], P["tn_b"], P["tn_eps"], D=c, ld_out=cp, out_dtype=dt)

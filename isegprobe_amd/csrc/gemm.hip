@@ -426,6 +426,108 @@ struct EpLnFold {
     }
 };
 
+// EpLnFold followed by a LayerNorm over the OUTPUT row (LoftUp's tail, loftup.py:139-149: LayerNorm -> 1x1 conv c -> C ->
+// channel LayerNorm): y[n] = rstd (v - mean s[n]) + bias[n], out = (y - mean_y) rstd_y g2[n] + b2[n].  The workgroup's tile
+// spans the whole output row (N <= BN), so mean_y / rstd_y come from the accumulators: per-wave partial sums through LDS,
+// one barrier, normalise in registers -- the [M, C] map is written once instead of written, read and written again.
+template <bool F16 = false>
+struct EpLnFoldLayerNorm {
+    static constexpr bool kRowLayerNorm = true;
+    bf16_t* out;
+    const float* bias;   // c + W b
+    const float* ssum;   // s[n]
+    const float* stats;  // [slots][M][2] from the producer of the input rows
+    long M;
+    int slots;
+    float inv_d, eps;    // input LayerNorm: 1 / channels, epsilon
+    long ldo;
+    const float* g2;     // output LayerNorm gain / bias over the N output channels
+    const float* b2;
+    float inv_n, eps2;
+    struct Cols {
+        float4 b, s, g, h;
+    };
+    using RowCtx = typename EpLnFold<ACT_NONE, F16>::RowCtx;
+    __device__ __forceinline__ Cols cols(int n) const {
+        return Cols{*reinterpret_cast<const float4*>(bias + n), *reinterpret_cast<const float4*>(ssum + n),
+                    *reinterpret_cast<const float4*>(g2 + n), *reinterpret_cast<const float4*>(b2 + n)};
+    }
+    __device__ __forceinline__ RowCtx row_begin(long m) const {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < slots; ++k) {
+            const float2 p = *reinterpret_cast<const float2*>(stats + ((size_t)k * M + m) * 2);
+            s1 += p.x, s2 += p.y;
+        }
+        const float mean = s1 * inv_d;
+        return RowCtx{mean, rsqrtf(fmaxf(s2 * inv_d - mean * mean, 0.f) + eps)};
+    }
+    __device__ __forceinline__ void value(f32x4& v, const Cols& c, const RowCtx& r) const {  // acc -> y, in place
+        v[0] = r.rstd * (v[0] - r.mean * c.s.x) + c.b.x, v[1] = r.rstd * (v[1] - r.mean * c.s.y) + c.b.y;
+        v[2] = r.rstd * (v[2] - r.mean * c.s.z) + c.b.z, v[3] = r.rstd * (v[3] - r.mean * c.s.w) + c.b.w;
+    }
+    __device__ __forceinline__ uint2 pack(const f32x4& y, const Cols& c, float mean, float rstd) const {
+        return make_uint2(pack2o_sat<!F16>((y[0] - mean) * rstd * c.g.x + c.h.x, (y[1] - mean) * rstd * c.g.y + c.h.y),
+                          pack2o_sat<!F16>((y[2] - mean) * rstd * c.g.z + c.h.z, (y[3] - mean) * rstd * c.g.w + c.h.w));
+    }
+};
+
+// The whole-row epilogue of gemm_tile_kernel for EP::kRowLayerNorm (tiles_n == 1).  red: [WN][BM] float2 of LDS behind the
+// operand ring's first bytes, which every wave has finished reading (barrier at entry).
+template <class CFG, class EP, class RowFn>
+__device__ __forceinline__ void row_layernorm_epilogue(const EP& ep, f32x4 (&acc)[CFG::TM][CFG::TN], RowFn row_of, int wm, int wn,
+                                                       int fr, int fq, int N, char* smem) {
+    constexpr int TM = CFG::TM, TN = CFG::TN, BM = CFG::BM;
+    float2* red = reinterpret_cast<float2*>(smem);
+    const int n_base = wn * (TN * 16);
+    typename EP::Cols cc[TN];
+    int ncol[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        ncol[ni] = n_base + ni * 16 + fq * 4;
+        cc[ni] = ep.cols(ncol[ni] < N ? ncol[ni] : N - 4);
+    }
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the operand ring
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int rl = wm * (TM * 16) + mi * 16 + fr;
+        const long m = row_of(rl);
+        const auto ctx = ep.row_begin(m >= 0 ? m : 0);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            ep.value(acc[mi][ni], cc[ni], ctx);
+            if (ncol[ni] < N) {
+                s1 += (acc[mi][ni][0] + acc[mi][ni][1]) + (acc[mi][ni][2] + acc[mi][ni][3]);
+                s2 += (acc[mi][ni][0] * acc[mi][ni][0] + acc[mi][ni][1] * acc[mi][ni][1]) +
+                      (acc[mi][ni][2] * acc[mi][ni][2] + acc[mi][ni][3] * acc[mi][ni][3]);
+            }
+        }
+        s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+        if (fq == 0) red[wn * BM + rl] = make_float2(s1, s2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int rl = wm * (TM * 16) + mi * 16 + fr;
+        const long m = row_of(rl);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < CFG::WN; ++w) {
+            const float2 p = red[w * BM + rl];
+            s1 += p.x, s2 += p.y;
+        }
+        const float mean = s1 * ep.inv_n;
+        const float rstd = rsqrtf(fmaxf(s2 * ep.inv_n - mean * mean, 0.f) + ep.eps2);
+        if (m < 0) continue;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+            if (ncol[ni] < N)
+                *reinterpret_cast<uint2*>(ep.out + (size_t)m * ep.ldo + ncol[ni]) = ep.pack(acc[mi][ni], cc[ni], mean, rstd);
+    }
+}
+
 // relu(v + bias[n] - sum over the 3x3 taps that fall OUTSIDE the image of taps[t][n]), bf16 out.
 // Used when a per-pixel affine map z = (I + aW)x + a*b in front of a zero-padded 3x3 conv is folded
 // into the conv weights: the constant part a*b only contributes through taps inside the image.
@@ -789,19 +891,23 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void gemm_tile_kernel(AL a
 #ifdef ISP_ABLATE_GEMM_NO_EPILOGUE  // timing experiment only
     if (acc[0][0][0] != 12345.678f) return;
 #endif
-    // interior tile (wave-uniform): every row of the tile maps to an output row and every column is < N
-    if (n0 + BN <= N && al.template tile_full<BM>(tm)) {
-        if constexpr (kStagedStore<EP> && NW * kStageBytes<TM, TN> <= CFG::LDS) {
-            if (staged_store_ok(ep)) {
-                __builtin_amdgcn_s_barrier();  // every wave is done reading the operand ring
-                staged_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, lane, n0 + wn * (TN * 16),
-                                        smem + wid * kStageBytes<TM, TN>);
-                return;
-            }
-        }
-        run_epilogue<TM, TN, true>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * CFG::WN + wn);
+    if constexpr (requires { EP::kRowLayerNorm; }) {  // (the launcher guarantees tiles_n == 1)
+        row_layernorm_epilogue<CFG>(ep, acc, row_of, wm, wn, fr, fq, N, smem);
     } else {
-        run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * CFG::WN + wn);
+        // interior tile (wave-uniform): every row of the tile maps to an output row and every column is < N
+        if (n0 + BN <= N && al.template tile_full<BM>(tm)) {
+            if constexpr (kStagedStore<EP> && NW * kStageBytes<TM, TN> <= CFG::LDS) {
+                if (staged_store_ok(ep)) {
+                    __builtin_amdgcn_s_barrier();  // every wave is done reading the operand ring
+                    staged_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, lane, n0 + wn * (TN * 16),
+                                            smem + wid * kStageBytes<TM, TN>);
+                    return;
+                }
+            }
+            run_epilogue<TM, TN, true>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * CFG::WN + wn);
+        } else {
+            run_epilogue<TM, TN>(ep, acc, row_of, wm * (TM * 16), fr, fq, n0 + wn * (TN * 16), N, tn * CFG::WN + wn);
+        }
     }
 }
 
@@ -1504,6 +1610,26 @@ extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int
                 return (int)ISP_ERR_UNSUPPORTED;
         }
     };
+    if (e->kind == ISP_EP_LNFOLD_LAYERNORM_BF16) {  // one tile spans the output row: smallest configuration with N <= BN
+        if (!e->bias || !e->gamma || !e->res || !e->pos || !e->out2 || e->tokens_per_image <= 0 || e->img_h <= 0 || N > CfgWide512::BN)
+            return ISP_ERR_INVALID;
+        auto go = [&](auto cfg) {
+            using CFG = decltype(cfg);
+            static_assert(CFG::WN * CFG::BM * 8 <= CFG::LDS);
+            DenseA<CFG::PA> al;
+            al.A = (const bf16_t*)A;
+            al.lda = lda;
+            al.M = M;
+            return launch_gemm<CFG, true>(al, Wt, M, N, K,
+                                          EpLnFoldLayerNorm<true>{(bf16_t*)e->out, e->bias, e->gamma, (const float*)e->res, M, e->img_h,
+                                                                  1.0f / (float)e->tokens_per_image, e->alpha, ldo, e->pos,
+                                                                  (const float*)e->out2, 1.0f / (float)N, e->alpha2}, s);
+        };
+        if (N <= 128) return go(Cfg128{});
+        if (N <= 384) return go(CfgWide384{});
+        if (N <= 448) return go(CfgWide448{});
+        return go(CfgWide512{});
+    }
     if (e->kind == ISP_EP_AXPY_RES_STATS_BF16) {  // full-row tiles whatever M is: the statistics' slot count is then fixed
         if (!e->res || !e->out2 || N > CfgWide448::BN) return ISP_ERR_INVALID;
         DenseA<CfgWide448::PA> al;

@@ -784,6 +784,25 @@ def linear_lnfold(x, stats, Wfold, ssum, bias, D, eps, act=None):
     return out
 
 
+def linear_lnfold_layernorm(x, stats, Wfold, ssum, bias, D, eps, gain2, bias2, eps2):
+    """LayerNorm_N(Linear(LayerNorm_D(x))) as ONE GEMM: ``linear_lnfold`` whose epilogue also runs the LayerNorm over the N
+    output channels (N <= 512: a tile spans the row; gain2 / bias2 f32 [N]) -- LoftUp's tail (loftup/loftup.py:139-149)
+    without the pass that re-reads and re-writes the [pixels, C] map."""
+    _need(x, F16, "x")
+    _need(stats, torch.float32, "stats")
+    if stats.shape[1] != x.shape[0] or stats.shape[2] != 2:
+        raise IspError("linear_lnfold_layernorm: stats must be [slots, M, 2]")
+    N = Wfold.shape[0]
+    if N > 512 or N % 4:
+        raise IspError("linear_lnfold_layernorm: N must be a multiple of 4, at most 512")
+    out = torch.empty(x.shape[0], N, device=x.device, dtype=F16)
+    ep = _epilogue(_lib.EP_LNFOLD_LAYERNORM_BF16, out, N, bias, gamma=ssum, res=stats, alpha=float(eps))
+    ep.tokens_per_image, ep.img_h = int(D), int(stats.shape[0])
+    ep.pos, ep.out2, ep.alpha2 = _p(_need(gain2, torch.float32, "gain2")), _p(_need(bias2, torch.float32, "bias2")), float(eps2)
+    gemm(x, Wfold, ep)
+    return out
+
+
 def fuse_flip_sigmoid(logits, with_flip):
     """logits [2n,1,H,W] (second half: mirrored image) -> sigmoid(0.5*(a + flip(b))) [n,1,H,W];
     with_flip=False: sigmoid(logits)."""

@@ -624,3 +624,41 @@ def test_layernorm_folded_into_gemm(ops, M, act):
     err = (y.float() - ref).abs().max().item()
     print(f"lnfold M={M} act={act}: max err {err:.3g} (ref max {ref.abs().max().item():.3g})")
     assert err < 2e-2
+
+
+@pytest.mark.parametrize("M,N", [(70000, 384), (1000, 384), (333, 128), (4097, 448), (129, 500), (2050, 64)])
+def test_lnfold_gemm_with_output_layernorm(ops, M, N):
+    """LoftUp's tail as ONE GEMM (csrc/gemm.hip, EpLnFoldLayerNorm): LayerNorm_D -> Linear -> LayerNorm_N, the second
+    LayerNorm from the accumulators of a tile that spans the output row (per-wave partial sums through LDS) -- against the
+    three ops in fp32 on the same 16-bit-rounded input rows.  Full-row tile configurations for N <= 128 / 384 / 448 / 512,
+    ragged M and N, a row mean far from zero on both sides."""
+    torch.manual_seed(M + N)
+    c, cp, Kin = 404, 448, 448
+    H16 = torch.float16
+    A = torch.randn(M, Kin, device="cuda").to(H16)
+    W0 = torch.zeros(cp, Kin, device="cuda")
+    W0[:c] = torch.randn(c, Kin, device="cuda") / math.sqrt(Kin)
+    b0 = torch.zeros(cp, device="cuda")
+    b0[:c] = torch.randn(c, device="cuda")
+    res = torch.zeros(M, cp, device="cuda")
+    res[:, :c] = torch.randn(M, c, device="cuda") * 2 + 0.7
+    x, stats = ops.linear_axpy_res_stats(A, W0.to(H16), b0, res.to(H16), 1.0)
+    xs = x.float()
+    g, beta = 1 + 0.2 * torch.randn(c, device="cuda"), 0.3 * torch.randn(c, device="cuda")
+    W1 = torch.zeros(N, cp, device="cuda")
+    W1[:, :c] = torch.randn(N, c, device="cuda") / math.sqrt(c)
+    b1 = torch.randn(N, device="cuda") + 1.5
+    g2, beta2 = 1 + 0.2 * torch.randn(N, device="cuda"), 0.3 * torch.randn(N, device="cuda")
+    wf = W1.clone()
+    wf[:, :c] *= g
+    wh = wf.to(H16)
+    y = ops.linear_lnfold_layernorm(x, stats, wh, wh.float().sum(1).contiguous(), (b1 + W1[:, :c] @ beta).contiguous(), c, 1e-5,
+                                    g2, beta2, 1e-6)
+    mid = F.layer_norm(xs[:, :c], (c,), g, beta, 1e-5) @ W1[:, :c].t() + b1
+    ref = F.layer_norm(mid, (N,), g2, beta2, 1e-6)
+    err = (y.float() - ref).abs().max().item()
+    two = ops.layernorm(ops.linear_lnfold(x, stats, wh, wh.float().sum(1).contiguous(), (b1 + W1[:, :c] @ beta).contiguous(), c, 1e-5),
+                        g2, beta2, 1e-6, out_dtype=H16)
+    print(f"lnfold+layernorm M={M} N={N}: max err {err:.3g} (two-kernel route {(two.float() - ref).abs().max().item():.3g}; ref max {ref.abs().max().item():.3g})")
+    assert y.shape == (M, N) and torch.isfinite(y.float()).all()
+    assert err < 2e-2
