@@ -176,3 +176,22 @@ def test_noc_tree_read_like_the_reference(golden):
         gt = smp.gt_mask(0)
         assert [int((gt == v).sum()) for v in (-1, 0, 1)] == g[f"gt_counts_{i}"].tolist()
         assert smp.objects_ids == [0]
+
+
+def test_noc_sbd_tree_read_like_the_reference(golden, tmp_path):
+    """tests/golden/noc_sbd (SBD layout) through this repo's SBD evaluation reader: the same (image, instance) pairs in the same
+    order, image bytes and object pixel counts as the reference's SBDEvaluationDataset recorded (sbd.py:79-131)."""
+    import os
+    import shutil
+    from isegprobe_amd.core.inference.datasets import get_dataset
+    g = golden("noc_dataset_sbd")
+    tree = tmp_path / "noc_sbd"
+    shutil.copytree(os.path.join(os.path.dirname(__file__), "golden", "noc_sbd"), tree)
+    ds = get_dataset("SBD", str(tree))
+    assert len(ds) == len(g["pairs"]) == 46
+    for i in range(len(ds)):
+        name, inst = ds.dataset_samples[i]
+        assert [int(name.split("_")[1]), int(inst)] == g["pairs"][i].tolist()
+        smp = ds.get_sample(i)
+        assert int(smp.image.astype(np.int64).sum()) == int(g[f"image_sum_{i}"])
+        assert int((smp.gt_mask(0) == 1).sum()) == int(g[f"gt_count_{i}"])

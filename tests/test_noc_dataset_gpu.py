@@ -131,3 +131,41 @@ def test_clicks_limit_through_evaluate(golden, tmp_path):
     print(f"clicks_limit=3: identical IoU arrays {exact}/50, max |dIoU| {np.abs(ious - ref).max():.2e}; "
           f"against the unlimited run the limit moves IoUs by up to {np.abs(ref - g['ious'][:, :8]).max():.2f}")
     assert np.abs(ious - ref).max() < 5e-3 and exact >= 45
+
+
+def _run_sbd(golden, tmp_path, extra):
+    import shutil
+    import evaluate
+    g = golden("noc_dataset_sbd")
+    _, ckpt = _checkpoint(golden, tmp_path, "bilinear")
+    tree = tmp_path / "noc_sbd"                      # (the SBD reader leaves its pair-list cache inside the tree)
+    shutil.copytree(os.path.join(GOLDEN, "noc_sbd"), tree)
+    (name, all_ious, table), = evaluate.main(["--checkpoint", str(ckpt), "--dataset", str(tree), "--dataset-name", "SBD", "--eval-mode", "fixed56",
+                                              "--n-clicks", "20", "--thresh", "0.5", "--logs", str(tmp_path / "logs")] + extra)
+    assert name == "SBD" and len(all_ious) == len(g["ious"]) == 46
+    return g, np.stack(all_ious), table
+
+
+def test_noc_sbd_layout_identical_to_reference_fp32(golden, tmp_path):
+    """north_star: "NoC@90 on GrabCut/SBD identical to reference".  tests/golden/noc_sbd/ is a 26-image tree in SBD's on-disk
+    layout (JPEG images, GTinst .mat instance maps, val.txt; two instances per image, no ignore band);
+    noc_dataset_sbd.npz holds what the reference's SBDEvaluationDataset + evaluate_dataset + compute_noc_metric produced
+    for its 46 (image, instance) objects with the bilinear NoC model.  fp32-accurate mode: NoC identical per object."""
+    g, ious, table = _run_sbd(golden, tmp_path, ["--fp32"])
+    ref, noc = g["ious"], _noc(ious)
+    exact = int(sum(np.array_equal(a, b) for a, b in zip(ious, ref)))
+    print(f"[SBD layout, fp32] NoC@80/85/90 = {noc.mean(0)} (reference {g['noc']}); identical IoU arrays {exact}/46; max |dIoU| {np.abs(ious - ref).max():.2e}")
+    assert np.array_equal(noc, g["noc_per_object"]) and np.allclose(noc.mean(0), g["noc"])
+    assert np.abs(ious - ref).max() < 5e-3
+    for k, t in enumerate(("NoC@80%", "NoC@85%", "NoC@90%")):
+        assert abs(table[t] - g["noc"][k]) < 1e-12
+
+
+def test_noc_sbd_layout_16bit_path(golden, tmp_path):
+    g, ious, table = _run_sbd(golden, tmp_path, [])
+    ref, noc = g["ious"], _noc(ious)
+    differ = np.nonzero((noc != g["noc_per_object"]).any(1))[0]
+    print(f"[SBD layout, 16-bit] NoC@80/85/90 = {noc.mean(0)} (reference {g['noc']}); objects whose NoC differs: "
+          f"{[(int(i), noc[i].tolist(), g['noc_per_object'][i].tolist()) for i in differ]}; mean |dIoU| {np.abs(ious - ref).mean():.2e}")
+    assert np.abs(noc.mean(0) - g["noc"]).max() <= 0.5 and len(differ) <= 6
+    assert abs(ious.mean() - ref.mean()) < 5e-3
