@@ -96,6 +96,9 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
                                       * epilogue of a tile that spans the whole row: LoftUp's tail LayerNorm -> 1x1 conv -> channel
                                       * LayerNorm (loftup/loftup.py:139-149) as ONE GEMM */
 
+#define ISP_EP_BIAS_RELU_STATS_BF16 19 /* isp_conv3x3_nhwc_f16: ISP_EP_BIAS_RELU_BF16 that also writes out2 = per-pixel partial sums f32
+                                      * [isp_conv_stats_slots(N)][B*H*W][2] of the stored values (for ISP_EP_LNFOLD_* consumers) */
+
 typedef struct isp_epilogue {
     int kind;             /* ISP_EP_* */
     void* out;            /* bf16 or f32 per kind */
@@ -120,6 +123,7 @@ int isp_gemm_bf16(const void* A, long lda, const void* Wt, long M, int N, int K,
  * kinds ISP_EP_BIAS_BF16, ISP_EP_BIAS_GELU_BF16 (half outputs saturate at +-65504), ISP_EP_AXPY_RES_BF16 (res and out half)
  * and ISP_EP_RESIDUAL_F32 (the ViT's fp32 residual stream); others ISP_ERR_UNSUPPORTED. */
 int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int N, int K, const isp_epilogue* ep, void* stream);
+int isp_conv_stats_slots(int N); /* partial-statistics slots of ISP_EP_BIAS_RELU_STATS_BF16 for N output channels */
 int isp_gemm_stats_slots(void); /* partial-statistics slots of ISP_EP_AXPY_RES_STATS_BF16 */
 int isp_gemm_f16_stats_slots(long M, int N); /* ... of ISP_EP_RESIDUAL_STATS_F32 for an M x N problem */
 

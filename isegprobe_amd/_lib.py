@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "l
 ABI_VERSION = 17
 
 ISP_F32, ISP_BF16, ISP_F16 = 0, 1, 2
-EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16, EP_BIAS_QGELU_SAVE_BF16, EP_MUL_DQGELU_BF16, EP_AXPY_RES_STATS_BF16, EP_LNFOLD_BF16, EP_LNFOLD_GELU_BF16, EP_RESIDUAL_STATS_F32, EP_LNFOLD_LAYERNORM_BF16 = range(19)
+EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16, EP_BIAS_QGELU_SAVE_BF16, EP_MUL_DQGELU_BF16, EP_AXPY_RES_STATS_BF16, EP_LNFOLD_BF16, EP_LNFOLD_GELU_BF16, EP_RESIDUAL_STATS_F32, EP_LNFOLD_LAYERNORM_BF16, EP_BIAS_RELU_STATS_BF16 = range(20)
 
 _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed"}
 
@@ -61,6 +61,7 @@ SIGNATURES = {
     "isp_attention_fwd_logit2_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_vp],
     "isp_attention_fwd_logit2": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_vp],
     "isp_gemm_stats_slots": [],
+    "isp_conv_stats_slots": [_i],
     "isp_gemm_f16_stats_slots": [_l, _i],
     "isp_attention_pipe_supported": [_i, _i, _i, _l],
     "isp_attention_fwd_pipe": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_i, _vp],

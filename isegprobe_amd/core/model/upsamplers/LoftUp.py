@@ -35,6 +35,7 @@ from . import BaseUpsampler
 
 LOFTUP_F16 = os.environ.get("ISEGPROBE_LOFTUP_F16", "1") != "0"  # IEEE-half inference stream (see _run)
 LOFTUP_LNFOLD = os.environ.get("ISEGPROBE_LOFTUP_LNFOLD", "1") != "0"  # LayerNorms folded into the consuming GEMMs (half stream)
+LOFTUP_Q0_STATS = os.environ.get("ISEGPROBE_LOFTUP_Q0_STATS", "1") != "0"  # row statistics from the second convolution's epilogue
 LOFTUP_TAIL_FUSED = os.environ.get("ISEGPROBE_LOFTUP_TAIL_FUSED", "1") != "0"  # final channel LayerNorm in the 1x1 conv's epilogue
 
 
@@ -318,17 +319,23 @@ class LoftUpUpsampler(BaseUpsampler):
                 return LiFTUpsampler._bn_forward(ops.conv3x3(f, P["conv2_w"], P["conv2_b"], None), fc[5], P["bn2_g"],
                                                  P["bn2_bt"])[0].view(M, cp)
             f = ops.conv3x3(f, P["conv1_w"], P["conv1_b"], "relu")
+            if fold and LOFTUP_Q0_STATS:  # the second convolution also emits the row statistics the first query projection's folded LayerNorm needs
+                y, st = ops.conv3x3_relu_stats(f, P["conv2_w"], P["conv2_b"])
+                return y.view(M, cp), st
             return ops.conv3x3(f, P["conv2_w"], P["conv2_b"], "relu").view(M, cp)
+        # Half stream with <= 448 padded channels: the LayerNorms in front of the feed-forward, of the query projections and
+        # of the final 1x1 conv are FOLDED into those GEMMs (weights carry the gain, a per-row correction in the epilogue),
+        # with the row statistics emitted by the kernel that produced the rows (the residual GEMMs, the second convolution) --
+        # no pass over the [B*H*W, 448] pixel map is left between the GEMMs (csrc/gemm.hip: EpAxpyResStats / EpBiasActStats /
+        # EpLnFold)
+        fold = half and cp <= 448 and LOFTUP_LNFOLD
         x = image_queries() if train else self._gcache.get(guidance, id(P), "x0", image_queries)
+        stats = None  # row statistics of the current x
+        if fold and LOFTUP_Q0_STATS:
+            x, stats = x
         scale = P["hd"] ** -0.5
         if save is not None:
             save.update(kv=kv, layers=[], geom=(B, h, w, C, H, W), train=train)
-        # Half stream with <= 448 padded channels: the LayerNorms in front of the feed-forward, of the second layer's query
-        # projection and of the final 1x1 conv are FOLDED into those GEMMs (weights carry the gain, a per-row correction in
-        # the epilogue), with the row statistics emitted by the residual GEMM that produced the rows -- four of the six
-        # passes over the [B*H*W, 448] pixel map per forward disappear (csrc/gemm.hip: EpAxpyResStats / EpLnFold)
-        fold = half and cp <= 448 and LOFTUP_LNFOLD
-        stats = None  # row statistics of the current x (None: x came from the convolutions)
         for li, L in enumerate(P["layers"]):
             def project_q(x=x, L=L, stats=stats):
                 if fold and stats is not None:

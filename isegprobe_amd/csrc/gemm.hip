@@ -200,6 +200,26 @@ struct EpBiasActBf16 {  // out[m][n] = bf16(act(v + bias[n]))
     }
 };
 
+// EpBiasActBf16 that also emits, per output row (pixel) and wave column group, the sum / sum of squares of the values it
+// stores -- partial[slot][M][2], slot = n-tile * (n-waves per tile) + n-wave; column groups past N write zeros.  LoftUp's
+// second convolution hands these to the first cross-attention's LN-folded query projection (EpLnFold), so the LayerNorm pass
+// over the [pixels, 448] map in front of it disappears (loftup/layers.py:186-195).
+template <int ACT, bool F16 = false>
+struct EpBiasActStats : EpBiasActBf16<ACT, F16> {
+    static constexpr bool kRowStats = true;
+    float* stats;  // [slots][M][2]
+    long M;
+    __device__ __forceinline__ void put_stats(long m, int slot, float s1, float s2) const {
+        *reinterpret_cast<float2*>(stats + ((size_t)slot * M + m) * 2) = make_float2(s1, s2);
+    }
+    static __device__ __forceinline__ void add(const uint2& q, float& s1, float& s2) {  // statistics of the values AS STORED
+        const float q0 = F16 ? h_lo(q.x) : __uint_as_float(q.x << 16), q1 = F16 ? h_hi(q.x) : __uint_as_float(q.x & 0xffff0000u);
+        const float q2 = F16 ? h_lo(q.y) : __uint_as_float(q.y << 16), q3 = F16 ? h_hi(q.y) : __uint_as_float(q.y & 0xffff0000u);
+        s1 += (q0 + q1) + (q2 + q3);
+        s2 += (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+    }
+};
+
 __device__ __forceinline__ float act_fwd(int act, float x) {
     return act == ACT_QGELU ? x / (1.0f + __expf(-1.702f * x)) : gelu_erf(x);
 }
@@ -405,11 +425,14 @@ struct EpLnFold {
         return Cols{*reinterpret_cast<const float4*>(bias + n), *reinterpret_cast<const float4*>(ssum + n)};
     }
     __device__ __forceinline__ RowCtx row_begin(long m) const {
+        // the four lanes that hold a row (lane >> 4 = 0..3) share the slot loads and exchange the sums
         float s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < slots; ++k) {
+        for (int k = (int)(__lane_id() >> 4); k < slots; k += 4) {
             const float2 p = *reinterpret_cast<const float2*>(stats + ((size_t)k * M + m) * 2);
             s1 += p.x, s2 += p.y;
         }
+        s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
         const float mean = s1 * inv_d;
         return RowCtx{mean, rsqrtf(fmaxf(s2 * inv_d - mean * mean, 0.f) + eps)};
     }
@@ -453,11 +476,14 @@ struct EpLnFoldLayerNorm {
                     *reinterpret_cast<const float4*>(g2 + n), *reinterpret_cast<const float4*>(b2 + n)};
     }
     __device__ __forceinline__ RowCtx row_begin(long m) const {
+        // the four lanes that hold a row (lane >> 4 = 0..3) share the slot loads and exchange the sums
         float s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < slots; ++k) {
+        for (int k = (int)(__lane_id() >> 4); k < slots; k += 4) {
             const float2 p = *reinterpret_cast<const float2*>(stats + ((size_t)k * M + m) * 2);
             s1 += p.x, s2 += p.y;
         }
+        s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
         const float mean = s1 * inv_d;
         return RowCtx{mean, rsqrtf(fmaxf(s2 * inv_d - mean * mean, 0.f) + eps)};
     }
@@ -681,6 +707,20 @@ __device__ __forceinline__ void run_epilogue(const EP& ep, f32x4 (&acc)[TM][TN],
                     const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
                     if constexpr (!requires { EP::kRowStats; }) ep(m, ncol[ni], v, cc[ni], pp[ni]);
                 }
+            } else if constexpr (requires { EP::kRowStats; }) {  // (no per-element operand: EpBiasActStats)
+                float s1 = 0.f, s2 = 0.f;
+                const bool row_ok = FULL || m >= 0;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    if (!row_ok || (!FULL && ncol[ni] >= N)) continue;
+                    const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                    const uint2 q = ep.pack(m, ncol[ni], v, cc[ni]);
+                    *reinterpret_cast<uint2*>(ep.out + (size_t)m * ep.ldo + ncol[ni]) = q;
+                    EP::add(q, s1, s2);
+                }
+                s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+                if (fq == 0 && row_ok) ep.put_stats(m, slot, s1, s2);
             } else {
                 if (!FULL && m < 0) continue;
                 if constexpr (requires { ep.row_begin(m); }) {
@@ -728,7 +768,7 @@ __device__ __forceinline__ bool staged_store_ok(const EP& ep) {  // 16-byte chun
 // kStageBytes<TM, TN> of LDS that no other wave touches any more.
 template <int TM, int TN, class EP, class RowFn>
 __device__ __forceinline__ void staged_epilogue(const EP& ep, f32x4 (&acc)[TM][TN], RowFn row_in, int row_base, int fr,
-                                                int fq, int lane, int n_base, char* stg) {
+                                                int fq, int lane, int n_base, char* stg, int slot = 0) {
     constexpr int SP = TN * 32 + 16, CPR = TN * 2;  // row pitch; 16-byte chunks per row
     static_assert((TM * 16 * CPR) % 64 == 0);
     typename EP::Cols cc[TN];
@@ -745,6 +785,18 @@ __device__ __forceinline__ void staged_epilogue(const EP& ep, f32x4 (&acc)[TM][T
                 const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
                 put(ni, ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni], ctx));
             }
+        } else if constexpr (requires { EP::kRowStats; }) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
+                const uint2 q = ep.pack(m, n_base + ni * 16 + fq * 4, v, cc[ni]);
+                put(ni, q);
+                EP::add(q, s1, s2);
+            }
+            s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+            if (fq == 0) ep.put_stats(m, slot, s1, s2);
         } else {
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
@@ -1353,7 +1405,7 @@ __device__ __forceinline__ void conv3x3_patch4_body(const bf16_t* __restrict__ i
         // the other waves are past every LDS read whose value is used: no barrier before the wave-private staging
         if constexpr (kStagedStore<EP>) {
             staged_epilogue<TM, TN>(ep, acc, row_in, wm * (TM * 16), fr_e, fq_e, lane_e, n0 + wn * (TN * 16),
-                                    smem + wid * kStageBytes<TM, TN>);
+                                    smem + wid * kStageBytes<TM, TN>, tn * 2 + wn);
         } else {
             run_epilogue<TM, TN, true>(ep, acc, row_in, wm * (TM * 16), fr_e, fq_e, n0 + wn * (TN * 16), N, tn * 2 + wn);
         }
@@ -1714,11 +1766,19 @@ extern "C" int isp_conv3x3_nhwc_f16(const void* in, const void* Wt, int B, int H
             case ISP_EP_RELU_DOT_PARTIAL_F32:
                 if (!e->bias || !e->gamma) return ISP_ERR_INVALID;
                 return launch_conv_patch4<4, EpReluDotPartial, true>(in, Wt, B, H, W, C, N, {(float*)e->out, e->bias, e->gamma, M}, s);
+            case ISP_EP_BIAS_RELU_STATS_BF16:
+                if (!e->out2) return ISP_ERR_INVALID;
+                return launch_conv_patch4<4, EpBiasActStats<ACT_RELU, true>, true>(in, Wt, B, H, W, C, N,
+                                                                                   {{(bf16_t*)e->out, e->bias, ldo}, (float*)e->out2, M}, s);
             default:
                 return ISP_ERR_UNSUPPORTED;
         }
     }
     switch (e->kind) {
+        case ISP_EP_BIAS_RELU_STATS_BF16:
+            if (!e->out2) return ISP_ERR_INVALID;
+            return launch_conv_patch4<6, EpBiasActStats<ACT_RELU, true>, true>(in, Wt, B, H, W, C, N,
+                                                                               {{(bf16_t*)e->out, e->bias, ldo}, (float*)e->out2, M}, s);
         case ISP_EP_BIAS_BF16:
             return launch_conv_patch4<6, EpBiasActBf16<ACT_NONE, true>, true>(in, Wt, B, H, W, C, N, {(bf16_t*)e->out, e->bias, ldo}, s);
         case ISP_EP_BIAS_RELU_BF16:
@@ -1734,6 +1794,9 @@ extern "C" int isp_conv3x3_nhwc_f16(const void* in, const void* Wt, int B, int H
             return ISP_ERR_UNSUPPORTED;
     }
 }
+
+// partial-statistics slots isp_conv3x3_nhwc_f16 writes with ISP_EP_BIAS_RELU_STATS_BF16 ([slots][B*H*W][2] floats)
+extern "C" int isp_conv_stats_slots(int N) { return N % 192 == 0 ? (N / 192) * 2 : ((N + 127) / 128) * 2; }
 
 extern "C" int isp_conv3x3_nhwc_bf16(const void* in, const void* Wt, int B, int H, int W, int C, int N,
                                      const isp_epilogue* ep, void* stream) {

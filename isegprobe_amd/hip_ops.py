@@ -235,6 +235,24 @@ def conv3x3(x, Wt, bias=None, act="relu", out_dtype=None):
     return out
 
 
+def conv3x3_relu_stats(x, Wt, bias=None):
+    """relu(conv3x3(x) + bias) on IEEE-half operands that also returns the per-pixel partial sums of the stored values:
+    (out [B,H,W,N] f16, stats f32 [slots, B*H*W, 2]) -- what ``linear_lnfold`` needs to run a LayerNorm + Linear on `out` as one
+    GEMM (csrc/gemm.hip, EpBiasActStats)."""
+    _need(x, F16, "x")
+    fn, name = _conv_entry(x, Wt)
+    B, H, W, C = x.shape
+    N = Wt.shape[0]
+    if Wt.shape[1] != 9 * C:
+        raise IspError("conv3x3 weight must be [N, 9*C]")
+    out = torch.empty(B, H, W, N, device=x.device, dtype=F16)
+    stats = torch.empty(_lib.lib().isp_conv_stats_slots(N), B * H * W, 2, device=x.device, dtype=torch.float32)
+    ep = _epilogue(_lib.EP_BIAS_RELU_STATS_BF16, out, N, bias)
+    ep.out2 = stats.data_ptr()
+    check(fn(_p(x), _p(Wt), B, H, W, C, N, ctypes.byref(ep), _stream()), name)
+    return out, stats
+
+
 def conv3x3_folded_affine(x, Wt, bias_full, taps):
     """conv3x3 + ReLU whose input carries a folded per-pixel affine map: `bias_full` = conv bias +
     sum of the 9 tap constants `taps` [9,N]; border pixels drop the taps outside the image."""

@@ -662,3 +662,23 @@ def test_lnfold_gemm_with_output_layernorm(ops, M, N):
     print(f"lnfold+layernorm M={M} N={N}: max err {err:.3g} (two-kernel route {(two.float() - ref).abs().max().item():.3g}; ref max {ref.abs().max().item():.3g})")
     assert y.shape == (M, N) and torch.isfinite(y.float()).all()
     assert err < 2e-2
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 40, 56, 64, 448), (1, 33, 17, 128, 448), (1, 16, 16, 64, 384), (1, 21, 50, 64, 128)])
+def test_conv3x3_relu_with_row_statistics(ops, B, H, W, C, N):
+    """csrc/gemm.hip, EpBiasActStats: the half-precision 3x3 conv + ReLU whose epilogue also emits per-pixel partial sums of
+    the values it stores (LoftUp's second convolution -> the LN-folded query projection).  Output bit-identical to the plain
+    conv; the partials summed over their slots equal the row sums / sums of squares of the stored map; 128- and 192-channel
+    block kernels, interior and ragged tiles (N = 448 = 3.5 blocks of 128: the last wave column group writes zeros)."""
+    torch.manual_seed(B * H + W)
+    H16 = torch.float16
+    x = torch.randn(B, H, W, C, device="cuda").to(H16)
+    w = (torch.randn(N, 9 * C, device="cuda") / math.sqrt(9 * C)).to(H16)
+    b = torch.randn(N, device="cuda")
+    y0 = ops.conv3x3(x, w, b, "relu")
+    y, st = ops.conv3x3_relu_stats(x, w, b)
+    assert torch.equal(y, y0)
+    ys = y.float().view(-1, N)
+    assert st.shape[1:] == (B * H * W, 2) and torch.isfinite(st).all()
+    assert torch.allclose(st.sum(0)[:, 0], ys.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(st.sum(0)[:, 1], ys.pow(2).sum(1), rtol=1e-5, atol=1e-3)
