@@ -425,12 +425,19 @@ struct EpLnFold {
         return Cols{*reinterpret_cast<const float4*>(bias + n), *reinterpret_cast<const float4*>(ssum + n)};
     }
     __device__ __forceinline__ RowCtx row_begin(long m) const {
-        // the four lanes that hold a row (lane >> 4 = 0..3) share the slot loads and exchange the sums
-        float s1 = 0.f, s2 = 0.f;
-        for (int k = (int)(__lane_id() >> 4); k < slots; k += 4) {
-            const float2 p = *reinterpret_cast<const float2*>(stats + ((size_t)k * M + m) * 2);
-            s1 += p.x, s2 += p.y;
-        }
+        return row_finish(row_partial(m));
+    }
+    // The four lanes that hold a row (lane >> 4 = 0..3) share the slot loads (slots <= 8: at most two each, no loop, so a
+    // caller can issue the loads of all its rows before it needs the first result) and exchange the sums.
+    __device__ __forceinline__ float2 row_partial(long m) const {
+        const int k = (int)(__lane_id() >> 4);
+        float2 a = make_float2(0.f, 0.f), b = a;
+        if (k < slots) a = *reinterpret_cast<const float2*>(stats + ((size_t)k * M + m) * 2);
+        if (k + 4 < slots) b = *reinterpret_cast<const float2*>(stats + ((size_t)(k + 4) * M + m) * 2);
+        return make_float2(a.x + b.x, a.y + b.y);
+    }
+    __device__ __forceinline__ RowCtx row_finish(float2 p) const {
+        float s1 = p.x, s2 = p.y;
         s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
         s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
         const float mean = s1 * inv_d;
@@ -476,12 +483,19 @@ struct EpLnFoldLayerNorm {
                     *reinterpret_cast<const float4*>(g2 + n), *reinterpret_cast<const float4*>(b2 + n)};
     }
     __device__ __forceinline__ RowCtx row_begin(long m) const {
-        // the four lanes that hold a row (lane >> 4 = 0..3) share the slot loads and exchange the sums
-        float s1 = 0.f, s2 = 0.f;
-        for (int k = (int)(__lane_id() >> 4); k < slots; k += 4) {
-            const float2 p = *reinterpret_cast<const float2*>(stats + ((size_t)k * M + m) * 2);
-            s1 += p.x, s2 += p.y;
-        }
+        return row_finish(row_partial(m));
+    }
+    // The four lanes that hold a row (lane >> 4 = 0..3) share the slot loads (slots <= 8: at most two each, no loop, so a
+    // caller can issue the loads of all its rows before it needs the first result) and exchange the sums.
+    __device__ __forceinline__ float2 row_partial(long m) const {
+        const int k = (int)(__lane_id() >> 4);
+        float2 a = make_float2(0.f, 0.f), b = a;
+        if (k < slots) a = *reinterpret_cast<const float2*>(stats + ((size_t)k * M + m) * 2);
+        if (k + 4 < slots) b = *reinterpret_cast<const float2*>(stats + ((size_t)(k + 4) * M + m) * 2);
+        return make_float2(a.x + b.x, a.y + b.y);
+    }
+    __device__ __forceinline__ RowCtx row_finish(float2 p) const {
+        float s1 = p.x, s2 = p.y;
         s1 += __shfl_xor(s1, 16), s2 += __shfl_xor(s2, 16);
         s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
         const float mean = s1 * inv_d;
@@ -512,12 +526,18 @@ __device__ __forceinline__ void row_layernorm_epilogue(const EP& ep, f32x4 (&acc
         ncol[ni] = n_base + ni * 16 + fq * 4;
         cc[ni] = ep.cols(ncol[ni] < N ? ncol[ni] : N - 4);
     }
+    float2 part[TM];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const long m = row_of(wm * (TM * 16) + mi * 16 + fr);
+        part[mi] = ep.row_partial(m >= 0 ? m : 0);
+    }
     __builtin_amdgcn_s_barrier();  // every wave is done reading the operand ring
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int rl = wm * (TM * 16) + mi * 16 + fr;
         const long m = row_of(rl);
-        const auto ctx = ep.row_begin(m >= 0 ? m : 0);
+        const auto ctx = ep.row_finish(part[mi]);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
@@ -774,12 +794,20 @@ __device__ __forceinline__ void staged_epilogue(const EP& ep, f32x4 (&acc)[TM][T
     typename EP::Cols cc[TN];
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) cc[ni] = ep.cols(n_base + ni * 16 + fq * 4);
+    [[maybe_unused]] float2 part[TM];
+    if constexpr (requires { ep.row_partial(0L); }) {  // all rows' statistics loads in flight before the first is needed
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) part[mi] = ep.row_partial(row_in(row_base + mi * 16 + fr));
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         [[maybe_unused]] const long m = row_in(row_base + mi * 16 + fr);
         auto put = [&](int ni, const uint2& o) { *reinterpret_cast<uint2*>(stg + (mi * 16 + fr) * SP + ni * 32 + fq * 8) = o; };
         if constexpr (requires { ep.row_begin(m); }) {
-            const auto ctx = ep.row_begin(m);
+            const auto ctx = [&] {
+                if constexpr (requires { ep.row_partial(0L); }) return ep.row_finish(part[mi]);
+                else return ep.row_begin(m);
+            }();
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
                 const float v[4] = {acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]};
@@ -1650,7 +1678,7 @@ extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int
                 return launch_gemm<CFG, true>(al, Wt, M, N, K, EpResidualStats{(float*)e->out, e->bias, e->gamma, ldo, (unsigned short*)e->out3, (float*)e->out2, M}, s);
             case ISP_EP_LNFOLD_BF16:
             case ISP_EP_LNFOLD_GELU_BF16: {
-                if (!e->bias || !e->gamma || !e->res || e->tokens_per_image <= 0 || e->img_h <= 0) return (int)ISP_ERR_INVALID;
+                if (!e->bias || !e->gamma || !e->res || e->tokens_per_image <= 0 || e->img_h <= 0 || e->img_h > 8) return (int)ISP_ERR_INVALID;  // (<= 8 statistics slots)
                 const float inv_d = 1.0f / (float)e->tokens_per_image;
                 if (e->kind == ISP_EP_LNFOLD_BF16)
                     return launch_gemm<CFG, true>(al, Wt, M, N, K,
@@ -1663,7 +1691,7 @@ extern "C" int isp_gemm_f16(const void* A, long lda, const void* Wt, long M, int
         }
     };
     if (e->kind == ISP_EP_LNFOLD_LAYERNORM_BF16) {  // one tile spans the output row: smallest configuration with N <= BN
-        if (!e->bias || !e->gamma || !e->res || !e->pos || !e->out2 || e->tokens_per_image <= 0 || e->img_h <= 0 || N > CfgWide512::BN)
+        if (!e->bias || !e->gamma || !e->res || !e->pos || !e->out2 || e->tokens_per_image <= 0 || e->img_h <= 0 || e->img_h > 8 || N > CfgWide512::BN)
             return ISP_ERR_INVALID;
         auto go = [&](auto cfg) {
             using CFG = decltype(cfg);
