@@ -565,6 +565,8 @@ ISP_ATT64_KERNEL(attention64_kernel_bf16, true, false, 64, 4)
 ISP_ATT64_KERNEL(attention64_kernel_f16, true, true, 64, 4)
 ISP_ATT64_KERNEL(attention128_kernel_bf16, true, false, 128, 8)
 ISP_ATT64_KERNEL(attention128_kernel_f16, true, true, 128, 8)
+ISP_ATT64_KERNEL(attention128_kernel_bf16_w4, true, false, 128, 4)  // (128-query blocks, two per CU: the default)
+ISP_ATT64_KERNEL(attention128_kernel_f16_w4, true, true, 128, 4)
 #undef ISP_ATT64_KERNEL
 
 constexpr int kAtt64Lds = Geo<64>::LDS;  // (K + V) x 2 buffers
@@ -577,8 +579,9 @@ int launch_attention64(const void* Q, const void* K, const void* V, void* O, int
     void (*kern)(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, long, long, long, long, long, long, long, long, long,
                  float, float*, long, int, int);
     if constexpr (HD == 128) {
-        static_assert(PRESCALED && NW == 8, "head_dim 128: base-2-logit queries, 8 waves");
-        kern = F16 ? attention128_kernel_f16 : attention128_kernel_bf16;
+        static_assert(PRESCALED && (NW == 8 || NW == 4), "head_dim 128: base-2-logit queries, 8 or 4 waves");
+        if constexpr (NW == 8) kern = F16 ? attention128_kernel_f16 : attention128_kernel_bf16;
+        else kern = F16 ? attention128_kernel_f16_w4 : attention128_kernel_bf16_w4;
     } else {
         static_assert(HD == 64 && NW == 4 && (PRESCALED || !F16));
         kern = !PRESCALED ? attention64_kernel_scale_bf16 : (F16 ? attention64_kernel_f16 : attention64_kernel_bf16);
@@ -667,6 +670,12 @@ static int attention_fwd_impl(const void* Q, const void* K, const void* V, void*
     }
     if (head_dim == 128) {
         // 256-query blocks once they still fill the chip several times over
+        // 128-query workgroups, two per CU (independent barriers), measured 2 % ahead of one 256-query workgroup per CU although
+        // K / V are then streamed twice as often (3.88 vs 3.97 ms per LoftUp launch); ISEGPROBE_ATT128_NW=8: the 8-wave form
+        static const bool w4 = [] { const char* e = getenv("ISEGPROBE_ATT128_NW"); return !(e && e[0] == '8'); }();
+        if (w4 && logit2 && !lse && (long)((Lq + 255) / 256) * B * H >= 2048 && dm128_ok(Lk, kv_stride_l))
+            return launch_attention64<true, false, 128, 4>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                                                           kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, s);
         if (logit2 && !lse && (long)((Lq + 255) / 256) * B * H >= 2048 && dm128_ok(Lk, kv_stride_l))
             return launch_attention64<true, false, 128, 8>(Q, K, V, O, B, H, Lq, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
                                                            kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, s);
@@ -754,6 +763,12 @@ extern "C" int isp_attention_fwd_logit2_f16(const void* Q, const void* K, const 
 #define ISP_ATT_F16G(HD, NW)                                                                                                     \
     launch_attention<HD, NW, true>(q2, K, V, o2, B, H, lq2, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b, kv_stride_l, \
                                    kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 0.6931471805599453f, nullptr, 0, hs)
+        // 128-query workgroups, two per CU (independent barriers), measured 2 % ahead of one 256-query workgroup per CU although
+        // K / V are then streamed twice as often (3.88 vs 3.97 ms per LoftUp launch); ISEGPROBE_ATT128_NW=8: the 8-wave form
+        static const bool w4 = [] { const char* e = getenv("ISEGPROBE_ATT128_NW"); return !(e && e[0] == '8'); }();
+        if (w4 && head_dim == 128 && wide && dm128_ok(Lk, kv_stride_l))
+            return launch_attention64<true, true, 128, 4>(q2, K, V, o2, B, H, lq2, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
+                                                          kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, hs);
         if (head_dim == 128 && wide && dm128_ok(Lk, kv_stride_l))  // deferred-maximum kernel, 8 waves (see attention64_kernel)
             return launch_attention64<true, true, 128, 8>(q2, K, V, o2, B, H, lq2, Lk, q_stride_b, q_stride_l, q_stride_h, kv_stride_b,
                                                           kv_stride_l, kv_stride_h, o_stride_b, o_stride_l, o_stride_h, 1.f, nullptr, 0, hs);
