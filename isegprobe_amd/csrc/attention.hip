@@ -291,7 +291,7 @@ int launch_attention(const void* Q, const void* K, const void* V, void* O, int B
 #define ISP_ATT_THR 6.0f
 #endif
 #ifndef ISP_ATT_ONES
-#define ISP_ATT_ONES 1
+#define ISP_ATT_ONES (-1)  // -1: by head_dim (see attention64_body)
 #endif
 
 __device__ __forceinline__ float xhalf_max(float x) {  // max(x of lane, x of lane ^ 32)
@@ -395,22 +395,20 @@ __device__ __forceinline__ void attention64_body(const bf16_t* __restrict__ Q, c
                     v_off[db][kb][s][jj] = G::TILE + key * G::ROW + G::vswz(key, col >> 3) * 16 + (col & 7) * 2;
                 }
 
+    // row sums: a ones-row MFMA per key sub-block at head_dim 64 (one of 9 MFMAs, off the vector pipe), vector adds at
+    // head_dim 128 (the 4 extra MFMAs per tile were 2.5 % of the launch there; -DISP_ATT_ONES=0 / 1 forces either)
+    constexpr bool ONES = ISP_ATT_ONES < 0 ? HD == 64 : ISP_ATT_ONES != 0;
     f32x16 o[DB], negm;
-#if ISP_ATT_ONES
-    f32x16 lacc;
+    [[maybe_unused]] f32x16 lacc;
     constexpr short kOne = F16 ? 0x3c00 : 0x3f80;  // 1.0 in half / bf16
-    const bf16x8 ones = {kOne, kOne, kOne, kOne, kOne, kOne, kOne, kOne};
-#else
-    float l_run = 0.f;
-#endif
+    [[maybe_unused]] const bf16x8 ones = {kOne, kOne, kOne, kOne, kOne, kOne, kOne, kOne};
+    [[maybe_unused]] float l_run = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) o[db][i] = 0.f;
         negm[i] = 0.f;
-#if ISP_ATT_ONES
-        lacc[i] = 0.f;
-#endif
+        if constexpr (ONES) lacc[i] = 0.f;
     }
     float m_run = 0.f;
 
@@ -436,19 +434,13 @@ __device__ __forceinline__ void attention64_body(const bf16_t* __restrict__ Q, c
     };
     // P = exp2(S') in place, then O^T += V^T P^T (and l += 1^T P^T) for one key block
     auto exp_pv = [&](f32x16& s, const char* buf, int kb) {
-#if !ISP_ATT_ONES
         float psum = 0.f;
-#endif
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             s[i] = __builtin_amdgcn_exp2f(PRESCALED ? s[i] : s[i] * c);
-#if !ISP_ATT_ONES
-            psum += s[i];
-#endif
+            if constexpr (!ONES) psum += s[i];
         }
-#if !ISP_ATT_ONES
-        l_run += psum;
-#endif
+        if constexpr (!ONES) l_run += psum;
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             bf16x8 pf;
@@ -464,9 +456,7 @@ __device__ __forceinline__ void attention64_body(const bf16_t* __restrict__ Q, c
                 const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 o[db] = att_mfma<F16>(vf, pf, o[db]);
             }
-#if ISP_ATT_ONES
-            lacc = att_mfma<F16>(ones, pf, lacc);
-#endif
+            if constexpr (ONES) lacc = att_mfma<F16>(ones, pf, lacc);
         }
     };
     // move the reference maximum by d (per row; the same in both halves of a row) before the tile's exponentials
@@ -478,14 +468,10 @@ __device__ __forceinline__ void attention64_body(const bf16_t* __restrict__ Q, c
             s0[i] -= d, s1[i] -= d;
 #pragma unroll
             for (int db = 0; db < DB; ++db) o[db][i] *= alpha;
-#if ISP_ATT_ONES
-            lacc[i] *= alpha;
-#endif
+            if constexpr (ONES) lacc[i] *= alpha;
             negm[i] = -m_run;
         }
-#if !ISP_ATT_ONES
-        l_run *= alpha;
-#endif
+        if constexpr (!ONES) l_run *= alpha;
     };
 
     const int nt = (Lk + KB - 1) / KB;
@@ -528,11 +514,9 @@ __device__ __forceinline__ void attention64_body(const bf16_t* __restrict__ Q, c
     if (!active) return;
 
     // ---- epilogue: O[b, q, h, d] = o / l
-#if ISP_ATT_ONES
-    const float l_tot = lacc[0];
-#else
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-#endif
+    float l_tot;
+    if constexpr (ONES) l_tot = lacc[0];
+    else l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     if (lse && hh == 0 && qrow < Lq) lse[(size_t)bh * lse_ld + qrow] = m_run * c + log2f(l_tot);
     if (qrow < Lq) {
