@@ -682,3 +682,21 @@ def test_conv3x3_relu_with_row_statistics(ops, B, H, W, C, N):
     assert st.shape[1:] == (B * H * W, 2) and torch.isfinite(st).all()
     assert torch.allclose(st.sum(0)[:, 0], ys.sum(1), rtol=1e-5, atol=1e-3)
     assert torch.allclose(st.sum(0)[:, 1], ys.pow(2).sum(1), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,H,W,p,chans,Kpad", [(2, 56, 84, 14, (3, 1, 2), 1216), (1, 448, 448, 14, (3, 0, 2), 1024), (2, 48, 32, 16, (3, 1, 0), 1024),
+                                                (1, 28, 42, 14, (0, 1, 2), 640), (1, 15, 10, 5, (3, 1, 2), 152)])
+def test_patchify_matrix(ops, B, H, W, p, chans, Kpad):
+    """isp_patchify_fwd: row t of sample b = [img | prev | click maps] patches flattened (c, i, j) as a Conv2d weight is, bf16,
+    zero padded to Kpad -- both kernels (a token row per block through LDS; the per-token gather for shapes it does not take:
+    p * p % 4 != 0) against torch unfold, bit for bit."""
+    torch.manual_seed(H + W)
+    n_img, n_prev, n_maps = chans
+    mk = lambda n: torch.randn(B, n, H, W, device="cuda") if n else None
+    img, prev, maps = mk(n_img), mk(n_prev), mk(n_maps)
+    A = ops.patchify(img, prev, maps, p, Kpad)
+    x = torch.cat([t for t in (img, prev, maps) if t is not None], 1)
+    ref = torch.nn.functional.unfold(x, kernel_size=p, stride=p).transpose(1, 2).reshape(B * (H // p) * (W // p), -1)  # [tokens, C*p*p], (c, i, j) order
+    assert A.shape == (B * (H // p) * (W // p), Kpad) and A.dtype == torch.bfloat16
+    assert torch.equal(A[:, :ref.shape[1]], ref.to(torch.bfloat16))
+    assert torch.equal(A[:, ref.shape[1]:], torch.zeros_like(A[:, ref.shape[1]:]))

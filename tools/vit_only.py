@@ -2,9 +2,11 @@
 """DINOv2 featurizer alone (B images at S^2, clicks fused into the patch matrix): HIP-event time per forward.
 usage: vit_only.py [B] [S] [arch] [iters]   -- run under rocprofv3 --kernel-trace --stats for the per-kernel split."""
 import logging
+import os
 import sys
 import torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, "tests"))
 logging.getLogger("root").setLevel(logging.WARNING)
 import bench
 
