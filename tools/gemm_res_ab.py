@@ -35,3 +35,8 @@ for K in (384, 1536):
     wv = (torch.randn(384, K, device="cuda") / math.sqrt(K)).to(H)
     g = torch.rand(384, device="cuda")
     print(f"vit residual fp32 stream M={Mv} K={K} N=384: {timeit(lambda: ops.linear_residual_(x, av, wv, b[:384].contiguous(), g), 50):8.1f} us")
+af = torch.randn(Mv, 384, device="cuda", dtype=H)
+wf = (torch.randn(1536, 384, device="cuda") / math.sqrt(384)).to(H)
+bf = torch.randn(1536, device="cuda")
+print(f"vit fc1 + GELU (half)    M={Mv} K=384 N=1536: {timeit(lambda: ops.linear(af, wf, bf, 'gelu'), 50):8.1f} us")
+print(f"vit fc1 bias only (half) M={Mv} K=384 N=1536: {timeit(lambda: ops.linear(af, wf, bf), 50):8.1f} us")
