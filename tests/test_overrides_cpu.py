@@ -26,3 +26,13 @@ def test_unknown_key_needs_plus():
     ov, _ = split_overrides(["+no_such_key=1", "++a.b.c=x"])
     cfg = apply_overrides(EVAL_DEFAULTS, ov)
     assert cfg["no_such_key"] == 1 and cfg["a"]["b"]["c"] == "x"
+
+
+def test_eval_config_keys_of_the_click_budget():
+    """configs/eval_cfg.yaml keys evaluate.py honours beyond the README's: clicks_limit (-1 = n_clicks -> predictor
+    net_clicks_limit, inference/utils.py:286-289), min_n_clicks and iou_analysis (both decide whether every click runs,
+    inference/utils.py:254-257)."""
+    ov, rest = split_overrides(["clicks_limit=-1", "min_n_clicks=2", "iou_analysis=true", "n_clicks=8"])
+    cfg = apply_overrides(EVAL_DEFAULTS, ov)
+    assert cfg["clicks_limit"] == -1 and cfg["min_n_clicks"] == 2 and cfg["iou_analysis"] is True and cfg["n_clicks"] == 8 and not rest
+    assert EVAL_DEFAULTS["clicks_limit"] is None and EVAL_DEFAULTS["min_n_clicks"] == 1 and EVAL_DEFAULTS["iou_analysis"] is False
