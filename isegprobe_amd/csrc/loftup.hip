@@ -95,10 +95,12 @@ __global__ __launch_bounds__(256) void loftup_fourier_cn_kernel(const float* __r
         float val = 0.f;
         if (ch < nsc) {
             const int f = ch / 5, m = ch - f * 5;
-            val = sinf(f5[m] * freqs[f] + bias_sin[ch]);
+            // (product and sum rounded separately, as the reference's `feats * freqs` then `+ biases` are: at freq = e^10 one
+            // ulp of the product is 2e-3 rad, so a fused multiply-add would move these phases by up to 1e-3)
+            val = sinf(__fadd_rn(__fmul_rn(f5[m], freqs[f]), bias_sin[ch]));
         } else if (ch < 2 * nsc) {
             const int k = ch - nsc, f = k / 5, m = k - f * 5;
-            val = cosf(f5[m] * freqs[f] + bias_cos[k]);
+            val = cosf(__fadd_rn(__fmul_rn(f5[m], freqs[f]), bias_cos[k]));
         } else if (ch < nfeat) {
             val = raw[ch - 2 * nsc];
         }
