@@ -290,6 +290,33 @@ def size896_block(arch, upsampler, B=8, S=896, warm=2, iters=5):
             "peak_mem_GiB": mem}
 
 
+def cfg3_block(S=896, warm=2, iters=5):
+    """BASELINE configs[3]: "ViT-L/14 + LiFT, 896x896 high-res click loop": one click of the loop = the image and its mirrored
+    copy (batch 2, predictor flip TTA) through DINOv2-L/14 + LiFT(1024) + ConvSegHead(1024,2,1), forward only."""
+    arch = "dinov2_vitl14"
+    vit = VITS[arch]
+    model = build("lift", S, arch).cuda()
+    image, points = synthetic_batch(2, S, seed=3896)
+    image, points = image.cuda(), points.cuda()
+    with torch.no_grad():
+        for _ in range(warm):
+            model(image, points)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = model(image, points)["instances"]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert out.shape == (2, 1, S, S) and torch.isfinite(out).all()
+    D, L, hw = vit["embed_dim"], vit["depth"], (S // 14) ** 2
+    mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    del model, out
+    torch.cuda.empty_cache()
+    return {"workload": f"{arch} + lift + ConvSegHead({D},2,1), {S}x{S}, batch 2 (image + mirrored copy = one click), forward-only",
+            "ms_per_click": dt / iters * 1e3, "clicks_per_sec": iters / dt, "vit_flops_per_click": 2 * vit_flops(D, L, hw),
+            "steps": iters, "warmup": warm, "peak_mem_GiB": mem}
+
+
 # ---------------------------------------------------------------------------------------------- CPU baseline (oracle)
 def cpu_baseline(model_sd, size, upsampler, vit, seed, full=False):
     """The CPU oracle (kind "port": torch-CPU restatement of the reference path, pinned by the golden fixtures) on
@@ -560,7 +587,8 @@ def run_forward(args):
             # the other numbers north_star names, measured in the same run (never `value`)
             del out
             torch.cuda.empty_cache()
-            for key, fn in (("loftup448", lambda: loftup448_block()), ("size896", lambda: size896_block(args.arch, args.upsampler))):
+            for key, fn in (("loftup448", lambda: loftup448_block()), ("size896", lambda: size896_block(args.arch, args.upsampler)),
+                            ("cfg3_vitl14_lift896", lambda: cfg3_block())):
                 try:
                     line[key] = fn()
                 except Exception as exc:
@@ -669,7 +697,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="batch-8 CPU baseline as the median of 3 runs (slow)")
     ap.add_argument("--no-stages", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the loftup448 / size896 blocks (north_star's other named numbers)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the loftup448 / size896 / cfg3_vitl14_lift896 blocks (north_star's other named numbers, BASELINE configs[3])")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region (bf16 head convolutions, alt_head_bf16)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
