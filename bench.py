@@ -295,6 +295,7 @@ def cfg3_block(S=896, warm=2, iters=5):
     copy (batch 2, predictor flip TTA) through DINOv2-L/14 + LiFT(1024) + ConvSegHead(1024,2,1), forward only."""
     arch = "dinov2_vitl14"
     vit = VITS[arch]
+    torch.cuda.reset_peak_memory_stats()
     model = build("lift", S, arch).cuda()
     image, points = synthetic_batch(2, S, seed=3896)
     image, points = image.cuda(), points.cuda()
@@ -315,6 +316,33 @@ def cfg3_block(S=896, warm=2, iters=5):
     return {"workload": f"{arch} + lift + ConvSegHead({D},2,1), {S}x{S}, batch 2 (image + mirrored copy = one click), forward-only",
             "ms_per_click": dt / iters * 1e3, "clicks_per_sec": iters / dt, "vit_flops_per_click": 2 * vit_flops(D, L, hw),
             "steps": iters, "warmup": warm, "peak_mem_GiB": mem}
+
+
+def train_block(arch, upsampler, B, S, sim_clicks=2, warm=2, iters=5):
+    """BASELINE configs[2] / [4] on this GPU's share: the SBD-shaped train step (clicks before the backbone, `sim_clicks` no-grad
+    simulated-click forwards, train-mode forward, HIP backward, flat-bucket all-reduce -- a no-op in one process -- and Adam).
+    `python bench.py --mode train` is the data-parallel measurement; this block only puts the single-GPU number into the line."""
+    from isegprobe_amd.core.training.trainer import DataParallelTrainer
+    torch.manual_seed(0)
+    torch.cuda.reset_peak_memory_stats()
+    model = build(upsampler, S, arch).cuda()
+    trainer = DataParallelTrainer(model, lr=5e-5)
+    batch = synthetic_train_batch(B, S, seed=2000)
+    for _ in range(warm):
+        trainer.step(batch, num_iters=sim_clicks)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        loss = trainer.step(batch, num_iters=sim_clicks)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(loss)
+    mem, nbytes = torch.cuda.max_memory_allocated() / 2 ** 30, trainer.bucket.nbytes()
+    del trainer, model, batch
+    torch.cuda.empty_cache()
+    return {"workload": f"{arch} + {upsampler} + ConvSegHead, {S}x{S} crops, batch {B}, clicks before the backbone, {sim_clicks} simulated "
+                        "corrective clicks per step, one GPU (no collective)", "ms_per_step": dt / iters * 1e3,
+            "images_per_sec": B * iters / dt, "gradient_bucket_bytes": nbytes, "steps": iters, "warmup": warm, "peak_mem_GiB": mem}
 
 
 # ---------------------------------------------------------------------------------------------- CPU baseline (oracle)
@@ -588,7 +616,8 @@ def run_forward(args):
             del out
             torch.cuda.empty_cache()
             for key, fn in (("loftup448", lambda: loftup448_block()), ("size896", lambda: size896_block(args.arch, args.upsampler)),
-                            ("cfg3_vitl14_lift896", lambda: cfg3_block())):
+                            ("cfg3_vitl14_lift896", lambda: cfg3_block()),
+                            ("cfg2_train_vits14_loftup224", lambda: train_block("dinov2_vits14", "loftup", 8, 224))):
                 try:
                     line[key] = fn()
                 except Exception as exc:
