@@ -84,3 +84,4 @@ def test_eval_mode_zoom_in_params():
     assert get_zoom_in_params("cvpr", "DAVIS") == {"skip_clicks": -1, "target_size": (672, 672)}
     with pytest.raises(NotImplementedError):
         get_zoom_in_params("original")
+
