@@ -84,8 +84,8 @@ int isp_patchify_fwd(const float* image, const float* prev_mask, const float* cl
 #define ISP_EP_LNFOLD_BF16 15      /* isp_gemm_f16: out = rstd[m] * (v - mean[m] * gamma[n]) + bias[n]: a LayerNorm over the first
                                     * tokens_per_image (= D) columns of A folded into this GEMM (weights carry the LayerNorm gain, gamma[n]
                                     * = their row sums, bias = c + W b); row statistics from res = the producer's partial sums
-                                    * [img_h slots][M][2], alpha = the LayerNorm epsilon (loftup/layers.py:186-228, 53-58) */
-#define ISP_EP_LNFOLD_GELU_BF16 16 /* the same followed by gelu_erf (FeedForward's first layer) */
+                                    * [img_h slots][M][2] (img_h <= 8), alpha = the LayerNorm epsilon (loftup/layers.py:186-228, 53-58) */
+#define ISP_EP_LNFOLD_GELU_BF16 16 /* the same followed by GELU (erf form; its sigmoid fit, max |error| 2.5e-5, on half outputs): FeedForward's first layer */
 
 #define ISP_EP_RESIDUAL_STATS_F32 17 /* isp_gemm_f16: ISP_EP_RESIDUAL_F32 that also writes out3 = IEEE-half copy of the updated rows (row stride
                                       * ldo) and out2 = their per-row partial sums f32 [isp_gemm_f16_stats_slots(M, N)][M][2]: the ViT block's
