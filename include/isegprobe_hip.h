@@ -141,6 +141,19 @@ int isp_conv3x3_nhwc_f16(const void* in, const void* Wt, int B, int H, int W, in
                          void* stream);
 
 int isp_conv3x3_partial_slots(int N);
+
+/* ---- First head convolution taken through the bilinear resize: relu(conv3x3(F.interpolate(x, (H, W), bilinear,
+ * align_corners=True)) + bias) without the [B,H,W,C] map -- iseg_probe_model.py:120-129 (or the bilinear upsampler plugin,
+ * basic_upsamplers.py:28-33) followed by heads/conv_heads.py:59-73.  The convolution is linear in the resized map, so
+ *   out[p][n] = act(bias[n] + sum_t [p+t inside] sum_{q in 2x2(p+t)} a(p+t, q) Z[q][t*N + n]),   Z = x [B*h*w, C] x [W_0..W_8]^T
+ * with Z ONE low-resolution GEMM (isp_gemm_f16 / isp_gemm_bf16 against Wz[t*N + n][c] = conv.weight[n][c][ty][tx]) and this
+ * entry the blend: 36 multiply-adds per output value instead of 9*C.  z [B*h*w, 9*N] IEEE half (N % 64 == 0) or f32 (N % 32 == 0;
+ * the fp32-accurate checking mode), bias f32 [N] or NULL, out [B,H,W,N] half / bf16 / f32 (f32 only for f32 z).
+ * isp_conv3x3_of_bilinear_supported: 1 when every 16 x 16 output tile's tap neighbourhood touches at most 5 x 5 source pixels
+ * (up-scaling by about 5.7 or more); otherwise callers materialise the resized map and use isp_conv3x3_nhwc_*. */
+int isp_conv3x3_of_bilinear_supported(int h, int w, int H, int W, int N, int z_dtype);
+int isp_conv3x3_of_bilinear_blend(const void* z, int z_dtype, const float* bias, void* out, int out_dtype, int B, int h, int w,
+                                  int H, int W, int N, int relu, void* stream);
 int isp_sum_partials_f32(const float* partial, float* out, long M, int slots, float bias, void* stream);
 
 /* ---- LayerNorm over the last dim (fp32 statistics), nn.LayerNorm(eps) of DINOv2.py:98 and

@@ -17,6 +17,7 @@ from .base_head import BaseClassifierHead
 
 
 HEAD_F16 = os.environ.get("ISEGPROBE_HEAD_F16", "1") != "0"  # f16 operands for the inference convolutions (see forward)
+CONV_OF_BILINEAR = os.environ.get("ISEGPROBE_CONV_OF_BILINEAR", "1") != "0"  # first conv through the bilinear resize (forward_of_bilinear)
 HEAD_W_BITS = int(os.environ.get("ISEGPROBE_HEAD_W_BITS", "8"))  # significant bits kept in the half-format weights (8..11)
 if not 8 <= HEAD_W_BITS <= 11:
     raise ValueError(f"ISEGPROBE_HEAD_W_BITS={HEAD_W_BITS}: the half-format head weights keep 8 (bf16-valued) to 11 (full half) bits")
@@ -155,6 +156,46 @@ class _StackedHead(BaseClassifierHead):
         wfold, bias_full, taps = cache.get((first.conv.weight, first.conv.bias, Wf, bf), build)
         y = ops.conv3x3_folded_affine(x, wfold, bias_full, taps)
         return self._tail(y, list(self.convs)[1:])
+
+
+    def of_bilinear_geometry(self, C, h, w, H, W):
+        """Whether ``forward_of_bilinear`` has a kernel for a [*, C, h, w] map resized to H x W: 3x3 first layer, channel
+        blocks of 64, up-scaling by ~5.7 or more (``ISEGPROBE_CONV_OF_BILINEAR=0`` switches the route off)."""
+        if not CONV_OF_BILINEAR or self.kernel_size != 3 or self.num_layers < 1:
+            return False
+        conv = self.convs[0].conv
+        return (C == conv.in_channels and C % 64 == 0 and (h, w) != (H, W)
+                and ops.conv3x3_of_bilinear_supported(h, w, H, W, conv.out_channels))
+
+    def of_bilinear_applies(self, x, H, W):
+        """... and the call is an inference call on a GPU tensor."""
+        if grad_mode(self) or (torch.is_grad_enabled() and x.requires_grad) or not x.is_cuda:
+            return False
+        return self.of_bilinear_geometry(x.shape[1], x.shape[2], x.shape[3], H, W)
+
+    def forward_of_bilinear(self, x, H, W):
+        """forward(F.interpolate(x, (H, W), mode="bilinear", align_corners=True)) without the resized map
+        (iseg_probe_model.py:120-129 / basic_upsamplers.py:28-33 followed by conv_heads.py:69-73): the first convolution is
+        linear in the resized map, so it runs as Z = x [W_0 .. W_8]^T at LOW resolution (one GEMM, 9*N columns) followed by
+        the bilinear blend of the nine tap planes (csrc/conv_bilinear.hip) -- 36 multiply-adds per output value instead
+        of 9*C, and the [B,H,W,C] map is never written.  x: [B,C,h,w]-shaped NHWC view (bf16 or half)."""
+        first = self.convs[0]
+        layers = list(self.convs)[1:]
+        xl = to_nhwc_bf16(x, keep_f16=True)
+        if xl.dtype != ops.F16:
+            xl = ops.to_f16(xl)  # bf16 values are exact in half
+        B, h, w, C = xl.shape
+        N = first.conv.out_channels
+
+        def build():
+            wt = first.conv.weight.detach().float()  # [N, C, 3, 3] -> rows t*N + n
+            return (wt.permute(2, 3, 0, 1).reshape(9 * N, C).to(ops.F16).contiguous(), first.conv.bias.detach().float().contiguous())
+        cache = self.__dict__.setdefault("_of_bilinear_packed", PackedCache())
+        wz, bias = cache.get((first.conv.weight, first.conv.bias), build)
+        z = ops.linear(xl.view(B * h * w, C), wz)
+        half_next = HEAD_F16 and self.num_classes == 1 and layers and all(l.takes_f16() for l in layers)
+        y = ops.conv3x3_of_bilinear_blend(z, bias, B, h, w, H, W, N, relu=True, out_dtype=ops.F16 if half_next else BF16)
+        return self._tail(y, layers)
 
 
 class SimpleConvSegHead(_StackedHead):

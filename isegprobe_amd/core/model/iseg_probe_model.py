@@ -77,9 +77,13 @@ class iSegProbeModel(iSegBaseModel):
             records = self._jbu_records_side_stream(image)
             # FeatUp JBU and LoftUp (inference) work in IEEE half from their first kernel on: the trunk's final LayerNorm
             # writes half for them (one bf16 rounding less between the trunk and the upsampler)
-            from .upsamplers import LoftUpUpsampler
+            from .upsamplers import BilinearUpsampler, LoftUpUpsampler
             half_out = (self.architecture == "backbone_upsampler_head"
                         and isinstance(self.upsampler, (JBUFeatUpUpsampler, LoftUpUpsampler)) and not self.upsampler.training)
+            # ... and so does the head's first convolution when it runs through the bilinear plugin's resize
+            half_out = half_out or (self.architecture == "backbone_upsampler_head" and isinstance(self.upsampler, BilinearUpsampler)
+                                    and self._head_through_resize(image, image.shape[2] // self.backbone.patch_size,
+                                                                  image.shape[3] // self.backbone.patch_size))
             feats = self.backbone.forward_fused_clicks(image, prev_mask, maps, self.embed_coords, out_f16=half_out)
             return self._after_backbone(image, feats, records)
         return super()._forward_prepared(image, prev_mask, points)
@@ -142,12 +146,35 @@ class iSegProbeModel(iSegBaseModel):
                     hr = nchw_view(ops.resize_nhwc(to_nhwc_bf16(hr), image.shape[2], image.shape[3], "bilinear"))
                 Wf, bf, alpha = self.upsampler.upsampler.fixup_affine()
                 return {"instances": self.head.forward_folded_affine(hr, Wf, bf, alpha), "instances_aux": None}
+            from .upsamplers import BilinearUpsampler
+            if isinstance(self.upsampler, BilinearUpsampler) and self._head_through_resize(image, *backbone_features.shape[2:], backbone_features):
+                # the plugin IS a bilinear(align_corners=True) resize to the guidance size (basic_upsamplers.py:28-33): the head's
+                # first convolution is taken through it (heads/conv_heads.py forward_of_bilinear), the [B,H,W,C] map never exists
+                return {"instances": self.head.forward_of_bilinear(backbone_features, image.shape[2], image.shape[3]),
+                        "instances_aux": None}
             backbone_features = self.upsampler(source=backbone_features, guidance=image)
             return {"instances": self._resize_and_head(image, backbone_features), "instances_aux": None}
         backbone_features = self.neck(backbone_features, guidance=image)
         return {"instances": self.head(backbone_features), "instances_aux": None}
 
+    def _head_through_resize(self, image, h, w, feats=None):
+        """True when resize-to-image-size + head can run as ``head.forward_of_bilinear`` (inference only).  ``feats`` None:
+        the question is asked before the features exist (their channel count is the head's)."""
+        head = self.head
+        if not hasattr(head, "of_bilinear_applies") or not image.is_cuda:
+            return False
+        if feats is not None:
+            return head.of_bilinear_applies(feats, image.shape[2], image.shape[3])
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return False
+        return head.of_bilinear_geometry(head.in_channels, h, w, image.shape[2], image.shape[3])
+
     def _resize_and_head(self, image, hr_features):
+        if (self.upsampler_type != "identity" and image.size()[2:] != hr_features.size()[2:]
+                and self._head_through_resize(image, *hr_features.shape[2:], hr_features)):
+            # iseg_probe_model.py:120-129 + conv_heads.py:69-73 as one operator (LiFT's 2h x 2w map, any plugin whose output
+            # is at least ~5.7x smaller than the image)
+            return self.head.forward_of_bilinear(hr_features, image.shape[2], image.shape[3])
         if self.upsampler_type != "identity" and image.size()[2:] != hr_features.size()[2:]:
             # iseg_probe_model.py:120-129: bilinear(align_corners=True) to the image size
             x = to_nhwc_bf16(hr_features)

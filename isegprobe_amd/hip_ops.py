@@ -289,6 +289,28 @@ def conv3x3_relu_classifier(x, Wt, bias, wcls, bcls):
 _DTYPE_CODE = {torch.float32: _lib.ISP_F32, BF16: _lib.ISP_BF16, torch.float16: _lib.ISP_F16}
 
 
+def conv3x3_of_bilinear_supported(h, w, H, W, N, z_dtype=F16):
+    """Whether ``conv3x3_of_bilinear`` has a kernel for this geometry (up-scaling by ~5.7 or more, N in whole channel blocks)."""
+    return bool(_lib.lib().isp_conv3x3_of_bilinear_supported(h, w, H, W, N, _DTYPE_CODE[z_dtype]))
+
+
+def conv3x3_of_bilinear_blend(z, bias, B, h, w, H, W, N, relu=True, out_dtype=F16):
+    """Blend half of the first head conv taken through the bilinear resize (csrc/conv_bilinear.hip): z [B*h*w, 9*N] half (or
+    f32), column t*N + n = (x W_t^T)[n] -> act(conv3x3(bilinear_ac(x, (H, W))) + bias) as [B,H,W,N] in ``out_dtype``."""
+    if z.dtype not in (F16, torch.float32):
+        raise IspError("conv3x3_of_bilinear_blend: z must be IEEE half or f32")
+    _need(z, z.dtype, "z")
+    if z.shape != (B * h * w, 9 * N):
+        raise IspError(f"conv3x3_of_bilinear_blend: z must be [{B * h * w}, {9 * N}], got {tuple(z.shape)}")
+    if bias is not None:
+        _need(bias, torch.float32, "bias")
+    out = torch.empty(B, H, W, N, device=z.device, dtype=out_dtype)
+    check(_lib.lib().isp_conv3x3_of_bilinear_blend(_p(z), _DTYPE_CODE[z.dtype], _p(bias), _p(out), _DTYPE_CODE[out_dtype], B, h, w,
+                                                   H, W, N, int(relu), _stream()), "isp_conv3x3_of_bilinear_blend")
+    return out
+
+
+
 def layernorm(x, gamma, beta, eps, out_dtype=BF16, group_out=0, skip=0, rows_out=None, D=None, ld_out=None):
     """LayerNorm over the first D columns of a [rows, ld] f32/bf16/f16 tensor (D defaults to ld); the
     output (f32, bf16, or f16) has row stride ld_out (default D) with columns [D, ld_out) zero-filled."""

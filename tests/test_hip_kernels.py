@@ -700,3 +700,55 @@ def test_patchify_matrix(ops, B, H, W, p, chans, Kpad):
     assert A.shape == (B * (H // p) * (W // p), Kpad) and A.dtype == torch.bfloat16
     assert torch.equal(A[:, :ref.shape[1]], ref.to(torch.bfloat16))
     assert torch.equal(A[:, ref.shape[1]:], torch.zeros_like(A[:, ref.shape[1]:]))
+
+
+# ---- first head conv through the bilinear resize (csrc/conv_bilinear.hip)
+def _conv_of_bilinear_ref(x_nhwc, wconv, bias, H, W):
+    """iseg_probe_model.py:120-129 + conv_heads.py:59-73 in torch fp32: resize, then conv + ReLU."""
+    y = F.interpolate(x_nhwc.float().permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=True)
+    return F.relu(F.conv2d(y, wconv, bias, padding=1)).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("geom", [
+    (2, 4, 4, 56, 56, 64, 64),        # tiny fixture geometry: partial 16 x 16 tiles, every tile touches a border
+    (1, 8, 8, 56, 56, 128, 64),       # LiFT's 2h x 2w map at the tiny size (x7)
+    (2, 16, 16, 224, 224, 64, 128),   # x14.9, interior tiles
+    (1, 32, 24, 224, 168, 64, 64),    # x7.2 / x7.3, non-square
+    (1, 9, 7, 75, 61, 64, 64),        # odd sizes, ragged tiles on both axes
+])
+def test_conv3x3_of_bilinear_vs_torch(ops, geom):
+    B, h, w, H, W, C, N = geom
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, h, w, C, generator=g).cuda()
+    wconv = (torch.randn(N, C, 3, 3, generator=g) / (9 * C) ** 0.5).cuda()
+    bias = (0.2 * torch.randn(N, generator=g)).cuda()
+    assert ops.conv3x3_of_bilinear_supported(h, w, H, W, N)
+    ref = _conv_of_bilinear_ref(x, wconv, bias, H, W)
+    wz = wconv.permute(2, 3, 0, 1).reshape(9 * N, C)
+    # fp32 tap planes: the blend itself is exact fp32 arithmetic -> 1e-5 of the torch result
+    z32 = (x.view(-1, C) @ wz.t()).contiguous()
+    out32 = ops.conv3x3_of_bilinear_blend(z32, bias, B, h, w, H, W, N, relu=True, out_dtype=torch.float32)
+    assert (out32 - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    # product route: half operands, half tap planes, half output
+    xh, wh = x.half(), wz.half().contiguous()
+    refh = _conv_of_bilinear_ref(xh, wh.float().view(3, 3, N, C).permute(2, 3, 0, 1).contiguous(), bias, H, W)
+    z16 = ops.linear(xh.view(-1, C), wh)
+    assert z16.dtype == torch.float16 and z16.shape == (B * h * w, 9 * N)
+    for odt in (torch.float16, torch.bfloat16):
+        out = ops.conv3x3_of_bilinear_blend(z16, bias, B, h, w, H, W, N, relu=True, out_dtype=odt)
+        tol = (2e-3 if odt == torch.float16 else 1e-2) * max(1.0, refh.abs().max().item())
+        assert (out.float() - refh).abs().max().item() <= tol
+    # no activation, no bias
+    lin = ops.conv3x3_of_bilinear_blend(z32, None, B, h, w, H, W, N, relu=False, out_dtype=torch.float32)
+    y = F.interpolate(x.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=True)
+    assert (lin - F.conv2d(y, wconv, None, padding=1).permute(0, 2, 3, 1)).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_of_bilinear_rejects_small_factors(ops):
+    from isegprobe_amd._lib import IspError
+    assert not ops.conv3x3_of_bilinear_supported(32, 32, 64, 64, 64)      # x2: footprint of a tile exceeds 5 x 5
+    assert not ops.conv3x3_of_bilinear_supported(512, 512, 448, 448, 64)  # down-scaling (FeatUp's 512 -> 448)
+    assert not ops.conv3x3_of_bilinear_supported(4, 4, 56, 56, 48)        # channel block
+    z = torch.zeros(32 * 32, 9 * 64, device="cuda", dtype=torch.float16)
+    with pytest.raises(IspError):
+        ops.conv3x3_of_bilinear_blend(z, None, 1, 32, 32, 64, 64, 64)

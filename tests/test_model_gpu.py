@@ -584,3 +584,36 @@ def test_reference_checkpoint_logits(golden):
     assert e.max().item() < 1e-2
     decided = ref.abs() > 1e-2
     assert ((y > 0) == (ref > 0))[decided].all()
+
+
+@pytest.mark.parametrize("up", ["bilinear", "lift"])
+def test_head_through_resize_vs_materialised_route(up, monkeypatch):
+    """The head's first convolution taken through the bilinear resize (heads/conv_heads.py::forward_of_bilinear, the default
+    for the bilinear plugin and for LiFT's 2h x 2w map) against the route that writes the resized [B,H,W,C] map and convolves it
+    (ISEGPROBE_CONV_OF_BILINEAR=0): same model, same inputs, S/14 width so that the f16 192-channel conv runs on the other side."""
+    from isegprobe_amd.core.model.heads import conv_heads
+    size, B = 224, 2
+    model = build_model(up, vit=S14, img=(size, size), upsampler_params=(dict(lift_path=None, n_dim=384, patch=14) if up == "lift" else None))
+    seeded_(model, 321)
+    with torch.no_grad():
+        model.backbone.model.pos_embed.mul_(0.3)
+    model = model.cuda()
+    rng = np.random.default_rng(3)
+    torch.manual_seed(3)
+    image = torch.rand(B, 4, size, size).cuda()
+    image[:, 3] = 0
+    points = torch.from_numpy(rand_points(rng, B, 5, size, size)).cuda()
+    calls = []
+    real = conv_heads._StackedHead.forward_of_bilinear
+    monkeypatch.setattr(conv_heads._StackedHead, "forward_of_bilinear", lambda self, *a: (calls.append(1), real(self, *a))[1])
+    with torch.no_grad():
+        y_new = model(image, points)["instances"]
+        assert calls, "the through-the-resize route did not run"
+        monkeypatch.setattr(conv_heads, "CONV_OF_BILINEAR", False)
+        n = len(calls)
+        y_old = model(image, points)["instances"]
+        assert len(calls) == n
+    err = (y_new - y_old).abs()
+    # both are 16-bit routes of the same fp32 function: their difference is bounded by the sum of their errors (1e-2 each)
+    assert err.max().item() <= 1e-2, err.max().item()
+    assert err.pow(2).mean().sqrt().item() <= 2e-3
