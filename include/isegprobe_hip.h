@@ -332,6 +332,12 @@ int isp_loftup_fourier_cn_f16(const float* image, const float* minmax_c2, const 
  *   (D, HID) = (384, 1536) (DINOv2-S/14). */
 int isp_vit_mlp_fused(float* x, const void* w1, const float* b1, const void* w2p, const float* b2, long M, int D, int HID,
                       float eps, void* stream);
+/* The same over the PATCH-token rows only of a [images][rows_per_image][D] stream: rows first_row .. first_row + T - 1 of every
+ * image (DINOv2: first_row = 1, rows_per_image = T + 1; row 0 is the class token, DINOv2.py:525-528), tiled per image so that
+ * 32 x 1024 patch tokens are exactly 256 workgroups; the class-token rows take the unfused kernels.  w_dtype: ISP_BF16, or
+ * ISP_F16 for w1 / w2p (and the kernel's 16-bit operands) in IEEE half -- the trunk's default inference stream. */
+int isp_vit_mlp_fused_rows(float* x, const void* w1, const float* b1, const void* w2p, const float* b2, int images,
+                           int rows_per_image, int first_row, int T, int D, int HID, float eps, int w_dtype, void* stream);
 
 /* ---- LiFT image pyramid (LiFT.py:70-91,106-112): 3x3 / stride 2 / pad 1 conv to 32 channels (input NCHW f32 with
  * 3 channels, or NHWC bf16 with 32), weights w [32][3][3][cin] f32; relu != 0: eval-BatchNorm folded into w/bias

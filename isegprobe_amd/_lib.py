@@ -106,6 +106,7 @@ SIGNATURES = {
     "isp_loftup_fourier_cn_f16": [_vp] * 8 + [_i, _i, _i, _i, _i, _f, _vp],
     "isp_conv3x3_s2_c32": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "isp_vit_mlp_fused": [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _vp],
+    "isp_vit_mlp_fused_rows": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
     "isp_bn_train_stats": [_vp, _vp, _l, _i, _vp],
     "isp_bn_train_apply": [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _f, _vp],
     "isp_bn_train_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp],

@@ -93,6 +93,10 @@ class BasePredictor(object):
             self.original_image = self.original_image.unsqueeze(0)
         self.prev_prediction = torch.zeros_like(self.original_image[:, :1, :, :])
         self._guidance_token = object()  # new image: guidance-only upsampler work must be redone
+        for net in (self.click_models or [self.net]):
+            backbone = getattr(net, "backbone", None)
+            if hasattr(backbone, "new_image"):
+                backbone.new_image()  # activation ranges depend on the image: the half-precision trunk re-checks its range
 
     def _select_click_model(self, clicker, clicks_list):
         if self.click_models is not None:

@@ -78,13 +78,39 @@ class _Block(nn.Module):
         self.ls2 = _Gamma(dim, init_values) if init_values else nn.Identity()
 
 
-def _use_fused_mlp(rows):
-    """ISEGPROBE_FUSED_MLP=1 routes the MLP branch of every block through the token-stationary fused kernel
-    (csrc/vit_fused.hip).  Off by default: measured at 32 768 rows it takes 133-135 us against 142-150 us for
-    LayerNorm + fc1 + fc2, but one workgroup owns 128 rows and streams every weight byte itself, so the batch-32
-    headline shape (32 x 1025 = 256 x 128 + 32 rows) needs a second round of workgroups and loses (199-210 us).
-    DESIGN.md section 4 has the ablation of where its time goes."""
-    return os.environ.get("ISEGPROBE_FUSED_MLP", "0") == "1" and rows >= 128
+FUSED_MLP = os.environ.get("ISEGPROBE_FUSED_MLP", "0")  # "0" | "auto" (whole rounds of tiles only) | "1" (whenever the kernel exists)
+
+
+def _use_fused_mlp(B, T):
+    """Route of a block's MLP branch: the token-stationary fused kernel (csrc/vit_fused.hip: LayerNorm + fc1 + GELU + fc2 +
+    LayerScale + residual, the [rows, 4D] hidden map never leaves registers) over the PATCH-token rows, tiled per image
+    (B x 1024 tokens at 448^2 = B x 8 tiles of 128 rows), with the B class-token rows on the unfused kernels -- or the
+    three-kernel route for all rows.  One workgroup owns a tile and streams every weight byte itself (2.4 MB), so the
+    kernel wins only when the tiles fill the chip in whole rounds ("auto": last round of 256 workgroups at least 90 % full).
+    Measured at batch 32 x 448^2 (256 tiles): 115 us for the fused kernel against 136 us for LayerNorm + fc1 + fc2 inside the
+    trunk -- but the three tiny launches for the 32 class-token rows cost 37 us per block, and the whole forward comes out at
+    4.03 against 3.83 ms.  OFF by default until the class-token rows ride along for free."""
+    if FUSED_MLP == "0" or T < 128:
+        return False
+    if FUSED_MLP == "1":
+        return True
+    tiles = B * ((T + 127) // 128)
+    return tiles >= 0.9 * ((tiles + 255) // 256) * 256
+
+
+def _mlp_fused_rows(x, B, T, blk, dtype, seen=lambda t: t):
+    """x += ls2 * fc2(GELU(fc1(LayerNorm(x)))) (block.py:92-117, second branch) on the [B, T+1, D] fp32 stream: the patch-token
+    rows by the fused kernel, the class-token rows (row 0 of every image, a strided [B, D] view) by the three unfused ones."""
+    key = "mlp_fused_h" if dtype == ops.F16 else "mlp_fused_b"
+    if key not in blk:
+        blk[key] = ops.vit_mlp_pack(*blk["mlp_fused_src"], dtype=dtype)
+    D = x.shape[1]
+    cls_rows = x.view(B, (T + 1) * D)  # LayerNorm / GEMM over the first D columns of each "row" = the class tokens
+    h = seen(ops.layernorm(cls_rows, blk["n2w"], blk["n2b"], LN_EPS, out_dtype=dtype, D=D))
+    half = dtype == ops.F16
+    hid = seen(ops.linear(h, blk["h_fc1_w" if half else "fc1_w"], blk["fc1_b"], "gelu"))
+    ops.linear_residual_(cls_rows, hid, blk["h_fc2_w" if half else "fc2_w"], blk["fc2_b"], blk["ls2"], ldo=(T + 1) * D)
+    ops.vit_mlp_fused_rows_(x, *blk[key], LN_EPS, B, T + 1, 1, T)
 
 
 class _PatchProj(nn.Module):
@@ -181,7 +207,8 @@ class DINOv2Featurizer(nn.Module):
                     qkv_w2=qw.to(BF16).contiguous(), qkv_b2=qb.contiguous(),
                     h_qkv_w=qw.to(ops.F16).contiguous(), h_proj_w=half(blk.attn.proj.weight),
                     h_fc1_w=half(blk.mlp.fc1.weight), h_fc2_w=half(blk.mlp.fc2.weight),
-                    qkv_fold=fold(qw, qb, blk.norm1), fc1_fold=fold(blk.mlp.fc1.weight.detach(), blk.mlp.fc1.bias.detach(), blk.norm2),
+                    qkv_fold=fold(qw, qb, blk.norm1) if VIT_LNFOLD else None,
+                    fc1_fold=fold(blk.mlp.fc1.weight.detach(), blk.mlp.fc1.bias.detach(), blk.norm2) if VIT_LNFOLD else None,
                     n1w=f32(blk.norm1.weight), n1b=f32(blk.norm1.bias),
                     qkv_w=b16(blk.attn.qkv.weight), qkv_b=f32(blk.attn.qkv.bias),
                     proj_w=b16(blk.attn.proj.weight), proj_b=f32(blk.attn.proj.bias),
@@ -191,10 +218,11 @@ class DINOv2Featurizer(nn.Module):
                     fc2_w=b16(blk.mlp.fc2.weight), fc2_b=f32(blk.mlp.fc2.bias),
                     ls2=f32(blk.ls2.gamma) if isinstance(blk.ls2, _Gamma) else None))
                 if ops.vit_mlp_fused_supported(m.embed_dim, blk.mlp.fc1.weight.shape[0]):
-                    blocks[-1]["mlp_fused"] = ops.vit_mlp_pack(blk.norm2.weight.detach(), blk.norm2.bias.detach(),
-                                                               blk.mlp.fc1.weight.detach(), blk.mlp.fc1.bias.detach(),
-                                                               blk.mlp.fc2.weight.detach(), blk.mlp.fc2.bias.detach(),
-                                                               blk.ls2.gamma.detach() if isinstance(blk.ls2, _Gamma) else None)
+                    # packed on first use, per operand format (vit_mlp_pack: LayerNorm folded into fc1, LayerScale into fc2)
+                    blocks[-1]["mlp_fused_src"] = (blk.norm2.weight.detach(), blk.norm2.bias.detach(),
+                                                   blk.mlp.fc1.weight.detach(), blk.mlp.fc1.bias.detach(),
+                                                   blk.mlp.fc2.weight.detach(), blk.mlp.fc2.bias.detach(),
+                                                   blk.ls2.gamma.detach() if isinstance(blk.ls2, _Gamma) else None)
             self._pos_cache.clear()
             return dict(blocks=blocks, nw=f32(m.norm.weight), nb=f32(m.norm.bias),
                         patch_w=m.patch_embed.proj.weight.detach().flatten(1).float(),
@@ -255,7 +283,8 @@ class DINOv2Featurizer(nn.Module):
             # weights (and every forward under ISEGPROBE_F16_PROBE=always) records the largest magnitude of each 16-bit
             # intermediate; at >= half of the range the weights are marked bf16-only (bf16 has fp32's range) and this
             # forward is redone in bf16 from a copy of the stream.  One device->host read per weight version.
-            probe = ("f16_ok" not in P or F16_PROBE_ALWAYS) and not torch.cuda.is_current_stream_capturing()
+            probe = (("f16_ok" not in P or F16_PROBE_ALWAYS or P.pop("f16_reprobe", False))
+                     and not torch.cuda.is_current_stream_capturing())
             peak = torch.zeros((), device=x.device) if probe else None
             x_in = x.clone() if probe else None
 
@@ -283,6 +312,10 @@ class DINOv2Featurizer(nn.Module):
                     seen(x16)
                     continue
                 ops.linear_residual_(x, att, blk["h_proj_w"], blk["proj_b"], blk["ls1"])
+                if "mlp_fused_src" in blk and _use_fused_mlp(B, T) and not probe:
+                    # (a probing forward takes the three-kernel route: the fused kernel's hidden map never leaves registers)
+                    _mlp_fused_rows(x, B, T, blk, H16)
+                    continue
                 hbuf = seen(ops.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS, out_dtype=H16))
                 hid = seen(ops.linear(hbuf, blk["h_fc1_w"], blk["fc1_b"], "gelu"))
                 ops.linear_residual_(x, hid, blk["h_fc2_w"], blk["fc2_b"], blk["ls2"])
@@ -306,9 +339,8 @@ class DINOv2Featurizer(nn.Module):
                 return qkv  # packed [B*L, 3, heads, 64]: the caller extracts K; the rest of the block is unused
             att = ops.attention_packed_qkv(qkv, B, L, heads, 64 ** -0.5, q_logit2=True)
             ops.linear_residual_(x, att, blk["proj_w"], blk["proj_b"], blk["ls1"])
-            if "mlp_fused" in blk and _use_fused_mlp(x.shape[0]):
-                # LayerNorm + fc1 + GELU + fc2 + LayerScale + residual in one token-stationary kernel (csrc/vit_fused.hip)
-                ops.vit_mlp_fused_(x, *blk["mlp_fused"], LN_EPS)
+            if "mlp_fused_src" in blk and _use_fused_mlp(B, T):
+                _mlp_fused_rows(x, B, T, blk, BF16)
                 continue
             hbuf = ops.layernorm(x, blk["n2w"], blk["n2b"], LN_EPS)
             hid = ops.linear(hbuf, blk["fc1_w"], blk["fc1_b"], "gelu")
@@ -366,6 +398,14 @@ class DINOv2Featurizer(nn.Module):
         if wants_grad:  # after_backbone, training: the add is the first node of the autograd graph
             feats = TokenAddFn.apply(feats.view(b, T, D), additional_features)
         return nchw_view(feats.view(b, h, w, D))  # DINOv2.py:545
+
+    def new_image(self):
+        """A new input image is about to be processed (BasePredictor.set_input_image): re-arm the half-precision stream's
+        range probe for the next forward.  Activation peaks depend on the image, so one probe per weight set is not enough;
+        the probe costs one extra copy of the token stream and one device->host read, once per image, never per click."""
+        P = self.packed()
+        if P.get("f16_ok", True):
+            P["f16_reprobe"] = True
 
     def forward_fused_clicks(self, image, prev_mask, click_maps, embed_coords, out_f16=False):
         """before_backbone fast path: image patches and click-map patches are embedded by ONE

@@ -44,6 +44,21 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {  // one v_
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
+// 16-bit operand format of the kernel: bf16, or IEEE half (the ViT trunk's default inference stream: three more mantissa bits
+// on the normalised rows, the hidden map and the weights at the same MFMA rate; values saturate at half's range)
+template <bool F16>
+__device__ __forceinline__ f32x16_t mfma32(bf16x8 a, bf16x8 b, f32x16_t c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16, bool SAT = true>
+__device__ __forceinline__ unsigned pack16(float lo, float hi) {
+    if constexpr (F16) return SAT ? pack2h_sat(lo, hi) : pack2h(lo, hi);
+    else return cvt_pk_bf16(lo, hi);
+}
+
 // Weight tiles, hidden axis in chunks of 64:
 //   A-tile (fc1)  (chunk c, kk < KK = D/128): LDS rows 0-63 = hidden 64c + r over k 128kk .. +63, rows 64-127 = the same
 //                 hidden units over k 128kk+64 .. +127 -> 2 accumulator tiles (32 hidden x 32 tokens) x 8 k-steps of 16.
@@ -51,10 +66,11 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {  // one v_
 //                 -> 4 accumulator tiles x 4 k-steps.
 // Stream order per 128-token tile:  A(0) | A(1) B(0) | A(2) B(1) | ... | A(CH-1) B(CH-2) | B(CH-1)   (each group KK + NB = 6
 // tiles), continuing seamlessly into the next token tile of the workgroup (or into harmless re-loads at the very end).
-template <int D, int HID>
+template <int D, int HID, bool F16>
 __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict__ x, const bf16_t* __restrict__ w1,
                                                                const float* __restrict__ b1, const bf16_t* __restrict__ w2,
-                                                               const float* __restrict__ b2, long M, float eps, int n_tiles) {
+                                                               const float* __restrict__ b2, long M, float eps, int n_tiles, int rot_mul,
+                                                               int tiles_per_image, int rows_per_image, int first_row, int T) {
     constexpr int KS = D / 16;     // k-steps of 16 over the embedding dim
     constexpr int KK = D / 128;    // A-tiles per chunk
     constexpr int NB = D / 128;    // B-tiles per chunk
@@ -66,6 +82,21 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lg = lane >> 5;
+    // Tiles walk the hidden chunks in rotated order (logical chunk j = physical chunk (j + rot) mod CH; the second product sums
+    // over chunks, so any order is the same function up to fp32 summation order): with one order for all, the 256 workgroups
+    // ask the L2 for the same 16 KiB weight tile at the same moment (measured: 130 -> 124 us per launch, 123 -> 115 us on the
+    // per-image tiling).  The rotation is a function of the tile's position INSIDE its image, so an image's result does not
+    // depend on its batch index or batch size; xcd_remap hands each XCD a contiguous run of tiles = all positions.
+    auto tile_of = [&](int t) { return xcd_remap(t, n_tiles); };
+    auto rot_of = [&](int tile) {
+        const int pos = tiles_per_image > 0 ? tile % tiles_per_image : tile;
+        return (int)(((unsigned)pos * (unsigned)rot_mul) % (unsigned)CH);
+    };
+    int rot = rot_of(tile_of(blockIdx.x)), rot_nx = rot;  // current tile's / next tile's (the stream runs across tiles)
+    auto phys = [&](int j, int r) {
+        const int c = j + r;
+        return c >= CH ? c - CH : c;
+    };
 
     // ---- weight stream: buffer_load ... lds against SGPR resources (a 32-bit byte offset per lane and piece, the tile
     // base as a scalar offset: no 64-bit pointers in VGPRs).  Piece p (1 KiB = 8 LDS rows): lane -> (row 8p + lane/8,
@@ -80,9 +111,9 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
         offA[i] = (unsigned)((row & 63) * D + 64 * (row >> 6) + sc) * 2u;
         offB[i] = (unsigned)(row * HID + sc) * 2u;
     }
-    auto issue_a = [&](int c, auto kktag, auto slottag) {
+    auto issue_a = [&](int c, auto kktag, auto slottag, int r) {
         constexpr int kk = decltype(kktag)::value, slot = decltype(slottag)::value;
-        const int base = (64 * c * D + 128 * kk) * 2;
+        const int base = (64 * phys(c, r) * D + 128 * kk) * 2;
 #ifdef ISP_ABLATE_MLP_NO_DMA  // timing experiment only: compute on whatever the ring holds
         if (base != -12345) return;
 #endif
@@ -93,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
     };
     auto issue_b = [&](int c, auto nbtag, auto slottag) {
         constexpr int nb = decltype(nbtag)::value, slot = decltype(slottag)::value;
-        const int base = (128 * nb * HID + 64 * c) * 2;
+        const int base = (128 * nb * HID + 64 * phys(c, rot)) * 2;
 #ifdef ISP_ABLATE_MLP_NO_DMA
         if (base != -12345) return;
 #endif
@@ -150,12 +181,12 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
     };
 
     // prime: stream positions 0..5 = A(0) (slots 0-2), A(1) (slots 3-5); then the first tile's first 8 fragments
-    issue_a(0, IC<0>{}, IC<0>{});
-    issue_a(0, IC<1>{}, IC<1>{});
-    issue_a(0, IC<2>{}, IC<2>{});
-    issue_a(1, IC<0>{}, IC<3>{});
-    issue_a(1, IC<1>{}, IC<4>{});
-    issue_a(1, IC<2>{}, IC<5>{});
+    issue_a(0, IC<0>{}, IC<0>{}, rot);
+    issue_a(0, IC<1>{}, IC<1>{}, rot);
+    issue_a(0, IC<2>{}, IC<2>{}, rot);
+    issue_a(1, IC<0>{}, IC<3>{}, rot);
+    issue_a(1, IC<1>{}, IC<4>{}, rot);
+    issue_a(1, IC<2>{}, IC<5>{}, rot);
 #ifdef ISP_ABLATE_MLP_NO_DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
@@ -171,9 +202,25 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
     f[6] = frag(IC<0>{}, IC<1>{}, IC<6>{});
     f[7] = frag(IC<0>{}, IC<1>{}, IC<7>{});
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const long tok = (long)tile * TOK_BLOCK + wid * 32 + lr;
-        const long tokc = tok < M ? tok : M - 1;
+    for (int t_lin = blockIdx.x; t_lin < n_tiles; t_lin += gridDim.x) {
+        const int tile = tile_of(t_lin);
+        rot = rot_nx;
+        rot_nx = t_lin + (int)gridDim.x < n_tiles ? rot_of(tile_of(t_lin + gridDim.x)) : 0;
+        // rows of a tile: M contiguous rows, or (tiles_per_image > 0) the T patch-token rows first_row .. first_row + T - 1 of
+        // each image's rows_per_image rows -- the class-token rows are left to the caller, so that B x 1024 patch tokens
+        // are exactly B x 8 tiles (32 x 1025 rows as one range are 256 tiles + 32 rows = a second round of workgroups)
+        long tok, tokc;
+        bool live;
+        if (tiles_per_image > 0) {
+            const int img = tile / tiles_per_image;
+            const int t = (tile - img * tiles_per_image) * TOK_BLOCK + wid * 32 + lr;
+            live = t < T;
+            tok = tokc = (long)img * rows_per_image + first_row + (live ? t : T - 1);
+        } else {
+            tok = (long)tile * TOK_BLOCK + wid * 32 + lr;
+            live = tok < M;
+            tokc = live ? tok : M - 1;
+        }
         // ---- LayerNorm prologue: the wave's 32 rows, normalised, as bf16 B operands (lane: token lr, 8 k of k-step s at 8*lg)
         bf16x8 act[KS];
         {
@@ -205,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
             for (int s = 0; s < KS; ++s) {
                 unsigned p[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) p[e] = pack2bf((v[s][2 * e] - mean) * rstd, (v[s][2 * e + 1] - mean) * rstd);
+                for (int e = 0; e < 4; ++e) p[e] = pack16<F16, false>((v[s][2 * e] - mean) * rstd, (v[s][2 * e + 1] - mean) * rstd);  // |x_hat| <= sqrt(D)
                 act[s] = __builtin_bit_cast(bf16x8, make_uint4(p[0], p[1], p[2], p[3]));
             }
         }
@@ -222,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
         // register-destination VMEM load inside the DMA stream would make the compiler drain the LDS-DMA pipeline.
         auto gelu_half = [&](int c, auto ttag, auto utag, bf16x8 (&hbn)[4]) {
             constexpr int T = decltype(ttag)::value, u = decltype(utag)::value;
-            const float* bb = b1 + 64 * c + 32 * T + 16 * u;
+            const float* bb = b1 + 64 * phys(c, rot) + 32 * T + 16 * u;
             float r[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {  // accumulator registers 8u + e = rows 16u + 8*(e/4) + 4*lg + e%4
@@ -235,8 +282,8 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
                 r[e] = gelu_sig5(hacc[T][8 * u + e] + (lg ? hi : lo));
 #endif
             }
-            hbn[2 * T + u] = __builtin_bit_cast(bf16x8, make_uint4(cvt_pk_bf16(r[0], r[1]), cvt_pk_bf16(r[2], r[3]),
-                                                                 cvt_pk_bf16(r[4], r[5]), cvt_pk_bf16(r[6], r[7])));
+            hbn[2 * T + u] = __builtin_bit_cast(bf16x8, make_uint4(pack16<F16>(r[0], r[1]), pack16<F16>(r[2], r[3]),
+                                                                 pack16<F16>(r[4], r[5]), pack16<F16>(r[6], r[7])));
         };
         // Pin the instruction order of the 8 MFMAs just emitted: MFMA, its fragment read, then NV VALU instructions (the
         // GELU work that runs beside a B-tile) -- left alone the scheduler clusters the reads and exposes their latency.
@@ -262,9 +309,9 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
                     f32x16_t z;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) z[e] = 0.f;
-                    hacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[I % 8], act[8 * kk + I % 8], z, 0, 0, 0);
+                    hacc[T] = mfma32<F16>(f[I % 8], act[8 * kk + I % 8], z);
                 } else {
-                    hacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[I % 8], act[8 * kk + I % 8], hacc[T], 0, 0, 0);
+                    hacc[T] = mfma32<F16>(f[I % 8], act[8 * kk + I % 8], hacc[T]);
                 }
                 if constexpr (I < 8)
                     f[I % 8] = frag(S{}, IC<1>{}, IC<I + 8>{});
@@ -289,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
             using NA = decltype(natag);
             auto mfma = [&](auto itag) {
                 constexpr int I = decltype(itag)::value;
-                oacc[4 * nb + I / 4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[I % 8], hbc[I % 4], oacc[4 * nb + I / 4], 0, 0, 0);
+                oacc[4 * nb + I / 4] = mfma32<F16>(f[I % 8], hbc[I % 4], oacc[4 * nb + I / 4]);
                 if constexpr (I < 8)
                     f[I % 8] = frag(S{}, IC<0>{}, IC<I + 8>{});
                 else
@@ -332,12 +379,12 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
             auto refill_a = [&](auto kktag) {
                 return [&, kktag] {
                     if constexpr (LAST) issue_b(j, kktag, IC<3 + decltype(kktag)::value>{});
-                    else issue_a(j + 1, kktag, IC<3 + decltype(kktag)::value>{});
+                    else issue_a(j + 1, kktag, IC<3 + decltype(kktag)::value>{}, rot);
                 };
             };
             auto refill_b = [&](auto nbtag) {
                 return [&, nbtag] {
-                    if constexpr (LAST) issue_a(0, nbtag, nbtag);
+                    if constexpr (LAST) issue_a(0, nbtag, nbtag, rot_nx);
                     else issue_b(j, nbtag, nbtag);
                 };
             };
@@ -357,16 +404,16 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
         for (int j = 1; j + 1 < CH; ++j) group(j, IC<0>{});
         group(CH - 1, IC<1>{});
         // ---- last group: B(CH-1) in slots 3-5 (6 ahead: A(1) of the next token tile, same slots); next tile: A(0) in slot 0
-        b_tile(IC<0>{}, IC<3>{}, IC<4>{}, IC<0>{}, hb, [&] { issue_a(1, IC<0>{}, IC<3>{}); }, no_valu, IC<0>{});
-        b_tile(IC<1>{}, IC<4>{}, IC<5>{}, IC<0>{}, hb, [&] { issue_a(1, IC<1>{}, IC<4>{}); }, no_valu, IC<0>{});
-        b_tile(IC<2>{}, IC<5>{}, IC<0>{}, IC<1>{}, hb, [&] { issue_a(1, IC<2>{}, IC<5>{}); }, no_valu, IC<0>{});
+        b_tile(IC<0>{}, IC<3>{}, IC<4>{}, IC<0>{}, hb, [&] { issue_a(1, IC<0>{}, IC<3>{}, rot_nx); }, no_valu, IC<0>{});
+        b_tile(IC<1>{}, IC<4>{}, IC<5>{}, IC<0>{}, hb, [&] { issue_a(1, IC<1>{}, IC<4>{}, rot_nx); }, no_valu, IC<0>{});
+        b_tile(IC<2>{}, IC<5>{}, IC<0>{}, IC<1>{}, hb, [&] { issue_a(1, IC<2>{}, IC<5>{}, rot_nx); }, no_valu, IC<0>{});
 
 #else
         oacc[0][0] = __builtin_bit_cast(float, (int)act[0][0]) + __builtin_bit_cast(float, (int)act[KS - 1][3]);
 #endif
         // ---- epilogue: x += acc + b2 (LayerScale folded into W2 / b2).  A lane owns, per 32-row tile, 4 x 4 consecutive
         // channels (rows 8i + 4*lg .. +3) of token lr.
-        if (tok < M) {
+        if (live) {
             float* row = x + (size_t)tok * D + 4 * lg;
 #pragma unroll
             for (int nt = 0; nt < NT32; ++nt)
@@ -385,9 +432,11 @@ __global__ __launch_bounds__(256, 1) void vit_mlp_fused_kernel(float* __restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last (unused) refills must land before the LDS is released
 }
 
-template <int D, int HID>
-int launch_mlp(float* x, const void* w1, const float* b1, const void* w2, const float* b2, long M, float eps, hipStream_t s) {
-    const int n_tiles = (int)((M + TOK_BLOCK - 1) / TOK_BLOCK);
+template <int D, int HID, bool F16>
+int launch_mlp(float* x, const void* w1, const float* b1, const void* w2, const float* b2, long M, float eps, int images,
+               int rows_per_image, int first_row, int T, hipStream_t s) {
+    const int tiles_per_image = images > 0 ? (T + TOK_BLOCK - 1) / TOK_BLOCK : 0;
+    const int n_tiles = images > 0 ? images * tiles_per_image : (int)((M + TOK_BLOCK - 1) / TOK_BLOCK);
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -396,14 +445,20 @@ int launch_mlp(float* x, const void* w1, const float* b1, const void* w2, const 
         cus = p.multiProcessorCount;
     }
     const int lds = NSTAGE * TILE_BYTES;
-    auto kern = vit_mlp_fused_kernel<D, HID>;
+    auto kern = vit_mlp_fused_kernel<D, HID, F16>;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return ISP_ERR_LAUNCH;
         attr = true;
     }
     const int grid = n_tiles < cus ? n_tiles : cus;
-    kern<<<grid, 256, lds, s>>>(x, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, M, eps, n_tiles);
+    static int rot_mul = -1;
+    if (rot_mul < 0) {
+        const char* e = getenv("ISEGPROBE_MLP_ROT");
+        rot_mul = e ? atoi(e) : 3;  // 8 tiles per image at 448^2 -> chunk offsets 0, 3, .., 21 of 24
+    }
+    kern<<<grid, 256, lds, s>>>(x, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, M, eps, n_tiles, rot_mul, tiles_per_image,
+                               rows_per_image, first_row, T);
     return isp_launch_status();
 }
 
@@ -413,6 +468,18 @@ extern "C" int isp_vit_mlp_fused(float* x, const void* w1, const float* b1, cons
                                  int HID, float eps, void* stream) {
     ISP_CHECK_ARG(x && w1 && b1 && w2p && b2 && M > 0);
     hipStream_t s = (hipStream_t)stream;
-    if (D == 384 && HID == 1536) return launch_mlp<384, 1536>(x, w1, b1, w2p, b2, M, eps, s);
+    if (D == 384 && HID == 1536) return launch_mlp<384, 1536, false>(x, w1, b1, w2p, b2, M, eps, 0, 0, 0, 0, s);
+    return ISP_ERR_UNSUPPORTED;
+}
+
+extern "C" int isp_vit_mlp_fused_rows(float* x, const void* w1, const float* b1, const void* w2p, const float* b2, int images,
+                                      int rows_per_image, int first_row, int T, int D, int HID, float eps, int w_dtype, void* stream) {
+    ISP_CHECK_ARG(x && w1 && b1 && w2p && b2 && images > 0 && T > 0 && first_row >= 0 && first_row + T <= rows_per_image);
+    hipStream_t s = (hipStream_t)stream;
+    const long M = (long)images * rows_per_image;
+    if (D == 384 && HID == 1536 && w_dtype == ISP_BF16)
+        return launch_mlp<384, 1536, false>(x, w1, b1, w2p, b2, M, eps, images, rows_per_image, first_row, T, s);
+    if (D == 384 && HID == 1536 && w_dtype == ISP_F16)
+        return launch_mlp<384, 1536, true>(x, w1, b1, w2p, b2, M, eps, images, rows_per_image, first_row, T, s);
     return ISP_ERR_UNSUPPORTED;
 }

@@ -146,10 +146,11 @@ def linear_mul_dgelu(A, Wt, pre, act="gelu"):
     return out
 
 
-def linear_residual_(x, A, Wt, bias=None, gamma=None):
-    """x (f32 [M,N]) += gamma * (A Wt^T + bias), in place."""
+def linear_residual_(x, A, Wt, bias=None, gamma=None, ldo=None):
+    """x (f32 [M,N]) += gamma * (A Wt^T + bias), in place.  ``ldo``: row stride of x in elements when the M rows are a
+    strided subset of a larger matrix (the ViT's class-token rows: every (T+1)-th row of the stream)."""
     _need(x, torch.float32, "x")
-    gemm(A, Wt, _epilogue(_lib.EP_RESIDUAL_F32, x, x.shape[-1], bias, gamma))
+    gemm(A, Wt, _epilogue(_lib.EP_RESIDUAL_F32, x, x.shape[-1] if ldo is None else ldo, bias, gamma))
     return x
 
 
@@ -168,7 +169,7 @@ def linear_residual_stats_(x, A, Wt, bias=None, gamma=None):
     return x16, stats
 
 
-def vit_mlp_pack(norm_w, norm_b, fc1_w, fc1_b, fc2_w, fc2_b, ls=None):
+def vit_mlp_pack(norm_w, norm_b, fc1_w, fc1_b, fc2_w, fc2_b, ls=None, dtype=BF16):
     """Weights of isp_vit_mlp_fused from a block's fp32 parameters: LayerNorm affine folded into fc1, LayerScale into
     fc2, fc2's hidden axis permuted inside every group of 16 to the 32x32 accumulator order of the first product
     (physical 8g+e <- logical 4g+e for e < 4, 8+4g+(e-4) otherwise, g in {0,1})."""
@@ -181,7 +182,7 @@ def vit_mlp_pack(norm_w, norm_b, fc1_w, fc1_b, fc2_w, fc2_b, ls=None):
     perm = torch.tensor([(4 * (p // 8) + p % 8) if p % 8 < 4 else (8 + 4 * (p // 8) + p % 8 - 4) for p in range(16)],
                         device=w2.device)
     idx = (torch.arange(0, hid, 16, device=w2.device)[:, None] + perm[None, :]).reshape(-1)
-    return (w1.to(BF16).contiguous(), b1.contiguous(), w2[:, idx].to(BF16).contiguous(), b2.contiguous())
+    return (w1.to(dtype).contiguous(), b1.contiguous(), w2[:, idx].to(dtype).contiguous(), b2.contiguous())
 
 
 def vit_mlp_fused_(x, w1, b1, w2p, b2, eps):
@@ -190,6 +191,20 @@ def vit_mlp_fused_(x, w1, b1, w2p, b2, eps):
     M, D = x.shape
     check(_lib.lib().isp_vit_mlp_fused(_p(x), _p(w1), _p(b1), _p(w2p), _p(b2), M, D, w1.shape[0], float(eps), _stream()),
           "isp_vit_mlp_fused")
+    return x
+
+
+def vit_mlp_fused_rows_(x, w1, b1, w2p, b2, eps, images, rows_per_image, first_row, T):
+    """``vit_mlp_fused_`` over rows first_row .. first_row + T - 1 of every image's rows_per_image rows (the patch tokens;
+    the class-token rows are the caller's)."""
+    _need(x, torch.float32, "x")
+    M, D = x.shape
+    if M != images * rows_per_image:
+        raise IspError("vit_mlp_fused_rows_: x must hold images * rows_per_image rows")
+    if w1.dtype != w2p.dtype or w1.dtype not in (BF16, F16):
+        raise IspError("vit_mlp_fused_rows_: w1 / w2p must both be bf16 or both IEEE half")
+    check(_lib.lib().isp_vit_mlp_fused_rows(_p(x), _p(w1), _p(b1), _p(w2p), _p(b2), images, rows_per_image, first_row, T, D,
+                                            w1.shape[0], float(eps), _DTYPE_CODE[w1.dtype], _stream()), "isp_vit_mlp_fused_rows")
     return x
 
 

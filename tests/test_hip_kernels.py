@@ -484,6 +484,36 @@ def test_vit_mlp_fused(ops, M, D, HID):
     assert e < 3e-2 and e < 2 * e3 + 1e-3
 
 
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("B,T", [(3, 200), (2, 1024), (40, 1024), (5, 128)])
+def test_vit_mlp_fused_rows(ops, B, T, half):
+    """The fused MLP over the patch-token rows of a [B, T+1, D] stream (row 0 of every image = class token, left untouched),
+    tiled per image: ragged last tile per image (T = 200), exact tiles, more tiles than workgroups (40 x 8 = 320: several
+    tiles per workgroup, the weight stream running across tiles with a different chunk rotation per tile), bf16 and
+    IEEE-half operands -- against torch fp32, against the three-kernel route, and batch-invariance of every image."""
+    D, HID = 384, 1536
+    torch.manual_seed(B * 1000 + T)
+    dt = torch.float16 if half else BF
+    x = torch.randn(B * (T + 1), D, device="cuda") * 2 + 0.3
+    nw, nb = torch.randn(D, device="cuda") * 0.3 + 1, torch.randn(D, device="cuda") * 0.2
+    w1, b1 = torch.randn(HID, D, device="cuda") / math.sqrt(D), torch.randn(HID, device="cuda") * 0.3
+    w2, b2 = torch.randn(D, HID, device="cuda") / math.sqrt(HID), torch.randn(D, device="cuda") * 0.3
+    ls = torch.randn(D, device="cuda") * 0.5 + 1
+    ref = x + ls * (F.gelu(F.layer_norm(x, (D,), nw, nb, 1e-6) @ w1.t() + b1) @ w2.t() + b2)
+    P = ops.vit_mlp_pack(nw, nb, w1, b1, w2, b2, ls, dtype=dt)
+    y = ops.vit_mlp_fused_rows_(x.clone(), *P, 1e-6, B, T + 1, 1, T)
+    y3 = x.clone()
+    ops.linear_residual_(y3, ops.linear(ops.layernorm(x, nw, nb, 1e-6, out_dtype=dt), w1.to(dt), b1, "gelu"), w2.to(dt), b2, ls)
+    yv, xv, rv, y3v = (t.view(B, T + 1, D) for t in (y, x, ref, y3))
+    assert torch.equal(yv[:, 0], xv[:, 0])  # class-token rows: not this kernel's
+    e, e3 = (yv[:, 1:] - rv[:, 1:]).abs().max().item(), (y3v[:, 1:] - rv[:, 1:]).abs().max().item()
+    assert e < (1e-2 if half else 3e-2) and e < 2 * e3 + 1e-3, (e, e3)
+    # an image's rows do not depend on where in the batch (or in which batch) the image sits
+    b = B // 2
+    alone = ops.vit_mlp_fused_rows_(xv[b].clone().view(T + 1, D), *P, 1e-6, 1, T + 1, 1, T)
+    assert torch.equal(alone.view(T + 1, D)[1:], yv[b, 1:])
+
+
 def test_sigmoid_gelu_far_from_zero(ops):
     """The kernels' GELU is x * sigmoid(x * quartic(x^2)) with a negative leading coefficient: without the clamp of x^2 it
     returns 0 for x > 11.1 and x for x < -11.1.  Hidden pre-activations of +-40 through the fused ViT MLP and the
