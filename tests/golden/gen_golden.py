@@ -1027,6 +1027,85 @@ def gen_checkpoint():
     save("checkpoint", **out)
 
 
+def gen_frozen_checkpoints():
+    """SURVEY.md 8(b) "Frozen-weight key layouts": three small files in the on-disk layouts the reference's loaders read, each
+    written from the reference's own modules and READ BACK BY THE REFERENCE'S OWN LOADER before its output is stored:
+      * frozen_ckpts/loftup_tiny.ckpt -- {"state_dict": {"upsampler.*", "model.1.norm.*", + keys of other sub-models that the
+        loader must ignore}} -> load_loftup_checkpoint (loftup/loftup.py:152-177);
+      * frozen_ckpts/lift_tiny.pth    -- flat state dict with the DataParallel "module." prefix -> load_lift_checkpoints
+        (LiFT.py:125-136; its .to("cuda") is the one line skipped, there is no GPU in the build container);
+      * frozen_ckpts/dinov2_tiny_hub.pth -- the DINOv2 hub layout (cls_token, pos_embed, mask_token, patch_embed.proj.*,
+        blocks.{i}.{norm1,attn.qkv,attn.proj,ls1.gamma,norm2,mlp.fc1,mlp.fc2,ls2.gamma}.*, norm.*; block_chunks=0) ->
+        DINOv2Featurizer with torch.hub.load replaced by the same file's class loading this state dict (DINOv2.py:491)."""
+    from functools import partial
+    from pathlib import Path
+    import core.model.featurizers.DINOv2 as refdv
+    import core.model.upsamplers.LiFT as reflift
+    from core.model.featurizers.dinov2.layers import MemEffAttention, NestedTensorBlock
+    from core.model.upsamplers.LoftUp import LoftUpUpsampler
+    from core.model.upsamplers.loftup.layers import ChannelNorm
+    from core.model.upsamplers.loftup.loftup import LoftUp
+    root = Path(OUT) / "frozen_ckpts"
+    root.mkdir(exist_ok=True)
+    out = {}
+    torch.manual_seed(17)
+    C = 64
+    src = torch.randn(2, C, 2, 3)
+    gd = torch.randn(2, 3, 28, 42)
+    out["source"], out["guidance"] = src.numpy(), gd.numpy()
+
+    # ---- LoftUp
+    up, cn = seeded_(LoftUp(C, lr_pe_type="sine", lr_size=16), 91), seeded_(ChannelNorm(C), 92)
+    sd = {"upsampler." + k: v.clone() for k, v in up.state_dict().items()}
+    sd.update({"model.1." + k: v.clone() for k, v in cn.state_dict().items()})
+    sd["model.0.model.cls_token"] = torch.zeros(1, 1, C)  # the training wrapper's backbone lives in the same dict: ignored
+    torch.save({"state_dict": sd, "epoch": 3}, root / "loftup_tiny.ckpt")
+    lu = LoftUpUpsampler(str(root / "loftup_tiny.ckpt"), n_dim=C).eval()  # the reference's loader
+    assert all(not p.requires_grad for p in lu.parameters())
+    with torch.no_grad():
+        out["loftup_y"] = lu(src, gd).numpy()
+
+    # ---- LiFT
+    lift = seeded_(reflift.LiFT(C, 14), 93)
+    torch.save({"module." + k: v.clone() for k, v in lift.state_dict().items()}, root / "lift_tiny.pth")
+    real_to = nn.Module.to
+    nn.Module.to = lambda self, *a, **k: self if a == ("cuda",) else real_to(self, *a, **k)
+    try:
+        lf = reflift.LiFTUpsampler(str(root / "lift_tiny.pth"), n_dim=C, patch=14).eval()  # the reference's loader
+    finally:
+        nn.Module.to = real_to
+    with torch.no_grad():
+        out["lift_y"] = lf(src, gd).numpy()
+
+    # ---- DINOv2, hub layout
+    def tiny_vit():
+        return refdv.DinoVisionTransformer(img_size=TINY["img_size"], patch_size=TINY["patch"], embed_dim=TINY["embed_dim"],
+                                           depth=TINY["depth"], num_heads=TINY["num_heads"], mlp_ratio=4, init_values=1.0,
+                                           block_chunks=0, block_fn=partial(NestedTensorBlock, attn_class=MemEffAttention))
+    hub = seeded_(tiny_vit(), 94)
+    with torch.no_grad():
+        hub.pos_embed.mul_(0.3)
+    torch.save({k: v.clone() for k, v in hub.state_dict().items()}, root / "dinov2_tiny_hub.pth")
+    out["hub_keys"] = np.array(sorted(hub.state_dict().keys()))
+
+    def fake_hub_load(repo, arch, **kw):
+        m = tiny_vit()
+        m.load_state_dict(torch.load(root / "dinov2_tiny_hub.pth", map_location="cpu"))
+        return m
+    real_hub_load, torch.hub.load = torch.hub.load, fake_hub_load
+    try:
+        feat = refdv.DINOv2Featurizer("dinov2_vits14", "before_backbone").eval()
+    finally:
+        torch.hub.load = real_hub_load
+    img = torch.randn(2, 3, 56, 70)
+    clicks = 0.3 * torch.randn(2, 4 * 5, TINY["embed_dim"])
+    with torch.no_grad():
+        out["dino_x"], out["dino_clicks"], out["dino_y"] = img.numpy(), clicks.numpy(), feat(img, clicks).numpy()
+    for f in sorted(root.iterdir()):
+        print(f"  {f} ({f.stat().st_size / 1024:.0f} KiB)")
+    save("frozen_ckpts", **out)
+
+
 def gen_train_step():
     """the reference iSegProbeModel in .train() (trainer.py:214 -- the frozen upsamplers'
     BatchNorm2d layers then use BATCH statistics and update their running ones), one NormalizedFocalLossSigmoid step
@@ -1226,9 +1305,9 @@ def gen_crops():
 def main():
     torch.set_num_threads(4)
     install_standins()
-    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "noc_dataset", "noc_upsamplers", "noc_sbd", "checkpoint", "train_step", "datasets", "crops"]
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "noc_dataset", "noc_upsamplers", "noc_sbd", "checkpoint", "frozen_ckpts", "train_step", "datasets", "crops"]
     fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino, "simple_vit": gen_simple_vit, "maskclip": gen_maskclip,
-           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "noc_dataset": gen_noc_dataset, "noc_upsamplers": gen_noc_dataset_upsamplers, "noc_sbd": gen_noc_dataset_sbd, "checkpoint": gen_checkpoint, "train_step": gen_train_step, "datasets": gen_datasets, "crops": gen_crops}
+           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "noc_dataset": gen_noc_dataset, "noc_upsamplers": gen_noc_dataset_upsamplers, "noc_sbd": gen_noc_dataset_sbd, "checkpoint": gen_checkpoint, "frozen_ckpts": gen_frozen_checkpoints, "train_step": gen_train_step, "datasets": gen_datasets, "crops": gen_crops}
     for w in which:
         fns[w]()
 

@@ -323,3 +323,32 @@ def test_loftup_odd_widths_fall_back_to_bf16(n_dim):
     print(f"loftup n_dim {n_dim}: max {err.max().item():.3g} rms {err.pow(2).mean().sqrt().item():.3g}")
     assert err.max().item() < 6e-2 * max(1.0, ref.abs().max().item())
     assert err.pow(2).mean().sqrt().item() < 1e-2 * max(1.0, ref.pow(2).mean().sqrt().item())
+
+
+def test_frozen_checkpoint_files_vs_reference_outputs(golden):
+    """The three frozen-weight files (tests/golden/frozen_ckpts/, layouts of the reference's loaders) loaded through the plugin
+    constructors -- LoftUpUpsampler(upsampler_path=), LiFTUpsampler(lift_path=), DINOv2Featurizer(weights=) -- against the
+    outputs the reference produced after reading the same files with its own loaders."""
+    import os
+    from conftest import GOLDEN
+    from helpers import TINY_VIT
+    from isegprobe_amd.core.model.featurizers import DINOv2Featurizer
+    from isegprobe_amd.core.model.upsamplers import LiFTUpsampler, LoftUpUpsampler
+    g = golden("frozen_ckpts")
+    root = os.path.join(GOLDEN, "frozen_ckpts")
+    src, gd = torch.from_numpy(g["source"]).cuda(), torch.from_numpy(g["guidance"]).cuda()
+    for name, up in (("loftup", LoftUpUpsampler(os.path.join(root, "loftup_tiny.ckpt"), n_dim=64)),
+                     ("lift", LiFTUpsampler(os.path.join(root, "lift_tiny.pth"), n_dim=64, patch=14))):
+        with torch.no_grad():
+            y = _f32(up.cuda().eval()(src, gd))
+        ref = torch.from_numpy(g[name + "_y"])
+        assert y.shape == ref.shape
+        err = (y - ref).abs()
+        print(name, "max err", err.max().item(), "rms", err.pow(2).mean().sqrt().item(), "ref rms", ref.pow(2).mean().sqrt().item())
+        assert err.max().item() < (6e-2 if name == "loftup" else 3e-2) * max(1.0, ref.abs().max().item())
+        assert err.pow(2).mean().sqrt().item() < 1e-2 * max(1.0, ref.pow(2).mean().sqrt().item())
+    f = DINOv2Featurizer("custom", "before_backbone", weights=os.path.join(root, "dinov2_tiny_hub.pth"), vit_kwargs=TINY_VIT).cuda().eval()
+    with torch.no_grad():
+        y = f(torch.from_numpy(g["dino_x"]).cuda(), torch.from_numpy(g["dino_clicks"]).cuda()).float().cpu()
+    ref = torch.from_numpy(g["dino_y"])
+    assert y.shape == ref.shape and (y - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
