@@ -91,7 +91,9 @@ class GuidanceCache:
         if name not in slot.fresh:
             new = build()
             old = slot.data.get(name)
-            if old is not None and all(o.shape == n.shape and o.dtype == n.dtype for o, n in zip(_tensors(old), _tensors(new))):
+            same = (old is not None and type(old) is type(new) and len(_tensors(old)) == len(_tensors(new))
+                    and all(o.shape == n.shape and o.dtype == n.dtype for o, n in zip(_tensors(old), _tensors(new))))
+            if same:  # (a tensor where a tuple was, or tuples of different lengths, replace the entry instead)
                 for o, n in zip(_tensors(old), _tensors(new)):
                     o.copy_(n)
             else:

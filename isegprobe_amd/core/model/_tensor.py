@@ -41,6 +41,15 @@ def to_nchw_f32(x):
     return x.float().contiguous()
 
 
+_pack_serial = [0]
+
+
+def pack_serial(P):
+    """Identity of a packed-weight value for cache keys: the serial number its build was given (monotonically increasing,
+    never reused -- ``id(P)`` of a rebuilt dict can be)."""
+    return P["_serial"] if isinstance(P, dict) and "_serial" in P else id(P)
+
+
 class PackedCache:
     """Kernel-layout (bf16, permuted, padded) copies of a module's fp32 parameters,
     rebuilt whenever a parameter is replaced or modified in place."""
@@ -61,5 +70,8 @@ class PackedCache:
         if key != self._key:
             with torch.no_grad():
                 self._val = build()
+            if isinstance(self._val, dict):
+                _pack_serial[0] += 1
+                self._val["_serial"] = _pack_serial[0]
             self._key = key
         return self._val

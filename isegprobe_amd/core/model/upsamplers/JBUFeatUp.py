@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .... import hip_ops as ops
 from ...utils.log import logger
-from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16
+from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16, pack_serial
 from .._guidance_cache import GuidanceCache
 from . import BaseUpsampler
 
@@ -61,7 +61,7 @@ class JBULearnedRange(nn.Module):
         P = self.packed()
         if drops is not None:  # train-mode Dropout2d: fresh multipliers per forward, nothing to cache
             return self._build_kernels(P, guidance, GH, GW, drops)
-        return self._gcache.get(guidance, id(P), (GH, GW), lambda: self._build_kernels(P, guidance, GH, GW))
+        return self._gcache.get(guidance, pack_serial(P), (GH, GW), lambda: self._build_kernels(P, guidance, GH, GW))
 
     @staticmethod
     def _build_kernels(P, guidance, GH, GW, drops=None):
@@ -92,7 +92,7 @@ class JBULearnedRange(nn.Module):
             small = ops.adaptive_avg_pool(guidance, GH, GW)
             proj = ops.jbu_range_proj(small, P["w0"], P["b0"], P["w3"], P["b3"])
             return ops.jbu_kernels_resized(proj, small, P["f0w"], P["f0b"], P["f3w"], P["f3b"], P["temp"], P["sigma"], OH, OW)
-        return self._gcache.get(guidance, id(P), (GH, GW, OH, OW), build)
+        return self._gcache.get(guidance, pack_serial(P), (GH, GW, OH, OW), build)
 
     def run_resized(self, source_nhwc, guidance, OH, OW, kc9=None, out_dtype=BF16):
         """resize_bilinear(run(source), OH, OW) as one operator (isp_jbu_apply_resized on the blended records)."""

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .... import hip_ops as ops
 from ...utils.log import logger
-from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16
+from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16, pack_serial
 from .._guidance_cache import GuidanceCache
 from . import BaseUpsampler
 
@@ -174,7 +174,7 @@ class LiFTUpsampler(BaseUpsampler):
             a = conv_s2(a, "ic1b", L.image_convs_1[4])
             a = ops.adaptive_max_pool_nhwc(a, 2 * h, 2 * w)                   # [B,2h,2w,32]
             return a, conv_s2(a, "ic2", L.image_convs_2[1])                    # [B,h,w,32]
-        i1, i2 = pyramid() if train else self._gcache.get(g, id(P), ("pyr", h, w), pyramid)
+        i1, i2 = pyramid() if train else self._gcache.get(g, pack_serial(P), ("pyr", h, w), pyramid)
         xin = torch.zeros(B, h, w, P["cu_in_p"], device=x.device, dtype=BF16)  # cat([x, imgs_2]) + zero pad
         xin[..., :C] = x
         xin[..., C:C + 32] = i2

@@ -28,7 +28,7 @@ import torch.nn as nn
 
 from .... import hip_ops as ops
 from ...utils.log import logger
-from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16
+from .._tensor import BF16, PackedCache, nchw_view, to_nhwc_bf16, pack_serial
 from .._guidance_cache import GuidanceCache
 from . import BaseUpsampler
 
@@ -329,7 +329,7 @@ class LoftUpUpsampler(BaseUpsampler):
         # no pass over the [B*H*W, 448] pixel map is left between the GEMMs (csrc/gemm.hip: EpAxpyResStats / EpBiasActStats /
         # EpLnFold)
         fold = half and cp <= 448 and LOFTUP_LNFOLD
-        x = image_queries() if train else self._gcache.get(guidance, id(P), "x0", image_queries)
+        x = image_queries() if train else self._gcache.get(guidance, pack_serial(P), "x0", image_queries)
         stats = None  # row statistics of the current x
         if fold and LOFTUP_Q0_STATS:
             x, stats = x
@@ -346,7 +346,7 @@ class LoftUpUpsampler(BaseUpsampler):
                     return ops.linear(qn, L["wq2"], L["bq2"]).view(B, H * W, heads, hdp)
                 return ops.linear(qn, L["wq"], L["bq"]).view(B, H * W, heads, hdp)
             # the first layer's queries see the image only (x is still x0)
-            q = (self._gcache.get(guidance, id(P), "q0" if save is None else "q0_grad", project_q) if (li == 0 and not train)
+            q = (self._gcache.get(guidance, pack_serial(P), "q0" if save is None else "q0_grad", project_q) if (li == 0 and not train)
                  else project_q())  # (the inference projection carries the softmax scale: its own cache slot)
             kn = ops.layernorm(kv, L["nkv_w"], L["nkv_b"], L["nkv_eps"], D=c, ld_out=cp, out_dtype=dt)
             k = ops.linear(kn, L["wk"], L["bk"]).view(B, T, heads, hdp)

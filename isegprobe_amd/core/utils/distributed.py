@@ -14,6 +14,10 @@ from torch import distributed as dist
 from torch.utils import data
 
 
+# ISEGPROBE_GRAD_OVERLAP=0: one all-reduce of the whole bucket after backward instead of the head slice from inside backward
+GRAD_OVERLAP = os.environ.get("ISEGPROBE_GRAD_OVERLAP", "1") != "0"
+
+
 def get_rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -79,25 +83,28 @@ def shard_indices(n, rank=None, world=None):
 def broadcast_buffers(module, src=0):
     """DDP's ``broadcast_buffers=True`` (the reference wraps the net with the default, core/utils/distributed.py:66-78):
     before every training forward rank ``src``'s module buffers replace every other rank's -- here the running
-    statistics of the frozen LiFT / LoftUp BatchNorms, which train-mode forwards update from each rank's own shard.
-    One flat broadcast of the floating-point buffers."""
+    statistics of the frozen LiFT / LoftUp BatchNorms, which train-mode forwards update from each rank's own shard, and
+    their integer ``num_batches_tracked`` counters.  Two flat broadcasts (floating point, integer), no device->host
+    synchronisation: the receiving ranks copy unconditionally (the buffers' version counters move, as they do anyway
+    in the train-mode forward that follows)."""
     if get_world_size() < 2:
         return 0
-    bufs = [b for b in module.buffers() if b.is_floating_point() and b.numel() > 0]
-    if not bufs:
-        return 0
-    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
-    dist.broadcast(flat, src=src)
-    if get_rank() != src:
-        off = 0
-        with torch.no_grad():
-            for b in bufs:
-                n = b.numel()
-                new = flat[off:off + n].view_as(b).to(b.dtype)
-                if not torch.equal(new, b):  # leave the version counter alone when nothing changed (packed-weight caches key on it)
-                    b.copy_(new)
-                off += n
-    return len(bufs)
+    done = 0
+    for floating in (True, False):
+        bufs = [b for b in module.buffers() if b.numel() > 0 and b.is_floating_point() == floating and not b.is_complex()]
+        if not bufs:
+            continue
+        flat = torch.cat([b.detach().reshape(-1).to(torch.float32 if floating else torch.int64) for b in bufs])
+        dist.broadcast(flat, src=src)
+        if get_rank() != src:
+            off = 0
+            with torch.no_grad():
+                for b in bufs:
+                    n = b.numel()
+                    b.copy_(flat[off:off + n].view_as(b))
+                    off += n
+        done += len(bufs)
+    return done
 
 
 class GradBucket:
@@ -175,7 +182,7 @@ class GradBucket:
         """Call before ``loss.backward()``: when the last early parameter's gradient has been accumulated, the early
         slice's all-reduce(sum) is issued with ``async_op=True`` (on RCCL it runs on the communicator's stream behind
         an event of the compute stream).  No-op for a single process or without early parameters."""
-        if get_world_size() < 2 or not self.n_early:
+        if get_world_size() < 2 or not self.n_early or not GRAD_OVERLAP:
             self._pending = None
             return
         if not self._hooks:
@@ -193,15 +200,26 @@ class GradBucket:
     def finish_overlapped(self):
         """After backward: all-reduce what the early launch did not cover, wait for both, divide by the world size.
         Equals ``all_reduce_mean()`` bit for bit on two ranks (the sum of two floats is order-independent) and up to
-        the collective's own reduction order beyond."""
+        the collective's own reduction order beyond.
+
+        Every rank issues the SAME sequence of collectives whatever its autograd graph did: [early slice, rest].  A rank
+        whose early hook did not fire the expected number of times (a head parameter that received no gradient this
+        step) issues the early slice here, synchronously, instead of skipping it -- a skipped collective would pair
+        this rank's next all-reduce with the other ranks' early one and hang the job."""
         world = get_world_size()
         if world < 2:
             return
         pending, self._pending = self._pending, None
-        early_work = pending[1] if pending else None
-        lo = self._early_numel if early_work is not None else 0
-        if lo < self.flat.numel():
-            dist.all_reduce(self.flat[lo:], op=dist.ReduceOp.SUM)
+        if pending is None:  # arm_early() was not called (or there are no early parameters): one collective
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(world)
+            return
+        early_work = pending[1]
+        self.early_fired_in_backward = early_work is not None
+        if early_work is None:
+            dist.all_reduce(self.flat[:self._early_numel], op=dist.ReduceOp.SUM)
+        if self._early_numel < self.flat.numel():
+            dist.all_reduce(self.flat[self._early_numel:], op=dist.ReduceOp.SUM)
         if early_work is not None:
             early_work.wait()
         self.flat.div_(world)

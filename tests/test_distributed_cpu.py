@@ -63,8 +63,23 @@ def _worker(rank, world, port, out):
     # 2c) DDP's buffer broadcast: rank-local running statistics are replaced by rank 0's
     bn = torch.nn.BatchNorm2d(4)
     bn.running_mean.fill_(float(rank + 1)), bn.running_var.fill_(3.0 * (rank + 1))
-    assert D.broadcast_buffers(bn) == 2
+    bn.num_batches_tracked.fill_(7 * (rank + 1))
+    assert D.broadcast_buffers(bn) == 3  # running_mean, running_var and the integer num_batches_tracked (DDP sends all)
     assert torch.equal(bn.running_mean, torch.ones(4)) and torch.equal(bn.running_var, torch.full((4,), 3.0))
+    assert int(bn.num_batches_tracked) == 7 and bn.num_batches_tracked.dtype == torch.int64
+    # 2d) a rank whose early hook never fires (its head got no gradient) still issues the same two collectives, in order
+    ob.zero()
+    ob.arm_early()
+    fired.clear()
+    dist.all_reduce = lambda t, **kw: (fired.append((t.numel(), kw.get("async_op", False))), orig(t, **kw))[1]
+    if rank == 0:
+        model(x).sum().backward()          # rank 0: normal backward, early slice from inside it
+    else:
+        model[0](x).sum().backward()       # rank 1: the head (model[2]) is not in this graph -> hook does not fire
+    ob.finish_overlapped()
+    dist.all_reduce = orig
+    assert [n for n, _ in fired] == [4 + 1, 3 * 4 * 9 + 4], fired
+    assert ob.early_fired_in_backward == (rank == 0)
     # 3) loss reduce to rank 0 and max-over-ranks timing
     red = D.reduce_loss_dict({"a": torch.tensor(float(rank + 1)), "b": torch.tensor(10.0 * (rank + 1))})
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
@@ -92,6 +107,83 @@ def test_two_rank_gloo():
     assert res["red"] == {"a": 1.5, "b": 15.0}
     assert abs(res["tmax"] - 0.2) < 1e-12
     assert res["nbytes"] == (3 * 4 * 9 + 4 + 4 + 1) * 4
+
+
+def _worker8(rank, world, port, out):
+    """World size 8 with BASELINE configs[4]'s bucket: ConvSegHead(768, 2, 1) = 10 619 137 + click PatchEmbed(3 -> 768, 14) = 452 352
+    trainable elements = 11.07 M (44.3 MB fp32)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from isegprobe_amd.core.utils import distributed as D
+    torch.set_num_threads(1)
+    assert D.init_distributed("gloo") and D.get_world_size() == world
+    n_img = 256 * 3 + 5  # a dataset that does not divide by 8: every rank gets ceil(n / 8) indices, the tail wraps around
+    shard = D.shard_indices(n_img)
+    head = torch.nn.Parameter(torch.zeros(2 * (768 * 768 * 9 + 768) + 768 + 1))
+    embed = torch.nn.Parameter(torch.zeros(3 * 14 * 14 * 768 + 768))
+    bucket = D.GradBucket([embed, head], early=[head])  # given in the model's order; the head is moved to the front
+    assert bucket.params[0] is head and bucket.flat.numel() == 11071489 and bucket.nbytes() == 44285956
+    bucket.zero()
+    bucket.arm_early()
+    # "backward": d/dhead = rank + 1, d/dembed = 10 (rank + 1); the head's gradient is accumulated first
+    (head.sum() * float(rank + 1) + embed.sum() * float(10 * (rank + 1))).backward()
+    bucket.check_bound()
+    bucket.finish_overlapped()
+    mean = sum(range(1, world + 1)) / world
+    ok = (bucket.early_fired_in_backward and torch.all(head.grad == mean).item() and torch.all(embed.grad == 10 * mean).item())
+    # one-shot fallback gives the same averages
+    bucket.zero()
+    (head.sum() * float(rank + 1) + embed.sum() * float(10 * (rank + 1))).backward()
+    bucket.all_reduce_mean()
+    ok = ok and torch.all(head.grad == mean).item() and torch.all(embed.grad == 10 * mean).item()
+    bn = torch.nn.BatchNorm2d(788)  # LoftUp(768)'s 788-channel BatchNorms
+    bn.running_mean.fill_(float(rank)), bn.num_batches_tracked.fill_(rank)
+    D.broadcast_buffers(bn)
+    ok = ok and float(bn.running_mean.abs().max()) == 0.0 and int(bn.num_batches_tracked) == 0
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (shard, bool(ok)))
+    D.synchronize()
+    if rank == 0:
+        out.put(gathered)
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_configs4_bucket():
+    """The first 8-GPU run must be a measurement, not a debug session: the rank-count-dependent host logic (shards, the
+    overlapped gradient all-reduce with the early slice, the one-shot fallback, the buffer broadcast) at world size 8 with
+    configs[4]'s 11.07 M-element bucket, on gloo."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, out)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = 256 * 3 + 5
+    shards = [r[0] for r in res]
+    assert all(r[1] for r in res)
+    assert all(len(s) == (n + 7) // 8 for s in shards)
+    flat = [i for s in shards for i in s]
+    assert set(flat) == set(range(n)) and len(flat) - n == 8 * ((n + 7) // 8) - n  # every image once, plus the wrapped tail
+
+
+def test_bench_eight_rank_train_dry_run():
+    """`python bench.py --gpus 8 --mode train --dry-run`: the self-spawned 8-rank launch path of the scaling bench (rendezvous,
+    barrier-bracketed region, max over ranks, ONE line from rank 0) on CPU + gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--mode", "train"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["mode"] == "train" and lines[0]["max_dt"] >= 0.08
 
 
 def test_single_process_noops():
