@@ -126,6 +126,95 @@ def upsampler_bytes(upsampler, C, h, w, H, W, e=2):
     return None
 
 
+# ---------------------------------------------------------------------------------------------- clock / power samples
+class Telemetry:
+    """Shader clock and socket power sampled on a host thread WHILE the timed region runs, so that a few-percent swing of
+    the headline between boxes or rounds is attributable (the head convolutions run at the socket's power limit: the clock
+    the chip holds there differs from device to device).  Source: the amdgpu hwmon files of the device torch runs on
+    (freq1_input = gfx clock in Hz, power1_average / power1_input in microwatts), else `rocm-smi --json` snapshots.
+    Reading a sysfs file costs microseconds and touches neither the GPU queue nor the timed thread."""
+
+    def __init__(self, period=0.1):
+        import threading
+        self.period, self.samples, self._stop, self._thr = period, [], threading.Event(), None
+        self.hwmon, self.source = self._find_hwmon(), None
+        self.source = "hwmon:" + self.hwmon if self.hwmon else "rocm-smi"
+
+    @staticmethod
+    def _find_hwmon():
+        import glob
+        cands = []
+        try:
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cands += glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+        except Exception:
+            pass
+        if not cands:
+            cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        for c in cands:
+            if os.path.exists(os.path.join(c, "freq1_input")):
+                return c
+        return None
+
+    def _read(self):
+        if self.hwmon:
+            out = {}
+            try:
+                out["sclk_mhz"] = int(open(os.path.join(self.hwmon, "freq1_input")).read()) / 1e6
+            except Exception:
+                pass
+            for f in ("power1_average", "power1_input"):
+                try:
+                    out["power_w"] = int(open(os.path.join(self.hwmon, f)).read()) / 1e6
+                    break
+                except Exception:
+                    continue
+            return out or None
+        try:
+            import subprocess
+            r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20)
+            card = next(iter(json.loads(r.stdout).values()))
+            out = {}
+            for k, v in card.items():
+                kl = k.lower()
+                if "sclk" in kl and "mhz" in str(v).lower():
+                    out["sclk_mhz"] = float(str(v).lower().replace("(", "").replace(")", "").replace("mhz", ""))
+                elif "power" in kl and "(w)" in kl:
+                    try:
+                        out["power_w"] = float(v)
+                    except Exception:
+                        pass
+            return out or None
+        except Exception:
+            return None
+
+    def __enter__(self):
+        import threading
+
+        def loop():
+            while not self._stop.is_set():
+                v = self._read()
+                if v:
+                    self.samples.append(v)
+                self._stop.wait(self.period if self.hwmon else 2.0)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thr.join(timeout=30)
+
+    def summary(self):
+        out = {"source": self.source, "samples": len(self.samples)}
+        for key in ("sclk_mhz", "power_w"):
+            v = [s[key] for s in self.samples if key in s]
+            if v:
+                out[key] = {"min": float(np.min(v)), "mean": float(np.mean(v)), "max": float(np.max(v))}
+        return out
+
+
 # ---------------------------------------------------------------------------------------------- in-region HIP-event timers
 class OpTimer:
     """HIP events (on the launch stream) around every call of the named callables during the timed steps."""
@@ -248,9 +337,10 @@ def loftup448_block(B=8, C=384, S=448, warm=2, iters=5):
     return {"workload": f"LoftUp(n_dim={C}) upsampler plugin alone, {S}x{S}, batch {B}, {h}x{h} LR tokens, inference stream (IEEE half)",
             "ms_per_batch": ms, "ms_per_image": ms / B, "images_per_sec": B / (ms * 1e-3),
             "mfma": {"achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS, "flops_per_batch": fl},
-            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_batch": by,
-                    "note": "minimal algorithmic bytes HW*(3*4 + 2C) + hw*(C+20)*2 per image: the algorithm is contraction-bound, "
-                            "the HBM fraction is what north_star's '60 % of HBM peak' would mean for it"}}
+            "min_bytes_per_batch": by,
+            "note": "contraction-bound as an algorithm (SURVEY.md 8(d)): its minimal traffic, HW*(3*4 + 2C) + hw*(C+20)*2 bytes per image, "
+                    f"is {gbs:.0f} GB/s at this rate -- HBM is not a bound here, so no HBM fraction is quoted (north_star's '60 % of HBM peak' "
+                    "describes the reference's materialised attention weights, 3.3 GB per image and layer)"}
 
 
 def size896_block(arch, upsampler, B=8, S=896, warm=2, iters=5):
@@ -311,11 +401,108 @@ def cfg3_block(S=896, warm=2, iters=5):
     assert out.shape == (2, 1, S, S) and torch.isfinite(out).all()
     D, L, hw = vit["embed_dim"], vit["depth"], (S // 14) ** 2
     mem = torch.cuda.max_memory_allocated() / 2 ** 30
-    del model, out
+    # the same click with LiFT's 128 x 128 map resized to 896 x 896 and convolved there (rounds 1-3; 1.6 GB per image in 16 bits)
+    from isegprobe_amd.core.model.heads import conv_heads
+    saved = conv_heads.CONV_OF_BILINEAR
+    conv_heads.CONV_OF_BILINEAR = False
+    try:
+        torch.cuda.reset_peak_memory_stats()
+        dt_old, out_old = _time_forward(model, image, points, 1, 3)
+        mem_old = torch.cuda.max_memory_allocated() / 2 ** 30
+    finally:
+        conv_heads.CONV_OF_BILINEAR = saved
+    diff = (out - out_old).abs().max().item()
+    del model, out, out_old
     torch.cuda.empty_cache()
-    return {"workload": f"{arch} + lift + ConvSegHead({D},2,1), {S}x{S}, batch 2 (image + mirrored copy = one click), forward-only",
+    return {"workload": f"{arch} + lift + ConvSegHead({D},2,1), {S}x{S}, batch 2 (image + mirrored copy = one click), forward-only; "
+                        "first head convolution through the resize (low-resolution GEMM + blend)",
             "ms_per_click": dt / iters * 1e3, "clicks_per_sec": iters / dt, "vit_flops_per_click": 2 * vit_flops(D, L, hw),
-            "steps": iters, "warmup": warm, "peak_mem_GiB": mem}
+            "steps": iters, "warmup": warm, "peak_mem_GiB": mem,
+            "materialised_route": {"ms_per_click": dt_old * 1e3, "peak_mem_GiB": mem_old, "max_abs_logit_diff_vs_default": diff}}
+
+
+def _time_forward(model, image, points, warm, iters):
+    with torch.no_grad():
+        for _ in range(warm):
+            model(image, points)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = model(image, points)["instances"]
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters, out
+
+
+def cfg0_block(B=32, S=448, warm=2, iters=5):
+    """BASELINE configs[0]'s model on the GPU: DINOv2-S/14 + bilinear upsampler + ConvSegHead(384,2,1), forward only.  The head's
+    first convolution runs THROUGH the bilinear plugin's resize (one [B*h*w, C] x [C, 9N] GEMM at low resolution + the blend
+    kernel, csrc/conv_bilinear.hip); `materialised_route` is the same step with the [B,S,S,C] map written and convolved
+    (rounds 1-3, ISEGPROBE_CONV_OF_BILINEAR=0)."""
+    from isegprobe_amd import hip_ops as ops
+    from isegprobe_amd.core.model.heads import conv_heads
+    arch = "dinov2_vits14"
+    D = VITS[arch]["embed_dim"]
+    model = build("bilinear", S, arch).cuda()
+    image, points = synthetic_batch(B, S, seed=448)
+    image, points = image.cuda(), points.cuda()
+    with OpTimer(ops, ("conv3x3_of_bilinear_blend",)) as t_blend:
+        dt, out = _time_forward(model, image, points, warm, iters)
+    assert out.shape == (B, 1, S, S) and torch.isfinite(out).all() and t_blend.pairs, "the through-the-resize route did not run"
+    blend_ms = float(np.mean(t_blend.times_ms()[-iters:]))
+    saved = conv_heads.CONV_OF_BILINEAR
+    conv_heads.CONV_OF_BILINEAR = False
+    try:
+        dt_old, out_old = _time_forward(model, image, points, warm, iters)
+    finally:
+        conv_heads.CONV_OF_BILINEAR = saved
+    diff = (out - out_old).abs().max().item()
+    h = S // 14
+    del model, out, out_old
+    torch.cuda.empty_cache()
+    out_bytes = B * S * S * D * 2.0
+    return {"workload": f"{arch} + bilinear + ConvSegHead({D},2,1), {S}x{S}, batch {B}, forward-only (BASELINE configs[0]'s model on the GPU)",
+            "images_per_sec": B / dt, "ms_per_step": dt * 1e3, "steps": iters, "warmup": warm,
+            "first_conv_through_resize": {"blend_launch_ms": blend_ms, "bound": "hbm", "algorithmic_bytes": out_bytes + B * h * h * 9 * D * 2.0,
+                                          "achieved": (out_bytes + B * h * h * 9 * D * 2.0) / (blend_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": (out_bytes + B * h * h * 9 * D * 2.0) / (blend_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "note": "blend kernel: writes the [B,S,S,N] half map once, reads the [B*h*w, 9N] tap planes; "
+                                                  "36 multiply-adds per output value instead of 9*C"},
+            "materialised_route": {"images_per_sec": B / dt_old, "ms_per_step": dt_old * 1e3, "max_abs_logit_diff_vs_default": diff}}
+
+
+def fp32_mode_block(arch, upsampler, B=32, S=448, iters=2):
+    """The NoC-identical mode (`evaluate.py --fp32`, core/model/precise.py: every contraction as three bf16 products with fp32
+    accumulation, everything between them in fp32) on the HEADLINE workload: what the configuration whose NoC equals the
+    reference's per object costs per step, next to the 16-bit path the headline is measured on.  `noc_16bit_vs_reference`
+    states what the 16-bit path gives up on the three dataset fixtures (tests/test_noc_dataset_gpu.py holds both)."""
+    model = build(upsampler, S, arch).cuda()
+    image, points = synthetic_batch(B, S, seed=1000)
+    image, points = image.cuda(), points.cuda()
+    torch.cuda.reset_peak_memory_stats()
+    with torch.no_grad():
+        ref16 = model(image, points)["instances"]
+        model.forward_fp32(image, points)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = model.forward_fp32(image, points)["instances"]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        dt16, _ = _time_forward(model, image, points, 1, 3)
+    diff = (out - ref16).abs()
+    mem = torch.cuda.max_memory_allocated() / 2 ** 30
+    del model, out, ref16
+    torch.cuda.empty_cache()
+    return {"workload": f"{arch} + {upsampler} + ConvSegHead, {S}x{S}, batch {B}, forward_fp32 (fp32-accurate: three bf16 products per contraction)",
+            "ms_per_step": dt * 1e3, "images_per_sec": B / dt, "x_16bit_path": dt / dt16, "ms_per_step_16bit_same_model": dt16 * 1e3,
+            "logits_16bit_minus_fp32_mode": {"max": diff.max().item(), "rms": diff.pow(2).mean().sqrt().item()},
+            "peak_mem_GiB": mem, "steps": iters,
+            "noc_16bit_vs_reference": {
+                "source": "tests/test_noc_dataset_gpu.py over tests/golden/noc_dataset*.npz (reference NoBRS evaluation, 20 clicks, flip + zoom-in)",
+                "grabcut_layout_bilinear_50_objects": {"NoC@80/85/90": {"reference = fp32 mode": [5.82, 8.22, 12.26], "16-bit path": [5.80, 8.22, 12.54]}, "objects_differing": 4},
+                "grabcut_layout_lift": {"NoC@85": {"reference = fp32 mode": 4.10, "16-bit path": 4.00}, "objects_differing": 1},
+                "grabcut_layout_loftup": {"NoC@80/85/90": {"reference = fp32 mode = 16-bit path": [2.68, 3.88, 5.84]}, "objects_differing": 0},
+                "sbd_layout_46_objects": {"NoC@80/85/90": {"reference = fp32 mode": [12.07, 17.07, 19.72], "16-bit path": [12.04, 17.07, 19.87]}, "objects_differing": 4}}}
 
 
 def train_block(arch, upsampler, B, S, sim_clicks=2, warm=2, iters=5):
@@ -346,10 +533,10 @@ def train_block(arch, upsampler, B, S, sim_clicks=2, warm=2, iters=5):
 
 
 # ---------------------------------------------------------------------------------------------- CPU baseline (oracle)
-def cpu_baseline(model_sd, size, upsampler, vit, seed, full=False):
+def cpu_baseline(model_sd, size, upsampler, vit, seed, quick=False):
     """The CPU oracle (kind "port": torch-CPU restatement of the reference path, pinned by the golden fixtures) on
     a bounded sample of the same workload, on this box's host cores: batch 1 (median of 3 runs, per-stage split) and
-    batch 8 (one run; three with --cpu-baseline-full), SURVEY.md 8(d).  A reported baseline, not the target."""
+    batch 8 (median of 3 runs; one with --cpu-baseline-quick), SURVEY.md 8(d).  A reported baseline, not the target."""
     import torch.nn.functional as F
     from oracle import model as omodel
     from oracle import upsamplers as ups
@@ -389,14 +576,15 @@ def cpu_baseline(model_sd, size, upsampler, vit, seed, full=False):
     r1 = np.array([one(1) for _ in range(3)])
     tot1 = r1.sum(1)
     med = int(np.argsort(tot1)[1])
-    r8 = np.array([one(8) for _ in range(3 if full else 1)])
+    r8 = np.array([one(8) for _ in range(1 if quick else 3)])
     tot8 = np.sort(r8.sum(1))[len(r8) // 2]
     names = ("click_maps+normalize", "featurizer", "upsampler(+resize)", "head")
-    return {"value": 1.0 / tot1[med], "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": 1.0 / tot1[med], "unit": "images/sec", "cores": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"batch 1: median of 3 runs of one {size}x{size} image through the same path ({tot1[med]:.1f} s each, fp32); "
-                      f"batch 8: {'median of 3 runs' if full else 'one run'} ({tot8:.1f} s)",
+                      f"batch 8: {'one run' if quick else 'median of 3 runs'} ({tot8:.1f} s)",
             "batch1_runs_s": [round(float(v), 2) for v in tot1],
             "batch1_stage_s": {k: round(float(v), 3) for k, v in zip(names, r1[med])},
+            "batch8_runs_s": [round(float(v), 2) for v in r8.sum(1)],
             "batch8_images_per_sec": 8.0 / float(tot8),
             "batch8_stage_s": {k: round(float(v), 3) for k, v in zip(names, r8[int(np.argsort(r8.sum(1))[len(r8) // 2])])}}
 
@@ -484,7 +672,8 @@ def run_forward(args):
         with OpTimer(ops, ("conv3x3", "conv3x3_folded_affine", "conv3x3_relu_classifier")) as t_conv, \
                 OpTimer(ops, ("attention_packed_qkv",)) as t_att, \
                 OpTimer(model.backbone, ("forward_fused_clicks",)) as t_vit, \
-                OpTimer(stack if fused_jbu else model.upsampler, ("forward_stages",) if fused_jbu else ("forward",)) as t_up:
+                OpTimer(stack if fused_jbu else model.upsampler, ("forward_stages",) if fused_jbu else ("forward",)) as t_up, \
+                Telemetry() as tele:
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 out = model(image, points)["instances"]
@@ -552,6 +741,13 @@ def run_forward(args):
             line["alt_head_bf16"] = {"value": B * args.steps / dt_bf16, "unit": "images/sec", "ms_per_step": dt_bf16 / args.steps * 1e3,
                                      "note": "same steps with ISEGPROBE_HEAD_F16=0 (bf16 head convolutions: bench-workload logit "
                                              "error 8.5e-3 max / 1.7e-3 rms instead of 5.7e-3 / 1.2e-3)"}
+        line["telemetry_timed_region"] = tele.summary()  # shader clock / socket power while the timed steps ran
+        if traffic is not None:
+            # mean over the step's two launches, like `traffic`: both read a [B,S,S,C] 16-bit map once, the first writes one
+            # (the second's output is the classifier's partial sums, 4 bytes x slots per pixel)
+            alg = B * S * S * (2.0 * xin.shape[3] * 2 + Wt.shape[0] * 2 + 4.0 * ops._lib.lib().isp_conv3x3_partial_slots(Wt.shape[0])) / 2
+            line["roofline"]["algorithmic_bytes_per_launch"] = alg
+            line["roofline"]["traffic_over_algorithmic"] = traffic / alg
         pk = _pmc_traffic("r01_peaks.json")
         if pk is not None:
             rnd = pk["mfma_bf16_16x16x32_register_loop_tflops"]["random"]
@@ -616,14 +812,15 @@ def run_forward(args):
             del out
             torch.cuda.empty_cache()
             for key, fn in (("loftup448", lambda: loftup448_block()), ("size896", lambda: size896_block(args.arch, args.upsampler)),
-                            ("cfg3_vitl14_lift896", lambda: cfg3_block()),
-                            ("cfg2_train_vits14_loftup224", lambda: train_block("dinov2_vits14", "loftup", 8, 224))):
+                            ("cfg0_bilinear448", lambda: cfg0_block()), ("cfg3_vitl14_lift896", lambda: cfg3_block()),
+                            ("cfg2_train_vits14_loftup224", lambda: train_block("dinov2_vits14", "loftup", 8, 224)),
+                            ("fp32_mode", lambda: fp32_mode_block(args.arch, args.upsampler, B, S))):
                 try:
                     line[key] = fn()
                 except Exception as exc:
                     line[key] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, S, args.upsampler, vit, seed=1000, full=args.cpu_baseline_full)
+            line["cpu_baseline"] = cpu_baseline(sd, S, args.upsampler, vit, seed=1000, quick=args.cpu_baseline_quick)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
@@ -724,7 +921,7 @@ def main():
     ap.add_argument("--upsampler", default=None, help="forward: jbu_featup; train: loftup")
     ap.add_argument("--sim-clicks", type=int, default=0, help="train: simulated corrective clicks (no-grad forwards) per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="batch-8 CPU baseline as the median of 3 runs (slow)")
+    ap.add_argument("--cpu-baseline-quick", action="store_true", help="batch-8 CPU baseline from one run instead of the median of 3")
     ap.add_argument("--no-stages", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the loftup448 / size896 / cfg3_vitl14_lift896 blocks (north_star's other named numbers, BASELINE configs[3])")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region (bf16 head convolutions, alt_head_bf16)")

@@ -107,3 +107,57 @@ class DataParallelTrainer:
         self.bucket.finish_overlapped()  # head slice was issued inside backward; the rest + wait + /world here
         self.optim.step()
         return loss.detach()
+
+
+class EpochTrainer:
+    """The epoch loop of the reference's iSegTrainer (core/training/trainer.py:180-314: ``run`` / ``training``) around a
+    step object: for every epoch -- sampler.set_epoch, one optimisation step per batch of this rank's loader, the losses
+    reduced to rank 0 for the log, ``last_checkpoint.pth`` after every epoch and ``<epoch:03d>.pth`` on the
+    ``checkpoint_interval`` cadence ([[start_epoch, every], ...], train_cfg.yaml:23: the last entry whose start is <= the
+    epoch applies), then the MultiStepLR(milestones, gamma 0.1) scheduler (models/defaults.py:110-114) steps once.
+
+    ``stepper``: anything with ``.net`` (``get_state_dict_to_save`` / ``_config`` for the checkpoint writer), ``.optim`` and
+    ``.step(batch) -> 0-dim loss tensor`` -- ``DataParallelTrainer`` on the GPU.  Validation, tensorboard / wandb logging
+    and image dumps of the reference's loop are outside this path."""
+
+    def __init__(self, stepper, loader, checkpoints_path=None, lr_milestones=(17, 20), checkpoint_interval=((0, 3), (15, 1)),
+                 device=None, log=print, prefix=""):
+        self.stepper, self.loader, self.checkpoints_path = stepper, loader, checkpoints_path
+        self.checkpoint_interval = [tuple(x) for x in checkpoint_interval] if isinstance(checkpoint_interval, (list, tuple)) \
+            else checkpoint_interval
+        self.device, self.log, self.prefix = device, log, prefix
+        self.lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(stepper.optim, milestones=list(lr_milestones), gamma=0.1)
+        self.history = []  # (epoch, mean loss over the epoch on rank 0, learning rate)
+
+    def run(self, num_epochs, start_epoch=0):
+        for _ in range(start_epoch):  # resuming: the schedule continues where it stopped (train_cfg.yaml:33)
+            self.lr_scheduler.step()
+        for epoch in range(start_epoch, num_epochs):
+            self.training(epoch)
+        return self.history
+
+    def _interval(self, epoch):
+        ci = self.checkpoint_interval
+        return [x for x in ci if x[0] <= epoch][-1][1] if isinstance(ci, (list, tuple)) else ci
+
+    def training(self, epoch):
+        from ..utils.misc import save_checkpoint
+        sampler = getattr(self.loader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
+        total, n = 0.0, 0
+        for batch in self.loader:
+            if self.device is not None:
+                batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
+            loss = self.stepper.step(batch)
+            red = D.reduce_loss_dict({"overall": loss.detach().float()})
+            total, n = total + float(red["overall"]), n + 1
+        lr = self.stepper.optim.param_groups[0]["lr"]
+        if D.get_rank() == 0:
+            self.history.append((epoch, total / max(n, 1), lr))
+            self.log(f"Epoch {epoch}, training loss {total / max(n, 1):.4f}, lr {lr:.2e}, {n} steps")
+            if self.checkpoints_path is not None:
+                save_checkpoint(self.stepper.net, self.checkpoints_path, prefix=self.prefix, epoch=None, verbose=False)
+                if epoch % self._interval(epoch) == 0:
+                    save_checkpoint(self.stepper.net, self.checkpoints_path, prefix=self.prefix, epoch=epoch, verbose=False)
+        self.lr_scheduler.step()

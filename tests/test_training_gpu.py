@@ -457,3 +457,32 @@ def test_simulated_click_forwards_share_guidance_work(up, monkeypatch):
         print(up, la, lb, np.abs(ya - yb).max())
         # (train-mode BatchNorm sums its batch statistics with float atomics: bf16-sized run-to-run noise in LoftUp's maps)
         assert abs(la - lb) <= 1e-3 * abs(la) and np.abs(ya - yb).max() <= 3e-2
+
+
+def test_train_py_on_sbd_tree(tmp_path):
+    """`python train.py --dataset <SBD root>`: the reference's loop (train.py:13-27 -> trainer.py:180-314) end to end on the
+    committed SBD-layout tree -- SBD reader, augmentation, MultiPointSampler clicks, the HIP train step (LoftUp probe, clicks
+    before the backbone), LR milestone, checkpoint cadence -- and the checkpoint it writes loads back through load_is_model."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import GOLDEN
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ckpt = str(tmp_path / "ckpts")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "train.py"), "--dataset", os.path.join(GOLDEN, "datasets", "sbd"), "--epochs", "2",
+           "--epoch-len", "4", "--batch", "2", "--size", "112", "--workers", "0", "--model", "dinov2/patch-embed_loftup", "--save", ckpt,
+           "training_params.lr_milestones=[1]", "training_params.checkpoint_interval=[[0,1]]"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    epochs = re.findall(r"Epoch (\d+), training loss ([0-9.eE+-]+|nan|inf), lr ([0-9.eE+-]+), (\d+) steps", out.stdout)
+    assert [(e[0], e[3]) for e in epochs] == [("0", "2"), ("1", "2")], out.stdout[-2000:]
+    assert all(np.isfinite(float(e[1])) and float(e[1]) > 0 for e in epochs)
+    assert abs(float(epochs[0][2]) - 5e-5) < 1e-9 and abs(float(epochs[1][2]) - 5e-6) < 1e-9
+    assert sorted(os.listdir(ckpt)) == ["000.pth", "001.pth", "last_checkpoint.pth"]
+    import isegprobe_amd
+    from isegprobe_amd.core.inference.utils import load_is_model
+    isegprobe_amd.install_as_core()
+    model = load_is_model(os.path.join(ckpt, "last_checkpoint.pth"), torch.device("cuda"))
+    assert type(model.upsampler).__name__ == "LoftUpUpsampler" and model.backbone.feats_injection_mode == "before_backbone"

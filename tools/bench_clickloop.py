@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-click time of the NoC loop (flip pair, zoom-in at S^2) for one synthetic image: device clicker,
-guidance cache on/off via ISEGPROBE_NO_GUIDANCE_CACHE.  usage: bench_clickloop.py [upsampler] [S]"""
+guidance cache on/off via ISEGPROBE_NO_GUIDANCE_CACHE.  usage: bench_clickloop.py [upsampler] [S] [fp32]
+(a third argument "fp32" routes the predictor through model.forward_fp32, the NoC-identical checking mode: evaluate.py --fp32)"""
 import logging
 import os
 import sys
@@ -18,6 +19,9 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 448
 params = {"jbu_featup": {"backbone_type": "dinov2"}, "loftup": {"upsampler_path": None, "n_dim": 384},
           "lift": {"lift_path": None, "n_dim": 384, "patch": 14}}.get(up)
 model = seeded_(build_model(up, vit=S14, img=(S, S), upsampler_params=params), 1).cuda().eval()
+FP32 = len(sys.argv) > 3 and sys.argv[3] == "fp32"
+if FP32:
+    model.forward = model.forward_fp32
 rng = np.random.default_rng(0)
 image = rng.integers(0, 255, (480, 640, 3), dtype=np.uint8)
 yy, xx = np.mgrid[:480, :640]
@@ -32,5 +36,5 @@ for rep in range(3):
     clicks, ious, _ = evaluate_sample(image, gt, predictor, max_iou_thr=1.01, pred_thr=0.5, max_clicks=20)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-print(f"{up} {S}x{S} graphs={os.environ.get('ISEGPROBE_HIP_GRAPHS', '0')} cache={'off' if os.environ.get('ISEGPROBE_NO_GUIDANCE_CACHE') else 'on'}: "
+print(f"{up} {S}x{S} {'fp32-accurate mode ' if FP32 else ''}graphs={os.environ.get('ISEGPROBE_HIP_GRAPHS', '0')} cache={'off' if os.environ.get('ISEGPROBE_NO_GUIDANCE_CACHE') else 'on'}: "
       f"{dt / len(ious) * 1e3:.2f} ms/click over {len(ious)} clicks")

@@ -11,9 +11,13 @@ Hydra config + a model script; this one keeps the same roles with plain argument
 `--model` names one of the reference's model scripts (models/sbd/<family>/<script>.py: backbone, click-injection
 mode, click encoder, upsampler and head exactly as configured there).  Each rank builds the same model (frozen
 backbone + frozen upsampler, trainable embed_coords + head), draws its own shard of the (synthetic, SBD-shaped) minibatch, and takes optimisation steps
-with ONE flat-bucket gradient all-reduce per step (core/training/trainer.py).  Real datasets are
-outside the dense-feature path: plug any iterable of
-{"images" [B,3,H,W], "instances" [B,1,H,W], "points" [B,2P,3]} batches into DataParallelTrainer."""
+with ONE flat-bucket gradient all-reduce per step (core/training/trainer.py).
+
+    python train.py --dataset /data/SBD/dataset --epochs 20 --save ckpts/    # the reference's loop on an SBD tree
+    python train.py +exp.model_path=models/sbd/dinov2/patch-embed_loftup.py +datasets.SBD_PATH=/data/SBD/dataset
+
+With --dataset the step runs inside the reference's epoch loop (core/training/trainer.py::EpochTrainer: SBD train reader,
+MultiPointSampler clicks, per-rank shards, MultiStepLR milestones, last_checkpoint.pth + NNN.pth cadence; core/data/)."""
 import argparse
 import os
 import sys
@@ -92,6 +96,14 @@ def main():
     ap.add_argument("--injection", default=None, help="override feats_injection_mode (before_backbone | after_backbone)")
     ap.add_argument("--lr", type=float, default=5e-5)
     ap.add_argument("--save", default=None, help="directory for a reference-format last_checkpoint.pth (rank 0)")
+    ap.add_argument("--dataset", default=None,
+                    help="SBD root (img/, inst/, train.txt): train on it for --epochs epochs instead of synthetic batches "
+                         "(reference: DATASETS.SBD_PATH of configs/main_cfg.yaml; Hydra form +datasets.SBD_PATH=<root>)")
+    ap.add_argument("--epochs", type=int, default=None, help="with --dataset: training_params.epochs (train_cfg.yaml:21)")
+    ap.add_argument("--epoch-len", type=int, default=-1, help="with --dataset: samples per epoch (-1: the dataset's size)")
+    ap.add_argument("--workers", type=int, default=None, help="with --dataset: DataLoader workers (dataloader.workers)")
+    ap.add_argument("--samples-scores", default=None,
+                    help="with --dataset: the sampling-weights pickle (reference ./assets/sbd_samples_weights.pkl, gamma 1.25)")
     ap.add_argument("--eval-frozen-bn", action="store_true",
                     help="keep the frozen upsampler's BatchNorm in eval mode (the reference's net.train() uses batch statistics)")
     from isegprobe_amd.core.utils.overrides import TRAIN_DEFAULTS, apply_overrides, split_overrides
@@ -109,8 +121,21 @@ def main():
             args.size = int(cs[0] if isinstance(cs, (list, tuple)) else cs)
         if "training.local_rank" in given:  # the reference reads the rank's device from YAML only (train_cfg.yaml:36)
             os.environ.setdefault("LOCAL_RANK", str(cfg["training"]["local_rank"]))
+        if "datasets.SBD_PATH" in given:
+            args.dataset = str(cfg["datasets"]["SBD_PATH"])
+        tp = cfg["training_params"]
+        args.epochs = args.epochs if args.epochs is not None else int(tp["epochs"])
+        args.workers = args.workers if args.workers is not None else int(cfg["dataloader"]["workers"])
+        args.lr_milestones, args.checkpoint_interval = list(tp["lr_milestones"]), [tuple(x) for x in tp["checkpoint_interval"]]
+        args.num_max_points, args.seed = int(tp["num_max_points"]), int(cfg["training"]["seed"])
         if D_rank0():
             print(f"experiment '{cfg['exp']['name']}', model script {args.model}")
+    for k, v in (("lr_milestones", TRAIN_DEFAULTS["training_params"]["lr_milestones"]), ("num_max_points", 24), ("seed", 0),
+                 ("checkpoint_interval", [tuple(x) for x in TRAIN_DEFAULTS["training_params"]["checkpoint_interval"]])):
+        if not hasattr(args, k):
+            setattr(args, k, v)
+    args.epochs = args.epochs if args.epochs is not None else TRAIN_DEFAULTS["training_params"]["epochs"]
+    args.workers = args.workers if args.workers is not None else TRAIN_DEFAULTS["dataloader"]["workers"]
 
     from isegprobe_amd.core.model import iSegProbeModel
     from isegprobe_amd.core.training.trainer import DataParallelTrainer
@@ -122,6 +147,25 @@ def main():
     model = iSegProbeModel(**model_configs(args.model, args.size, args.arch, args.upsampler, args.injection),
                            use_disks=True, norm_radius=5, with_prev_mask=True).cuda()
     trainer = DataParallelTrainer(model, lr=args.lr, frozen_bn_batch_stats=not args.eval_frozen_bn)
+    if args.dataset:
+        # the reference's loop (trainer.py:180-314): epochs over the SBD train split, clicks from MultiPointSampler, this
+        # rank's shard of every epoch, LR milestones and checkpoint cadence of train_cfg.yaml
+        import random
+        from isegprobe_amd.core.data import SBDTrainSet, make_loader
+        from isegprobe_amd.core.training.trainer import EpochTrainer
+        if args.seed >= 0:
+            random.seed(args.seed + D.get_rank()), np.random.seed(args.seed + D.get_rank())
+        trainset = SBDTrainSet(args.dataset, crop_size=(args.size, args.size), num_max_points=args.num_max_points,
+                               samples_scores_path=args.samples_scores, epoch_len=args.epoch_len)
+        loader = make_loader(trainset, args.batch, workers=args.workers, seed=max(args.seed, 0))
+        model.save_cfg = {"embed_coords": True, "backbone": False, "upsampler": False, "head": True}  # as the model scripts do
+        if D.get_rank() == 0:
+            print(f"model {args.model}  world {D.get_world_size()}  SBD train: {len(trainset)} samples per epoch, "
+                  f"{len(loader)} steps per rank and epoch at batch {args.batch}, {args.epochs} epochs")
+        EpochTrainer(trainer, loader, checkpoints_path=args.save, lr_milestones=args.lr_milestones,
+                     checkpoint_interval=args.checkpoint_interval, device="cuda").run(args.epochs)
+        D.synchronize()
+        return
     rng = np.random.default_rng(100 + D.get_rank())
     if D.get_rank() == 0:
         print(f"model {args.model}  world {D.get_world_size()}  trainable bucket {trainer.bucket.nbytes() / 1e6:.1f} MB  "
