@@ -441,6 +441,10 @@ int isp_adaptive_conv7_nhwc_f32(const float* hr, const float* k49, float* out, i
 int isp_split_bf16x3(const float* x, long ld_in, void* out_bf16, long rows, int K, int Kpad, int weights_layout, int act,
                      float scale, void* stream);
 int isp_softmax_rows_f32(float* x, long rows, int cols, long ld, void* stream);
+/* Self-attention of the ViT trunk in exact fp32 (the checking mode's form of dinov2/layers/attention.py:54-71):
+ * out [B*L, heads*64] = softmax((q * scale) k^T) v per (batch, head) from the packed fp32 qkv [B*L, 3*heads*64], head_dim 64,
+ * one launch (flash form on the f32-input MFMA, exact fp32 multiply-adds, fp32 online softmax). */
+int isp_attention_packed_f32(const float* qkv, float* out, int B, int L, int heads, float scale, void* stream);
 
 /* ---- On-box roofline probes (diagnostics; tools/peaks.py): a register-resident v_mfma_f32_16x16x32_bf16 loop
  * (blocks x 4 waves x iters x 16 MFMAs; operands read once from a 64 Ki-element bf16 seed: zeros vs random bits show the

@@ -77,6 +77,7 @@ SIGNATURES = {
     "isp_adaptive_conv7_nhwc_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "isp_split_bf16x3": [_vp, _l, _vp, _l, _i, _i, _i, _i, _f, _vp],
     "isp_softmax_rows_f32": [_vp, _l, _i, _l, _vp],
+    "isp_attention_packed_f32": [_vp, _vp, _i, _i, _i, _f, _vp],
     "isp_probe_mfma_bf16": [_vp, _vp, _i, _i, _vp],
     "isp_probe_mfma_bf16_32x32": [_vp, _vp, _i, _i, _vp],
     "isp_probe_copy": [_vp, _vp, _l, _vp],

@@ -21,6 +21,39 @@ def _pack_conv(weight):
     return weight.detach().permute(0, 2, 3, 1).reshape(n, -1).to(BF16).contiguous()
 
 
+# ---- test hook: ReLU masks imposed from outside (tests/test_training_gpu.py).  A 16-bit forward puts a pre-activation that is
+# within rounding noise of zero on either side of it, and one flipped mask entry moves a weight-gradient sum by its whole
+# term; comparing gradients against the fp32 oracle WITH THE ORACLE'S MASKS separates that (legitimate) effect from errors of
+# the backward kernels.  The list holds {0,1}-valued [B,H,W,N] tensors in backward order; each conv + ReLU node of the head
+# takes the next one instead of (its own output > 0).  None outside the tests.
+_RELU_MASKS = None
+
+
+class impose_relu_masks:
+    def __init__(self, masks_in_backward_order):
+        self.masks = list(masks_in_backward_order)
+
+    def __enter__(self):
+        global _RELU_MASKS
+        _RELU_MASKS = self.masks
+        return self
+
+    def __exit__(self, *exc):
+        global _RELU_MASKS
+        _RELU_MASKS = None
+
+
+def _imposed_mask(y):
+    if not _RELU_MASKS:
+        return None
+    m = _RELU_MASKS.pop(0).to(device=y.device, dtype=y.dtype)
+    if m.shape[:-1] == y.shape[:-1] and m.shape[-1] < y.shape[-1]:  # channel-padded maps (LiFT): the padding stays masked
+        m = torch.nn.functional.pad(m, (0, y.shape[-1] - m.shape[-1]))
+    if m.shape != y.shape:
+        raise RuntimeError(f"imposed ReLU mask {tuple(m.shape)} does not fit the node's output {tuple(y.shape)}")
+    return m.contiguous()
+
+
 class Conv3x3ReluFn(torch.autograd.Function):
     """relu(conv3x3(x) + bias): x [B,H,W,C] bf16 NHWC, weight [N,C,3,3] fp32 -> [B,H,W,N] bf16."""
 
@@ -33,7 +66,8 @@ class Conv3x3ReluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, y, weight = ctx.saved_tensors
-        g, db = ops.relu_mask_colsum(gy.contiguous(), y)
+        m = _imposed_mask(y)
+        g, db = ops.relu_mask_colsum(gy.contiguous(), y if m is None else m)
         dx, dweight = _conv3x3_grads(x, g, weight, ctx.needs_input_grad[0])
         return dx, dweight, db
 
@@ -71,6 +105,10 @@ class Conv3x3ReluClassifierFn(torch.autograd.Function):
         x, y, weight, cls_weight = ctx.saved_tensors
         wc = cls_weight.detach().float().reshape(-1).contiguous()
         g, dwc, dbc, db = ops.classifier_bwd(gl.float().reshape(-1), y, wc, want_dx_colsum=True)
+        m = _imposed_mask(y)
+        if m is not None:  # (test hook) the pre-activation gradient gl (x) wc under the imposed mask instead of (y > 0)
+            gfull = (gl.float().reshape(-1, 1) * wc.reshape(1, -1)).to(y.dtype).view_as(y)
+            g, db = ops.relu_mask_colsum(gfull.contiguous(), m)
         dx, dweight = _conv3x3_grads(x, g, weight, ctx.needs_input_grad[0])
         return dx, dweight, db, dwc.view_as(cls_weight), dbc.view(1)
 

@@ -23,6 +23,12 @@ from ..._lib import EP_BIAS_F32, EP_TOKENS_F32, IspError
 from .featurizers.DINOv2 import LN_EPS
 
 
+import os
+
+# ISEGPROBE_FP32_ATTENTION=split: the trunk's attention as per-(batch, head) split-bf16 GEMMs + a softmax pass (rounds 1-3)
+_FUSED_ATTENTION = os.environ.get("ISEGPROBE_FP32_ATTENTION", "fused") != "split"
+
+
 class _WeightSplits:
     """[whi | wlo | whi] images of the parameters, rebuilt when a parameter changes (data pointer / version)."""
 
@@ -54,6 +60,8 @@ def _residual(x, h, w3, bias, gamma, act=None):
 
 def _attention(qkv, B, L, heads, scale):
     """softmax(q k^T * scale) v per (batch, head) from the packed fp32 qkv [B*L, 3*heads*64] (attention.py:54-71)."""
+    if _FUSED_ATTENTION:  # one launch per block: flash form on the f32-input matrix instruction (csrc/attention_f32.hip)
+        return ops.attention_packed_qkv_f32(qkv.contiguous(), B, L, heads, scale)
     D = heads * 64
     Lp = (L + 3) // 4 * 4  # GEMM output columns come in fours: zero key rows, masked out by the softmax
     out = torch.empty(B * L, D, device=qkv.device, dtype=torch.float32)
@@ -426,16 +434,33 @@ def forward_fp32(model, image, points):
             y = _loftup(up, cache, y, image)
         elif isinstance(up, JBUFeatUpUpsampler):
             y = _jbu(up, cache, y, image)
+        first_done = False
         if not isinstance(up, IdentityUpsampler) and tuple(y.shape[1:3]) != (H, W):
-            # BilinearUpsampler.forward (basic_upsamplers.py:28-33) / the model's resize of a learned upsampler's
-            # output to the image size (iseg_probe_model.py:120-129): bilinear, align_corners=True, on fp32 planes
-            planes = ops.resize_bilinear_nchw_f32(y.permute(0, 3, 1, 2).contiguous(), H, W)
-            y = planes.permute(0, 2, 3, 1).contiguous()
+            from .heads.conv_heads import CONV_OF_BILINEAR
+            n0 = head.convs[0].conv.out_channels if len(head.convs) else 0
+            if (save is None and CONV_OF_BILINEAR and len(head.convs) and head.kernel_size == 3 and y.shape[3] == head.convs[0].conv.in_channels
+                    and ops.conv3x3_of_bilinear_supported(y.shape[1], y.shape[2], H, W, n0, torch.float32)):
+                # resize + first 3x3 convolution as ONE operator, as on the 16-bit path (heads/conv_heads.py::forward_of_bilinear):
+                # the nine tap planes Z_t = y W_t^T at low resolution (three bf16 products, fp32 out), then their bilinear
+                # blend in fp32 (csrc/conv_bilinear.hip, exact fp32 arithmetic) -- the [B,H,W,C] fp32 map is never written
+                cw0 = head.convs[0].conv.weight
+                wz3 = _w3(cache, ("conv_of_bilinear", 0), lambda: cw0.permute(2, 3, 0, 1).reshape(9 * n0, cw0.shape[1]), cw0)
+                Bl, hl, wl, Cl = y.shape
+                z = _linear(y.reshape(-1, Cl), wz3, None)
+                y = ops.conv3x3_of_bilinear_blend(z, f32(head.convs[0].conv.bias), Bl, hl, wl, H, W, n0, relu=False, out_dtype=torch.float32)
+                first_done = True
+            else:
+                # BilinearUpsampler.forward (basic_upsamplers.py:28-33) / the model's resize of a learned upsampler's
+                # output to the image size (iseg_probe_model.py:120-129): bilinear, align_corners=True, on fp32 planes
+                planes = ops.resize_bilinear_nchw_f32(y.permute(0, 3, 1, 2).contiguous(), H, W)
+                y = planes.permute(0, 2, 3, 1).contiguous()
         Bh, Hh, Wh, C = y.shape
-        act = None
+        act = "relu" if first_done else None
         if save is not None:
             save.update(geom=(B, h, w, H, W), layer_in=[], lowres=(Hh, Wh) != (h, w))
         for j, layer in enumerate(head.convs):
+            if first_done and j == 0:
+                continue
             if save is not None:
                 save["layer_in"].append((y, act))  # pre-activation input of layer j and the activation applied on the way in
             cw_ = layer.conv.weight

@@ -1096,6 +1096,18 @@ def split3(x, weights=False, act=None, scale=1.0, K=None):
     return out
 
 
+def attention_packed_qkv_f32(qkv, B, L, heads, scale):
+    """softmax((q * scale) k^T) v per (batch, head) in exact fp32 from the packed fp32 qkv [B*L, 3*heads*64] -> fp32 [B*L, heads*64]
+    (csrc/attention_f32.hip: the fp32-accurate checking mode's attention, one launch)."""
+    _need(qkv, torch.float32, "qkv")
+    D = heads * 64
+    if qkv.shape != (B * L, 3 * D):
+        raise IspError(f"attention_packed_qkv_f32: qkv must be [{B * L}, {3 * D}]")
+    out = torch.empty(B * L, D, device=qkv.device, dtype=torch.float32)
+    check(_lib.lib().isp_attention_packed_f32(_p(qkv), _p(out), B, L, heads, float(scale), _stream()), "isp_attention_packed_f32")
+    return out
+
+
 def softmax_rows_(x, cols):
     """In-place softmax over the first `cols` columns of each row of a contiguous fp32 matrix; the rest becomes 0."""
     _need(x, torch.float32, "x")

@@ -77,7 +77,7 @@ def features_with_grad(image, points, w, cfg):
         up = cfg.get("upsampler", "bilinear")
         bn_train, stats = cfg.get("bn_train", False), cfg.get("bn_stats_out")  # net.train() semantics of the frozen upsamplers
         if up == "lift":
-            hr = ups.lift(feats, image, w, "upsampler.lift.", bn_train=bn_train, stats=stats)
+            hr = ups.lift(feats, image, w, "upsampler.lift.", bn_train=bn_train, stats=stats, capture=cfg.get("capture"))
         elif up == "loftup":
             hr = ups.loftup(feats, image, w, "upsampler.upsampler.", bn_train=bn_train, stats=stats)
         elif up == "jbu_featup":

@@ -40,7 +40,7 @@ def _bn_eval(x, w, prefix, eps=1e-5, train=False, stats=None):
 
 
 # --- LiFT (core/model/upsamplers/LiFT.py:47-122), eval-mode BatchNorm --------
-def lift(source, guidance, w, prefix="lift.", bn_train=False, stats=None):
+def lift(source, guidance, w, prefix="lift.", bn_train=False, stats=None, capture=None):
     """LiFTUpsampler.forward(source, guidance) = LiFT(imgs=guidance, x=source) (:145-146).
     Returns [B, C, 2h, 2w]."""
     import functools
@@ -63,8 +63,12 @@ def lift(source, guidance, w, prefix="lift.", bn_train=False, stats=None):
     x = torch.cat([x, i1], dim=1)
     x = F.relu(_bn_eval(F.conv2d(x, g("up1.conv_1.double_conv.0.weight"), None, padding=1),
                         ws, "up1.conv_1.double_conv.1."))
+    if capture is not None:  # (tests: the ReLU masks of the two DoubleConv layers, the only non-linearities on the source's path)
+        capture["lift_relu1"] = (x > 0).detach()
     x = F.relu(_bn_eval(F.conv2d(x, g("up1.conv_1.double_conv.3.weight"), None, padding=1),
                         ws, "up1.conv_1.double_conv.4."))
+    if capture is not None:
+        capture["lift_relu2"] = (x > 0).detach()
     return F.conv2d(x, g("outc.weight"), g("outc.bias"))  # :119
 
 

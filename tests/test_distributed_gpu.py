@@ -99,7 +99,7 @@ def test_two_rank_train_step(backend):
     cos = torch.nn.functional.cosine_similarity(g2, g1, dim=0).item()
     rel = (g2 - g1).norm().item() / g1.norm().item()
     print(f"rank-averaged vs whole-batch gradients: cos {cos:.6f} rel {rel:.3e}")
-    assert cos > 0.9999 and rel < 2e-2                # (tightened to the measured value in DESIGN.md section 6)
+    assert cos > 0.9999 and rel < 1e-5                # measured 9.7e-8 (fp32 atomics: summation order differs, values agree)
 
 
 def _rccl_single_rank(port, out):

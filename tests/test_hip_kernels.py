@@ -782,3 +782,19 @@ def test_conv3x3_of_bilinear_rejects_small_factors(ops):
     z = torch.zeros(32 * 32, 9 * 64, device="cuda", dtype=torch.float16)
     with pytest.raises(IspError):
         ops.conv3x3_of_bilinear_blend(z, None, 1, 32, 32, 64, 64, 64)
+
+
+@pytest.mark.parametrize("B,L,heads", [(2, 17, 2), (1, 257, 6), (2, 1025, 6), (3, 129, 1)])
+def test_attention_packed_f32_vs_torch(ops, B, L, heads):
+    """The checking mode's exact-fp32 attention (csrc/attention_f32.hip, attention.py:54-71) against torch in fp64: ragged
+    last key tile (L = 17, 129, 257, 1025), several query blocks per (batch, head), a score spike that moves the running maximum
+    late in the key sequence."""
+    torch.manual_seed(L)
+    D = heads * 64
+    qkv = torch.randn(B * L, 3 * D, device="cuda")
+    qkv[L - 2, D:D + 64] *= 6.0  # one key of (batch 0, head 0) far above the rest, in the last tile
+    out = ops.attention_packed_qkv_f32(qkv, B, L, heads, 64 ** -0.5)
+    q, k, v = (qkv.double().view(B, L, 3, heads, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = (torch.softmax((q * 64 ** -0.5) @ k.transpose(-1, -2), dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * L, D)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-6 * max(1.0, ref.abs().max().item()), err
