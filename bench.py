@@ -710,7 +710,7 @@ def run_forward(args):
         xin, Wt = t_conv.last_args[0], t_conv.last_args[1]
         conv_flops = 2.0 * xin.shape[0] * xin.shape[1] * xin.shape[2] * xin.shape[3] * 9 * Wt.shape[0]
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12
-        pmc = _pmc_traffic("r03_conv_pmc.json") or _pmc_traffic("r02_conv_pmc.json") or _pmc_traffic("r01_conv_pmc.json")
+        pmc = _pmc_traffic("r04_conv_pmc.json") or _pmc_traffic("r03_conv_pmc.json") or _pmc_traffic("r02_conv_pmc.json") or _pmc_traffic("r01_conv_pmc.json")
         traffic = None
         if pmc is not None and B == 32 and S == 448 and args.arch == "dinov2_vits14":
             traffic = pmc["derived"]["traffic_bytes_per_launch"]
@@ -734,7 +734,7 @@ def run_forward(args):
                          "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_note": "fabric bytes per launch from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE, separate --pmc passes "
-                                         "(profiles/r03_conv_pmc.json, else r02 / r01)",
+                                         "(profiles/r04_conv_pmc.json, else r03 / r02 / r01)",
                          "launch_ms": conv_ms, "flops_per_launch": conv_flops},
         }
         if dt_bf16 is not None:
@@ -791,7 +791,7 @@ def run_forward(args):
             ms = up_ms_seq or up_ms_in
             gbs = B * by / (ms * 1e-3) / 1e9
             up_traffic = None
-            allpmc = _pmc_traffic("r03_bench_pmc.json") or _pmc_traffic("r02_bench_pmc.json")
+            allpmc = _pmc_traffic("r04_bench_pmc.json") or _pmc_traffic("r03_bench_pmc.json") or _pmc_traffic("r02_bench_pmc.json")
             if allpmc is not None and args.upsampler == "jbu_featup" and B == 32 and S == 448 and args.arch == "dinov2_vits14":
                 # fabric bytes per step of the stage's kernels (4 profiled forwards: 1 warm-up + 3 steps)
                 up_traffic = sum(v["traffic_bytes_per_launch"] * v["FETCH_SIZE"]["launches"] / 4.0
@@ -803,7 +803,7 @@ def run_forward(args):
                                           "frac": gbs / HBM_PEAK_GBS, "ms_per_step": ms, "bytes_per_step": B * by,
                                           "traffic": up_traffic,
                                           "traffic_note": "fabric bytes per step summed over the stage's kernels, rocprofv3 --pmc "
-                                                          "passes of this program (profiles/r03_bench_pmc.json, else r02)",
+                                                          "passes of this program (profiles/r04_bench_pmc.json, else r03 / r02)",
                                           "note": "time = the stage run on its own (stages.*): inside the step its guidance-only half "
                                                   f"overlaps the ViT on a second stream (main-stream share {up_ms_in:.2f} ms)"
                                           if up_ms_seq and up_ms_in else "HIP events inside the timed steps"}

@@ -109,7 +109,9 @@ class iSegProbeModel(iSegBaseModel):
         main = torch.cuda.current_stream()
         side = getattr(self, "_side_stream", None)
         if side is None or side.device != image.device:
-            side = self._side_stream = torch.cuda.Stream(device=image.device)
+            # ISEGPROBE_SIDE_PRIO: HIP stream priority of the records' stream (torch: lower number = higher priority; the
+            # featurizer runs on the caller's stream at the default priority 0)
+            side = self._side_stream = torch.cuda.Stream(device=image.device, priority=int(os.environ.get("ISEGPROBE_SIDE_PRIO", "0")))
         side.wait_stream(main)
         p = self.backbone.patch_size
         with torch.cuda.stream(side):

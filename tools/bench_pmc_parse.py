@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise tools/bench_pmc.sh: per-kernel launch durations (kernel-stats) and fabric traffic (PMC passes) of bench.py's
-own launches -> profiles/<round>_bench_jbu448_b32_kernel_stats.csv, <round>_bench_pmc.json, <round>_conv_pmc.json (ROUND env, default r03)."""
+own launches -> profiles/<round>_bench_jbu448_b32_kernel_stats.csv, <round>_bench_pmc.json, <round>_conv_pmc.json (ROUND env, default r04)."""
 import csv
 import glob
 import json
@@ -9,7 +9,7 @@ import shutil
 import sys
 
 out = sys.argv[1] if len(sys.argv) > 1 else "profiles"
-R = os.environ.get("ROUND", "r03")
+R = os.environ.get("ROUND", "r04")
 
 
 def latest(pattern):
