@@ -92,6 +92,29 @@ class DataParallelTrainer:
         loss = self.loss_fn(output["instances"], gt_mask).mean()
         return loss, output
 
+    def validate(self, batch: Dict, num_iters=None):
+        """The validation branch of batch_forward (trainer.py:377-477 with validation=True, called from trainer.py:316-375):
+        the net in eval mode throughout, no gradients, the same simulated corrective clicks; returns the loss."""
+        self.net.eval()
+        image, gt_mask, points = batch["images"], batch["instances"], batch["points"]
+        prev_output = torch.zeros_like(image[:, :1], dtype=torch.float32)
+        self._sim_scope += 1
+        with torch.no_grad(), guidance_scope(("val_clicks", id(self), self._sim_scope)):
+            if num_iters is None:
+                num_iters = random.randint(0, self.max_num_next_clicks)
+            for click_indx in range(num_iters):
+                net_input = torch.cat((image, prev_output), dim=1) if self.net.with_prev_mask else image
+                prev_output = torch.sigmoid(self.net(net_input, points)["instances"])
+                points = get_next_points(prev_output, gt_mask, points, click_indx + 1)
+            net_input = torch.cat((image, prev_output), dim=1) if self.net.with_prev_mask else image
+            output = self.net(net_input, points)
+            loss = self.loss_fn(output["instances"], gt_mask).mean()
+        for m in self.net.modules():
+            gc = getattr(m, "_gcache", None)
+            if gc is not None:
+                gc.clear()
+        return loss.detach()
+
     def step(self, batch: Dict, num_iters=None):
         """One optimisation step; returns the (rank-local) loss as a 0-dim tensor."""
         self._train_mode()
@@ -117,12 +140,15 @@ class EpochTrainer:
     epoch applies), then the MultiStepLR(milestones, gamma 0.1) scheduler (models/defaults.py:110-114) steps once.
 
     ``stepper``: anything with ``.net`` (``get_state_dict_to_save`` / ``_config`` for the checkpoint writer), ``.optim`` and
-    ``.step(batch) -> 0-dim loss tensor`` -- ``DataParallelTrainer`` on the GPU.  Validation, tensorboard / wandb logging
-    and image dumps of the reference's loop are outside this path."""
+    ``.step(batch) -> 0-dim loss tensor`` -- ``DataParallelTrainer`` on the GPU.  With ``val_loader`` every epoch ends with the reference's
+    validation pass (trainer.py:316-375: eval mode, no gradients, mean loss).  Tensorboard / wandb logging, the AdaptiveIoU
+    train metric and image dumps of the reference's loop are outside this path."""
 
     def __init__(self, stepper, loader, checkpoints_path=None, lr_milestones=(17, 20), checkpoint_interval=((0, 3), (15, 1)),
-                 device=None, log=print, prefix=""):
+                 device=None, log=print, prefix="", val_loader=None):
         self.stepper, self.loader, self.checkpoints_path = stepper, loader, checkpoints_path
+        self.val_loader = val_loader  # with it (and a stepper that has .validate): trainer.py:316-375 after every epoch
+        self.val_history = []
         self.checkpoint_interval = [tuple(x) for x in checkpoint_interval] if isinstance(checkpoint_interval, (list, tuple)) \
             else checkpoint_interval
         self.device, self.log, self.prefix = device, log, prefix
@@ -134,7 +160,21 @@ class EpochTrainer:
             self.lr_scheduler.step()
         for epoch in range(start_epoch, num_epochs):
             self.training(epoch)
+            if self.val_loader is not None and hasattr(self.stepper, "validate"):
+                self.validation(epoch)
         return self.history
+
+    def validation(self, epoch):
+        """trainer.py:316-375: mean validation loss over this rank's shard of the validation loader, reduced to rank 0."""
+        total, n = 0.0, 0
+        for batch in self.val_loader:
+            if self.device is not None:
+                batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
+            red = D.reduce_loss_dict({"overall": self.stepper.validate(batch).float()})
+            total, n = total + float(red["overall"]), n + 1
+        if D.get_rank() == 0:
+            self.val_history.append((epoch, total / max(n, 1)))
+            self.log(f"Epoch {epoch}, validation loss: {total / max(n, 1):.4f}")
 
     def _interval(self, epoch):
         ci = self.checkpoint_interval

@@ -473,6 +473,7 @@ def test_train_py_on_sbd_tree(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     cmd = [sys.executable, os.path.join(root, "train.py"), "--dataset", os.path.join(GOLDEN, "datasets", "sbd"), "--epochs", "2",
            "--epoch-len", "4", "--batch", "2", "--size", "112", "--workers", "0", "--model", "dinov2/patch-embed_loftup", "--save", ckpt,
+           "--validate", "--val-len", "2",
            "training_params.lr_milestones=[1]", "training_params.checkpoint_interval=[[0,1]]"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -480,6 +481,8 @@ def test_train_py_on_sbd_tree(tmp_path):
     assert [(e[0], e[3]) for e in epochs] == [("0", "2"), ("1", "2")], out.stdout[-2000:]
     assert all(np.isfinite(float(e[1])) and float(e[1]) > 0 for e in epochs)
     assert abs(float(epochs[0][2]) - 5e-5) < 1e-9 and abs(float(epochs[1][2]) - 5e-6) < 1e-9
+    vals = re.findall(r"Epoch (\d+), validation loss: ([0-9.eE+-]+)", out.stdout)  # trainer.py:316-375 after every epoch
+    assert [v[0] for v in vals] == ["0", "1"] and all(np.isfinite(float(v[1])) and float(v[1]) > 0 for v in vals), out.stdout[-2000:]
     assert sorted(os.listdir(ckpt)) == ["000.pth", "001.pth", "last_checkpoint.pth"]
     import isegprobe_amd
     from isegprobe_amd.core.inference.utils import load_is_model

@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--epochs", type=int, default=None, help="with --dataset: training_params.epochs (train_cfg.yaml:21)")
     ap.add_argument("--epoch-len", type=int, default=-1, help="with --dataset: samples per epoch (-1: the dataset's size)")
     ap.add_argument("--workers", type=int, default=None, help="with --dataset: DataLoader workers (dataloader.workers)")
+    ap.add_argument("--validate", action="store_true", help="with --dataset: a validation pass over <root>/val.txt after every epoch "
+                                                            "(reference training_params.do_validation)")
+    ap.add_argument("--val-len", type=int, default=-1, help="with --validate: samples per validation pass (-1: the split's size)")
     ap.add_argument("--samples-scores", default=None,
                     help="with --dataset: the sampling-weights pickle (reference ./assets/sbd_samples_weights.pkl, gamma 1.25)")
     ap.add_argument("--eval-frozen-bn", action="store_true",
@@ -162,8 +165,13 @@ def main():
         if D.get_rank() == 0:
             print(f"model {args.model}  world {D.get_world_size()}  SBD train: {len(trainset)} samples per epoch, "
                   f"{len(loader)} steps per rank and epoch at batch {args.batch}, {args.epochs} epochs")
+        val_loader = None
+        if args.validate:  # training_params.do_validation (train_cfg.yaml:25): the val split through the same feed
+            valset = SBDTrainSet(args.dataset, crop_size=(args.size, args.size), num_max_points=args.num_max_points, split="val",
+                                 epoch_len=args.val_len)
+            val_loader = make_loader(valset, args.batch, workers=args.workers, seed=max(args.seed, 0), shuffle=False)
         EpochTrainer(trainer, loader, checkpoints_path=args.save, lr_milestones=args.lr_milestones,
-                     checkpoint_interval=args.checkpoint_interval, device="cuda").run(args.epochs)
+                     checkpoint_interval=args.checkpoint_interval, device="cuda", val_loader=val_loader).run(args.epochs)
         D.synchronize()
         return
     rng = np.random.default_rng(100 + D.get_rank())
