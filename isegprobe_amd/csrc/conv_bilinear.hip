@@ -12,13 +12,14 @@
 // the kernel below is the blend: 36 multiply-adds per output value instead of 9 C (= 3 456 at C = 384, 9 216 at C = 1024),
 // and the [B, H, W, C] map (4.9 GB at batch 32 x 448^2 x 384, 1.6 GB per image at 896^2 x 1024) never exists.
 //
-// Kernel: a workgroup owns a 16 x 16 patch of output pixels, one pixel per thread.  The source pixels its 18 x 18 tap
-// neighbourhood touches (<= FMAX x FMAX, checked by the launcher with the kernel's own fp32 coordinate arithmetic) are staged
-// per channel block in LDS as [q][tap][CB channels]; a thread keeps 12 row / column weights (tap validity folded in as zeros,
-// coordinates clamped so the addresses stay inside the staged footprint) and 12 row / column offsets in registers, reads
-// 16-byte channel groups (neighbouring pixels mostly share their corners: LDS broadcasts) and accumulates in fp32
-// (v_fma_mix_f32 takes the half operand as is).  Per channel block and CU the LDS port and the vector pipe are equally
-// loaded (4.6 k cycles each per 256 pixels x 64 channels); HBM sees the output map once, Z stays in L2 / Infinity Cache.
+// Kernels: a workgroup owns a 16 x 16 patch of output pixels.  The source pixels its 18 x 18 tap neighbourhood touches
+// (<= FMAX x FMAX, checked by the launcher with the kernel's own fp32 coordinate arithmetic) are staged per 64-channel block in LDS
+// as [q][tap][channels]; tap validity is folded into the blend weights as zeros with clamped coordinates, so border tiles run
+// the same code.  Two forms below: on the matrix pipe for half tap planes (the product path), on the vector pipe for fp32 ones
+// (the checking mode).  HBM sees the output map once (4.93 GB at batch 32 x 448^2 x 384: 1.70 ms; a plain resize kernel writing
+// the same map takes 1.71 ms, a broadcast multiply 1.30 ms), Z stays in L2 / Infinity Cache.
+#include <type_traits>
+
 #include "isp_common.h"
 
 namespace {
@@ -60,154 +61,38 @@ __device__ __host__ __forceinline__ void src_coord(int d, float s, int n_in, int
     l = f - (float)i0;
 }
 
-template <typename ZT, int OUT, bool RELU>
-__global__ __launch_bounds__(256, 3) void conv_bilinear_blend_kernel(const ZT* __restrict__ z, const float* __restrict__ bias,
-                                                                  void* __restrict__ out, int h, int w, int H, int W, int N,
-                                                                  float sy, float sx) {
-    constexpr int CB = ZTraits<ZT>::CB;
-    constexpr int QROW = 9 * CB * (int)sizeof(ZT);  // bytes of one staged source pixel: [tap][CB]
-    constexpr int QPITCH = QROW + 16;               // +16: consecutive source pixels start 4 banks apart (mod 64: 36, 8, 44, ...)
-    constexpr int PIECES = QROW / 16;               // 16-byte pieces per source pixel
-    constexpr int TAPB = CB * (int)sizeof(ZT);      // bytes per tap
-    __shared__ __attribute__((aligned(16))) char zs[FMAX * FMAX * QPITCH];
-
-    const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int Y0 = blockIdx.y * TPX, X0 = blockIdx.x * TPX;
-    // footprint of the tile's clipped 18 x 18 neighbourhood (block-uniform)
-    int qy_lo, qx_lo, fy, fx;
-    {
-        int i0, i1;
-        float l;
-        src_coord(max(Y0 - 1, 0), sy, h, i0, i1, l);
-        qy_lo = i0;
-        src_coord(min(Y0 + TPX, H - 1), sy, h, i0, i1, l);
-        fy = i1 - qy_lo + 1;
-        src_coord(max(X0 - 1, 0), sx, w, i0, i1, l);
-        qx_lo = i0;
-        src_coord(min(X0 + TPX, W - 1), sx, w, i0, i1, l);
-        fx = i1 - qx_lo + 1;
-    }
-    const int py = tid >> 4, px = tid & 15;
-    const int Y = Y0 + py, X = X0 + px;
-    const bool live = Y < H && X < W;
-    // per tap row / column: two LDS byte offsets and two weights (zero when the tap leaves the image)
-    int roff[3][2], coff[3][2];
-    float wy[3][2], wx[3][2];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        int i0, i1;
-        float l;
-        const int yy = Y + t - 1, xx = X + t - 1;
-        const bool vy = yy >= 0 && yy < H, vx = xx >= 0 && xx < W;
-        src_coord(min(max(yy, 0), H - 1), sy, h, i0, i1, l);
-        i0 = min(max(i0 - qy_lo, 0), fy - 1), i1 = min(max(i1 - qy_lo, 0), fy - 1);  // (dead threads of a partial tile stay in range)
-        roff[t][0] = i0 * fx * QPITCH, roff[t][1] = i1 * fx * QPITCH;
-        wy[t][0] = vy ? 1.f - l : 0.f, wy[t][1] = vy ? l : 0.f;
-        src_coord(min(max(xx, 0), W - 1), sx, w, i0, i1, l);
-        i0 = min(max(i0 - qx_lo, 0), fx - 1), i1 = min(max(i1 - qx_lo, 0), fx - 1);
-        coff[t][0] = i0 * QPITCH, coff[t][1] = i1 * QPITCH;
-        wx[t][0] = vx ? 1.f - l : 0.f, wx[t][1] = vx ? l : 0.f;
-    }
-    const size_t zrow = (size_t)9 * N;  // elements per source pixel in Z
-    const ZT* zb = z + ((size_t)b * h * w) * zrow;
-    const int nq = fy * fx;
-    const size_t opix = ((size_t)b * H + Y) * W + X;
-
-    for (int n0 = 0; n0 < N; n0 += CB) {
-        __syncthreads();  // previous block's reads are done
-        // the 36 corner addresses and weights are re-derived per channel block from these 24 values (hoisted out of the
-        // loop they cost 72 registers = one wave per SIMD)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                asm volatile("" : "+v"(roff[t][c]));
-                asm volatile("" : "+v"(coff[t][c]));
-                asm volatile("" : "+v"(wy[t][c]));
-                asm volatile("" : "+v"(wx[t][c]));
-            }
-        // ---- stage [q][tap][CB]: piece i of source pixel q = 16 bytes of tap i / (PIECES / 9)
-        for (int i = tid; i < nq * PIECES; i += 256) {
-            const int q = i / PIECES, pc = i - q * PIECES;
-            const int t = pc / (PIECES / 9), r = pc - t * (PIECES / 9);
-            const int qy = qy_lo + q / fx, qx = qx_lo + q % fx;
-            const ZT* src = zb + ((size_t)qy * w + qx) * zrow + (size_t)t * N + n0 + r * (16 / (int)sizeof(ZT));
-            *reinterpret_cast<uint4*>(zs + q * QPITCH + pc * 16) = *reinterpret_cast<const uint4*>(src);
-        }
-        __syncthreads();
-        float acc[CB];
-#pragma unroll
-        for (int c = 0; c < CB; ++c) acc[c] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const char* p = zs + roff[t / 3][c >> 1] + coff[t % 3][c & 1] + t * TAPB;
-                const float wv = wy[t / 3][c >> 1] * wx[t % 3][c & 1];
-                if constexpr (sizeof(ZT) == 2) {
-#pragma unroll
-                    for (int g = 0; g < CB / 8; ++g) {
-                        const f16x8_t v = *reinterpret_cast<const f16x8_t*>(p + g * 16);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[g * 8 + e] = fmaf((float)v[e], wv, acc[g * 8 + e]);
-                    }
-                } else {
-#pragma unroll
-                    for (int g = 0; g < CB / 4; ++g) {
-                        const float4 v = *reinterpret_cast<const float4*>(p + g * 16);
-                        acc[g * 4 + 0] = fmaf(v.x, wv, acc[g * 4 + 0]);
-                        acc[g * 4 + 1] = fmaf(v.y, wv, acc[g * 4 + 1]);
-                        acc[g * 4 + 2] = fmaf(v.z, wv, acc[g * 4 + 2]);
-                        acc[g * 4 + 3] = fmaf(v.w, wv, acc[g * 4 + 3]);
-                    }
-                }
-                // keep the groups in order: left alone all 288 fragment reads are hoisted in front of the multiply-adds (724
-                // spilled registers); the accumulators pass through an opaque asm so that a group's arithmetic cannot sink
-#pragma unroll
-                for (int e = 0; e < CB; ++e) asm volatile("" : "+v"(acc[e]));
-            }
-        }
-        if (live) {
-#pragma unroll
-            for (int g = 0; g < CB / 8; ++g) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v[e] = acc[g * 8 + e] + (bias ? bias[n0 + g * 8 + e] : 0.f);
-                    if (RELU) v[e] = fmaxf(v[e], 0.f);
-                }
-                store8<OUT>(out, opix * N + n0 + g * 8, v);
-            }
-        }
-    }
-}
-
-// ---- two-phase form of the same tile (the default): the blend is separable, a(p + t, q) = ay(Y + ty, qy) ax(X + tx, qx), so a
-// tile first combines the tap planes ALONG X at the source rows it touches,
+// ---- vector form (fp32 tap planes: the checking mode; ISEGPROBE_BLEND_FORM=3 for half).  The blend is separable,
+// a(p + t, q) = ay(Y + ty, qy) ax(X + tx, qx), so a tile first combines the tap planes ALONG X at the source rows it touches,
 //     U[ty][qy][X][n] = sum_tx [X + tx inside] sum_{qx in 2(X + tx)} ax(X + tx, qx) Z[qy][qx][(ty, tx)][n]      (6 multiply-adds),
-// into LDS (3 x fy x 16 entries per channel, one entry per thread), and then blends ALONG Y per output pixel,
-//     out[Y][X][n] = act(b[n] + sum_ty [Y + ty inside] sum_{qy in 2(Y + ty)} ay(Y + ty, qy) U[ty][qy][X][n])       (6 multiply-adds):
-// 12 multiply-adds through 12 LDS reads per output value instead of 36 through 36 (a tile's U entries are shared by its 16
-// rows), i.e. 3.8x less vector work and 2.3x less LDS traffic per tile than the one-phase kernel above -- which leaves the
-// kernel on the HBM write of the output map.  U is kept in the tap planes' precision (half on the product route, where it is
-// one more 2^-12 rounding; fp32 on the checking route).
+// into LDS (3 x fy x 16 entries per channel) and then blends ALONG Y per output pixel (6 more): 12 multiply-adds and LDS reads
+// per value instead of 36 (a tile's U entries serve its 16 rows).  A lane owns ONE 16-byte channel group (8 half / 4 fp32
+// channels) of an entry or pixel (the first forms gave a thread all 64 channels of a pixel: 3.13 ms one-phase, 2.17 ms two-phase,
+// against 1.90 ms for this one and 1.70 ms for the matrix-pipe form below, batch 32 x 448^2 x 384).  A thread = (group g of 32, octet o of 8); phase A computes column g % 16 of the U rows
+// g / 16, g / 16 + 2, .., phase B row g % 16 of the pixel columns g / 16, g / 16 + 2, ..: every address is a lane constant plus a
+// loop constant, and eight neighbouring lanes read / write one aligned 128-byte row, so
+//   * the output leaves as whole 128-byte lines (a thread-per-pixel store instruction touches 64 different lines: its address
+//     processing alone was a quarter of the kernel), U and Z reads are conflict-free without padding U's rows,
+//   * phase A keeps all 256 threads busy (144 entries at a 3 x 3 footprint used 2.25 of 4 waves),
+//   * a thread holds 8 accumulators instead of 64 (the opaque-asm fences of the first forms are not needed), and
+//   * the per-column / per-row blend weights and source indices are tile-wide tables in LDS (16 x 6 each), read as broadcasts.
 template <typename ZT, int OUT, bool RELU>
-__global__ __launch_bounds__(256, 3) void conv_bilinear_blend2_kernel(const ZT* __restrict__ z, const float* __restrict__ bias,
-                                                                      void* __restrict__ out, int h, int w, int H, int W, int N,
-                                                                      float sy, float sx, int zs_bytes) {
+__global__ __launch_bounds__(256) void conv_bilinear_blend3_kernel(const ZT* __restrict__ z, const float* __restrict__ bias,
+                                                                   void* __restrict__ out, int h, int w, int H, int W, int N,
+                                                                   float sy, float sx, int zs_bytes) {
     constexpr int CB = ZTraits<ZT>::CB;
     constexpr int ES = (int)sizeof(ZT);
+    constexpr int VEC = 16 / ES;                    // channels per lane
+    static_assert(CB / VEC == 8, "eight 16-byte groups per entry");
     constexpr int QROW = 9 * CB * ES, QPITCH = QROW + 16, PIECES = QROW / 16, TAPB = CB * ES;
-    constexpr int UPITCH = CB * ES + 16;  // bytes per (ty, qy, X) entry: 16 consecutive X start 4 banks apart (x36 / x68 dwords mod 64)
-    constexpr int VEC = 16 / ES;          // channels per 16-byte read
-    // dynamic LDS sized by the launcher for the largest footprint any tile of this geometry has (3 x 3 source pixels at x14:
-    // 31 KiB, five workgroups per CU; the 5 x 5 worst case would be 64 KiB)
+    constexpr int UROW = CB * ES;                   // 128 bytes per (ty, qy, X) entry, unpadded: two neighbouring entries = 64 banks
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const zs = lds;
     char* const us = lds + zs_bytes;
+    __shared__ float xw[TPX][6], yw[TPX][6];        // blend weights per tile column / row: [tap][corner], 0 where the tap leaves the image
+    __shared__ int xi[TPX][6], yi[TPX][6];          // ... and the corner's index inside the staged footprint
 
     const int tid = threadIdx.x;
+    const int o = tid & 7, g = tid >> 3;
     const int b = blockIdx.z;
     const int Y0 = blockIdx.y * TPX, X0 = blockIdx.x * TPX;
     int qy_lo, qx_lo, fy, fx;
@@ -223,72 +108,57 @@ __global__ __launch_bounds__(256, 3) void conv_bilinear_blend2_kernel(const ZT* 
         src_coord(min(X0 + TPX, W - 1), sx, w, i0, i1, l);
         fx = i1 - qx_lo + 1;
     }
-    // ---- phase-A role: entry (ty, qy, X) of U
-    const bool a_live = tid < 3 * fy * TPX;
-    const int a_ty = a_live ? tid / (fy * TPX) : 0;
-    const int a_r = tid - a_ty * fy * TPX;
-    const int a_qy = a_live ? a_r / TPX : 0, a_x = a_r % TPX;
-    int zoff[3][2];
-    float wx[3][2];
+    if (tid < 2 * TPX) {  // threads 0-15: column table, 16-31: row table
+        const bool col = tid < TPX;
+        const int c = col ? tid : tid - TPX;
+        const int base = (col ? X0 : Y0) + c, n_out = col ? W : H, n_in = col ? w : h, lo = col ? qx_lo : qy_lo, f = col ? fx : fy;
+        const float sc = col ? sx : sy;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        int i0, i1;
-        float l;
-        const int xx = X0 + a_x + t - 1;
-        const bool vx = xx >= 0 && xx < W;
-        src_coord(min(max(xx, 0), W - 1), sx, w, i0, i1, l);
-        i0 = min(max(i0 - qx_lo, 0), fx - 1), i1 = min(max(i1 - qx_lo, 0), fx - 1);
-        zoff[t][0] = (a_qy * fx + i0) * QPITCH + (a_ty * 3 + t) * TAPB;
-        zoff[t][1] = (a_qy * fx + i1) * QPITCH + (a_ty * 3 + t) * TAPB;
-        wx[t][0] = vx ? 1.f - l : 0.f, wx[t][1] = vx ? l : 0.f;
-    }
-    const int uw_off = ((a_ty * fy + a_qy) * TPX + a_x) * UPITCH;
-    // ---- phase-B role: output pixel (Y, X)
-    const int py = tid >> 4, px = tid & 15;
-    const int Y = Y0 + py, X = X0 + px;
-    const bool live = Y < H && X < W;
-    int uoff[3][2];
-    float wy[3][2];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        int i0, i1;
-        float l;
-        const int yy = Y + t - 1;
-        const bool vy = yy >= 0 && yy < H;
-        src_coord(min(max(yy, 0), H - 1), sy, h, i0, i1, l);
-        i0 = min(max(i0 - qy_lo, 0), fy - 1), i1 = min(max(i1 - qy_lo, 0), fy - 1);
-        uoff[t][0] = ((t * fy + i0) * TPX + px) * UPITCH, uoff[t][1] = ((t * fy + i1) * TPX + px) * UPITCH;
-        wy[t][0] = vy ? 1.f - l : 0.f, wy[t][1] = vy ? l : 0.f;
+        for (int t = 0; t < 3; ++t) {
+            int i0, i1;
+            float l;
+            const int d = base + t - 1;
+            const bool v = d >= 0 && d < n_out;
+            src_coord(min(max(d, 0), n_out - 1), sc, n_in, i0, i1, l);
+            i0 = min(max(i0 - lo, 0), f - 1), i1 = min(max(i1 - lo, 0), f - 1);
+            (col ? xw : yw)[c][2 * t] = v ? 1.f - l : 0.f, (col ? xw : yw)[c][2 * t + 1] = v ? l : 0.f;
+            (col ? xi : yi)[c][2 * t] = i0, (col ? xi : yi)[c][2 * t + 1] = i1;
+        }
     }
     const size_t zrow = (size_t)9 * N;
     const ZT* zb = z + ((size_t)b * h * w) * zrow;
-    const int nq = fy * fx;
-    const size_t opix = ((size_t)b * H + Y) * W + X;
+    const int nq = fy * fx, n_rows = 3 * fy;  // U rows R = ty * fy + qy, 16 entries (X) each
+    __syncthreads();                          // tables
+    // Lane-constant address parts, so that the inner loops are one ds_read_b128 + 8 multiply-adds per tap:
+    //   phase A: this lane's column X = g % 16 for every entry it handles (rows R = g / 16 + 2 j): Z address = rowA[j] + colA[k];
+    //   phase B: this lane's row py = g % 16 for every pixel it handles (columns g / 16 + 2 k): U address = rowB[j] + immediate.
+    const int ax = g & 15, ar0 = g >> 4;
+    int colA[6];
+    float wxa[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) colA[k] = xi[ax][k] * QPITCH + (k >> 1) * TAPB + o * 16, wxa[k] = xw[ax][k];
+    const int py = g & 15, bx0 = g >> 4;
+    int rowB[6];
+    float wyb[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) rowB[j] = (((j >> 1) * fy + yi[py][j]) * TPX + bx0) * UROW + o * 16, wyb[j] = yw[py][j];
+    const int Y = Y0 + py;
+    const size_t orow = (((size_t)b * H + Y) * W + X0 + bx0) * N + o * VEC;  // pixel (py, bx0); + 2 k N per step
 
-    auto accumulate = [&](float (&acc)[CB], const char* p, float wv) {
+    auto fma_group = [&](float (&acc)[VEC], const char* p, float wv) {
         if constexpr (ES == 2) {
+            const f16x8_t v = *reinterpret_cast<const f16x8_t*>(p);
 #pragma unroll
-            for (int g = 0; g < CB / 8; ++g) {
-                const f16x8_t v = *reinterpret_cast<const f16x8_t*>(p + g * 16);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[g * 8 + e] = fmaf((float)v[e], wv, acc[g * 8 + e]);
-            }
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf((float)v[e], wv, acc[e]);
         } else {
-#pragma unroll
-            for (int g = 0; g < CB / 4; ++g) {
-                const float4 v = *reinterpret_cast<const float4*>(p + g * 16);
-                acc[g * 4 + 0] = fmaf(v.x, wv, acc[g * 4 + 0]);
-                acc[g * 4 + 1] = fmaf(v.y, wv, acc[g * 4 + 1]);
-                acc[g * 4 + 2] = fmaf(v.z, wv, acc[g * 4 + 2]);
-                acc[g * 4 + 3] = fmaf(v.w, wv, acc[g * 4 + 3]);
-            }
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            acc[0] = fmaf(v.x, wv, acc[0]), acc[1] = fmaf(v.y, wv, acc[1]), acc[2] = fmaf(v.z, wv, acc[2]), acc[3] = fmaf(v.w, wv, acc[3]);
         }
-#pragma unroll
-        for (int e = 0; e < CB; ++e) asm volatile("" : "+v"(acc[e]));  // keep the six groups in order (see the kernel above)
     };
 
     for (int n0 = 0; n0 < N; n0 += CB) {
-        __syncthreads();  // the previous block's phase B is done with us, its phase A with zs
+        // (no barrier here: zs is free since the barrier behind the previous phase A, and us is written only behind the next one,
+        //  which every thread reaches after its previous phase B)
         for (int i = tid; i < nq * PIECES; i += 256) {
             const int q = i / PIECES, pc = i - q * PIECES;
             const int t = pc / (PIECES / 9), r = pc - t * (PIECES / 9);
@@ -297,48 +167,214 @@ __global__ __launch_bounds__(256, 3) void conv_bilinear_blend2_kernel(const ZT* 
             *reinterpret_cast<uint4*>(zs + q * QPITCH + pc * 16) = *reinterpret_cast<const uint4*>(src);
         }
         __syncthreads();
-        if (a_live) {  // phase A
-            float acc[CB];
+        // ---- phase A: U[R][X = ax] (this lane's channel group) for the rows R = ar0, ar0 + 2, ..
+        for (int R = ar0; R < n_rows; R += 2) {
+            const int ty = R / fy, qy = R - ty * fy;
+            const char* zr = zs + qy * fx * QPITCH + ty * 3 * TAPB;
+            float acc[VEC];
 #pragma unroll
-            for (int c = 0; c < CB; ++c) acc[c] = 0.f;
+            for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) accumulate(acc, zs + zoff[t][j], wx[t][j]);
-            char* up = us + uw_off;
-            if constexpr (ES == 2) {
-#pragma unroll
-                for (int g = 0; g < CB / 8; ++g)
-                    *reinterpret_cast<uint4*>(up + g * 16) = make_uint4(pack2h_sat(acc[g * 8], acc[g * 8 + 1]), pack2h_sat(acc[g * 8 + 2], acc[g * 8 + 3]),
-                                                                        pack2h_sat(acc[g * 8 + 4], acc[g * 8 + 5]), pack2h_sat(acc[g * 8 + 6], acc[g * 8 + 7]));
-            } else {
-#pragma unroll
-                for (int g = 0; g < CB / 4; ++g)
-                    *reinterpret_cast<float4*>(up + g * 16) = make_float4(acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]);
-            }
+            for (int k = 0; k < 6; ++k) fma_group(acc, zr + colA[k], wxa[k]);
+            char* up = us + (R * TPX + ax) * UROW + o * 16;
+            if constexpr (ES == 2)
+                *reinterpret_cast<uint4*>(up) = make_uint4(pack2h_sat(acc[0], acc[1]), pack2h_sat(acc[2], acc[3]), pack2h_sat(acc[4], acc[5]),
+                                                           pack2h_sat(acc[6], acc[7]));
+            else
+                *reinterpret_cast<float4*>(up) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
         __syncthreads();
-        {  // phase B
-            float acc[CB];
+        // ---- phase B: pixels (py, bx0 + 2 k): six U entries each, at immediate offsets from this lane's six row addresses
+        float bv[VEC];
 #pragma unroll
-            for (int c = 0; c < CB; ++c) acc[c] = 0.f;
+        for (int e = 0; e < VEC; ++e) bv[e] = bias ? bias[n0 + o * VEC + e] : 0.f;
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+        for (int k = 0; k < TPX / 2; ++k) {
+            float acc[VEC];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) accumulate(acc, us + uoff[t][i], wy[t][i]);
-            if (live) {
+            for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
 #pragma unroll
-                for (int g = 0; g < CB / 8; ++g) {
-                    float v[8];
+            for (int j = 0; j < 6; ++j) fma_group(acc, us + rowB[j] + 2 * k * UROW, wyb[j]);
+            if (Y < H && X0 + bx0 + 2 * k < W) {
+                const size_t at = orow + (size_t)2 * k * N + n0;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        v[e] = acc[g * 8 + e] + (bias ? bias[n0 + g * 8 + e] : 0.f);
-                        if (RELU) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    store8<OUT>(out, opix * N + n0 + g * 8, v);
+                for (int e = 0; e < VEC; ++e) {
+                    acc[e] += bv[e];
+                    if (RELU) acc[e] = fmaxf(acc[e], 0.f);
+                }
+                if constexpr (OUT == ISP_F32) {
+                    float* op = reinterpret_cast<float*>(out) + at;
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 4) *reinterpret_cast<float4*>(op + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+                } else if constexpr (VEC == 8) {
+                    unsigned short* op = reinterpret_cast<unsigned short*>(out) + at;
+                    if constexpr (OUT == ISP_F16)
+                        *reinterpret_cast<uint4*>(op) = make_uint4(pack2h_sat(acc[0], acc[1]), pack2h_sat(acc[2], acc[3]),
+                                                                   pack2h_sat(acc[4], acc[5]), pack2h_sat(acc[6], acc[7]));
+                    else
+                        *reinterpret_cast<uint4*>(op) = make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]),
+                                                                   pack2bf(acc[6], acc[7]));
                 }
             }
         }
+    }
+}
+
+// ---- the blend on the matrix pipe (half tap planes; the default for them).  PMC of the vector form above: 7 163 vector
+// instructions per wave, vector pipe 70 % busy, 2.6 of the 6.9 TB/s a plain fill writes here -- the 12 multiply-adds per value ARE
+// the kernel.  Both phases are small matrix products against tile-constant weight matrices with K <= 15:
+//   phase A, per U row R = (ty, qy):   U^T[ch][X]   = sum_{k = (tx, qx)} Z^T[ch][k] Bx[k][X]      K = 3 tx x (fx <= 5 source columns)
+//   phase B, per pixel column px:       out^T[ch][py] = sum_{k = R}       U^T[ch][k] Ay[k][py]      K = 3 ty x (fy <= 5 source rows)
+// on v_mfma_f32_16x16x16_f16 (M = 16 channels, N = 16 columns / rows of the tile).  The A operand's rows k are rows of the
+// staged images at arbitrary addresses -- exactly what ds_read_b64_tr_b16 gathers (each lane of a 16-lane group supplies the
+// address of one row's four channels; lane i receives channel i of the group's four rows) -- and B is a per-lane constant
+// built once per tile (the bilinear weights, rounded to half: 2^-12 like the tap planes themselves).  The four MFMAs of a
+// 64-channel block take channels 32 (c / 2) + 8 p + 4 (c % 2) + {0..3} from address lane p, so a lane ends with two runs of 8
+// consecutive channels of its column / pixel and the four lanes of a pixel store 64 consecutive bytes per instruction.  Per wave and channel block:
+// ~25 MFMAs + 25 transposed reads + the epilogue of 4 x 16 values, against 1 194 vector instructions.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ f16x4_t tr_read4(const char* p) {
+    return __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ISP_LDS s16x4_t*)p));
+}
+
+template <int OUT, bool RELU>
+__global__ __launch_bounds__(256) void conv_bilinear_blend4_kernel(const _Float16* __restrict__ z, const float* __restrict__ bias,
+                                                                   void* __restrict__ out, int h, int w, int H, int W, int N,
+                                                                   float sy, float sx, int zs_bytes, int G, int abl) {
+    constexpr int CB = 64, ES = 2, VEC = 8;
+    constexpr int UROW = CB * ES;
+    // G channel blocks are staged per pass (their loads' latency is paid once per G blocks): [q][tap][G x 64 channels]
+    const int TAPB = G * CB * ES, QPITCH = 9 * TAPB + 16, PIECES = 9 * TAPB / 16;
+    constexpr int KF = 5;  // k = tap * KF + source index inside the footprint (<= 5 per axis): 15 rows, row 15 is a zero-weight dummy
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const zs = lds;
+    char* const us = lds + zs_bytes;
+    __shared__ float xw[TPX][6], yw[TPX][6];
+    __shared__ int xi[TPX][6], yi[TPX][6];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.z;
+    const int Y0 = blockIdx.y * TPX, X0 = blockIdx.x * TPX;
+    int qy_lo, qx_lo, fy, fx;
+    {
+        int i0, i1;
+        float l;
+        src_coord(max(Y0 - 1, 0), sy, h, i0, i1, l);
+        qy_lo = i0;
+        src_coord(min(Y0 + TPX, H - 1), sy, h, i0, i1, l);
+        fy = i1 - qy_lo + 1;
+        src_coord(max(X0 - 1, 0), sx, w, i0, i1, l);
+        qx_lo = i0;
+        src_coord(min(X0 + TPX, W - 1), sx, w, i0, i1, l);
+        fx = i1 - qx_lo + 1;
+    }
+    if (tid < 2 * TPX) {  // threads 0-15: column table, 16-31: row table (as in the vector form)
+        const bool col = tid < TPX;
+        const int c = col ? tid : tid - TPX;
+        const int base = (col ? X0 : Y0) + c, n_out = col ? W : H, n_in = col ? w : h, lo = col ? qx_lo : qy_lo, f = col ? fx : fy;
+        const float sc = col ? sx : sy;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            int i0, i1;
+            float l;
+            const int d = base + t - 1;
+            const bool v = d >= 0 && d < n_out;
+            src_coord(min(max(d, 0), n_out - 1), sc, n_in, i0, i1, l);
+            i0 = min(max(i0 - lo, 0), f - 1), i1 = min(max(i1 - lo, 0), f - 1);
+            (col ? xw : yw)[c][2 * t] = v ? 1.f - l : 0.f, (col ? xw : yw)[c][2 * t + 1] = v ? l : 0.f;
+            (col ? xi : yi)[c][2 * t] = i0, (col ? xi : yi)[c][2 * t + 1] = i1;
+        }
+    }
+    __syncthreads();
+    // ---- tile constants of this lane.  MFMA lane roles: n = lane % 16 (tile column X in phase A, tile row py in phase B),
+    // k = 4 (lane / 16) + e for B-operand element e; as an address lane of a transposed read: group gq = lane / 16 reads rows
+    // k = 4 gq + q with q = (lane % 16) / 4, channels 16 p + 4 c + {0..3} with p = lane % 4.
+    const int n = lane & 15, gq = lane >> 4, aq = (lane & 15) >> 2, ap = lane & 3;
+    f16x4_t bxa, bya;  // B operands: Bx[k][X = n], Ay[k][py = n]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * gq + e, t = k / KF, s_ = k - t * KF;
+        float vx = 0.f, vy = 0.f;
+        if (t < 3) {
+            vx = (xi[n][2 * t] == s_ ? xw[n][2 * t] : 0.f) + (xi[n][2 * t + 1] == s_ ? xw[n][2 * t + 1] : 0.f);
+            vy = (yi[n][2 * t] == s_ ? yw[n][2 * t] : 0.f) + (yi[n][2 * t + 1] == s_ ? yw[n][2 * t + 1] : 0.f);
+        }
+        bxa[e] = (_Float16)vx, bya[e] = (_Float16)vy;
+    }
+    // the row this lane ADDRESSES in the transposed reads: k = 4 gq + aq
+    const int ak = 4 * gq + aq, at = ak / KF, as_ = ak - at * KF;
+    const bool a_on = at < 3;
+    // phase A: Z row (tx = at, source column as_) of U row R = (ty, qy): zs + (qy fx + as_) QPITCH + (ty 3 + at) TAPB
+    const int za = (a_on ? min(as_, fx - 1) * QPITCH + at * TAPB : 0) + ap * 16;
+    // phase B: U row (ty = at, source row as_) at pixel column px: us + ((at fy + as_) 16 + px) UROW
+    const int ua = (a_on ? (at * fy + min(as_, fy - 1)) * TPX * UROW : 0) + ap * 16;
+    const size_t zrow = (size_t)9 * N;
+    const _Float16* zb = z + ((size_t)b * h * w) * zrow;
+    const int nq = fy * fx, n_rows = 3 * fy;
+    const int Y = Y0 + n;  // phase B: this lane's pixel row
+
+    for (int ng = 0; ng < N; ng += G * CB) {
+        __syncthreads();  // the previous pass's last phase A is done with zs (and its phase B with us)
+        if (!(abl & 2))
+        for (int i = tid; i < nq * PIECES; i += 256) {
+            const int q = i / PIECES, pc = i - q * PIECES;
+            const int t = pc / (PIECES / 9), r = pc - t * (PIECES / 9);
+            const int qy = qy_lo + q / fx, qx = qx_lo + q % fx;
+            const _Float16* src = zb + ((size_t)qy * w + qx) * zrow + (size_t)t * N + ng + r * VEC;
+            *reinterpret_cast<uint4*>(zs + q * QPITCH + pc * 16) = *reinterpret_cast<const uint4*>(src);
+        }
+      for (int gi = 0; gi < G; ++gi) {
+        const int n0 = ng + gi * CB;
+        __syncthreads();  // stage landed (gi = 0) / the previous block's phase B is done with us
+        // ---- phase A: wave `wid` forms the U rows R = wid, wid + 4, ..
+        for (int R = wid; R < n_rows; R += 4) {
+            const int ty = R / fy, qy = R - ty * fy;
+            const char* zr = zs + qy * fx * QPITCH + ty * 3 * TAPB + za + gi * (CB * ES);
+            f32x4 d[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f16x4_t a = tr_read4(zr + (c >> 1) * 64 + (c & 1) * 8);  // channels 32 (c / 2) + 8 p + 4 (c % 2) .. + 3 of the lane's row
+                d[c] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, bxa, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+            // D^T[m = 4 gq + i][X = n] of MFMA c = channel 32 (c / 2) + 8 gq + 4 (c % 2) + i: two runs of 8 channels of U[R][X = n]
+            char* up = us + (R * TPX + n) * UROW + gq * 16;
+            *reinterpret_cast<uint4*>(up) = make_uint4(pack2h_sat(d[0][0], d[0][1]), pack2h_sat(d[0][2], d[0][3]),
+                                                       pack2h_sat(d[1][0], d[1][1]), pack2h_sat(d[1][2], d[1][3]));
+            *reinterpret_cast<uint4*>(up + 64) = make_uint4(pack2h_sat(d[2][0], d[2][1]), pack2h_sat(d[2][2], d[2][3]),
+                                                            pack2h_sat(d[3][0], d[3][1]), pack2h_sat(d[3][2], d[3][3]));
+        }
+        __syncthreads();
+        // ---- phase B: wave `wid` forms the pixel columns px = wid, wid + 4, wid + 8, wid + 12
+        float bv[16];  // channels n0 + 8 gq + {0..7} and n0 + 32 + 8 gq + {0..7}
+#pragma unroll
+        for (int e = 0; e < 16; ++e) bv[e] = bias ? bias[n0 + (e >> 3) * 32 + gq * 8 + (e & 7)] : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int px = wid + 4 * kk;
+            const char* ur = us + px * UROW + ua;
+            f32x4 d[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f16x4_t a = tr_read4(ur + (c >> 1) * 64 + (c & 1) * 8);
+                d[c] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, bya, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+            const int X = X0 + px;
+            if (Y < H && X < W && !((abl & 1) && n0 + (int)blockIdx.x < 1000000)) {
+                float v[16];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float r = d[c][i] + bv[4 * c + i];
+                        v[4 * c + i] = RELU ? fmaxf(r, 0.f) : r;
+                    }
+                // the four lanes of a pixel write 64 consecutive bytes per instruction (whole sectors), the two instructions its line
+                const size_t at_ = (((size_t)b * H + Y) * W + X) * N + n0 + gq * 8;
+                store8<OUT>(out, at_, v);
+                store8<OUT>(out, at_ + 32, v + 8);
+            }
+        }
+      }
     }
 }
 
@@ -360,21 +396,30 @@ int launch(const void* z, const float* bias, void* out, int B, int h, int w, int
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     const dim3 grid((W + TPX - 1) / TPX, (H + TPX - 1) / TPX, B);
-    static const bool one_phase = [] { const char* e = getenv("ISEGPROBE_BLEND_ONE_PHASE"); return e && e[0] == '1'; }();  // A/B switch
-    if (one_phase) {
-        if (relu)
-            conv_bilinear_blend_kernel<ZT, OUT, true><<<grid, 256, 0, s>>>((const ZT*)z, bias, out, h, w, H, W, N, sy, sx);
-        else
-            conv_bilinear_blend_kernel<ZT, OUT, false><<<grid, 256, 0, s>>>((const ZT*)z, bias, out, h, w, H, W, N, sy, sx);
+    // ISEGPROBE_BLEND_FORM: 4 (default for half tap planes) both phases on MFMA; 3 (fp32 tap planes; A/B switch for half) the vector form
+    static const int form_env = [] { const char* e = getenv("ISEGPROBE_BLEND_FORM"); return e ? atoi(e) : 4; }();
+    const int form = (form_env == 4 && !std::is_same<ZT, _Float16>::value) ? 3 : form_env;  // 4 = matrix-pipe form, half tap planes only
+    constexpr int CB = ZTraits<ZT>::CB, ES = (int)sizeof(ZT);
+    const int FY = max_footprint(h, H, sy), FX = max_footprint(w, W, sx);
+    const int zs_bytes = FY * FX * (9 * CB * ES + 16);
+    if (form == 4) {
+        if constexpr (std::is_same<ZT, _Float16>::value) {
+            static const int abl = [] { const char* e = getenv("ISEGPROBE_BLEND_ABL"); return e ? atoi(e) : 0; }();  // timing experiments: 1 no stores, 2 no staging
+            // one 64-channel block per staging pass: two blocks per pass (half the passes, 46 KiB of LDS) measured 1.97 against 1.76 ms
+            const int G = 1, us_bytes = 3 * FY * TPX * (CB * ES);
+            const int zs4 = FY * FX * (9 * G * CB * ES + 16);
+            const int lds = zs4 + us_bytes;
+            if (relu)
+                conv_bilinear_blend4_kernel<OUT, true><<<grid, 256, lds, s>>>((const _Float16*)z, bias, out, h, w, H, W, N, sy, sx, zs4, G, abl);
+            else
+                conv_bilinear_blend4_kernel<OUT, false><<<grid, 256, lds, s>>>((const _Float16*)z, bias, out, h, w, H, W, N, sy, sx, zs4, G, abl);
+        }
     } else {
-        constexpr int CB = ZTraits<ZT>::CB, ES = (int)sizeof(ZT);
-        const int FY = max_footprint(h, H, sy), FX = max_footprint(w, W, sx);
-        const int zs_bytes = FY * FX * (9 * CB * ES + 16);
-        const int lds = zs_bytes + 3 * FY * TPX * (CB * ES + 16);  // <= 63 760 B at the 5 x 5 limit: inside the default 64 KiB
+        const int lds = zs_bytes + 3 * FY * TPX * (CB * ES);  // 3 x 3 footprint: 10.5 + 18 KiB; 5 x 5: 29.2 + 30 KiB
         if (relu)
-            conv_bilinear_blend2_kernel<ZT, OUT, true><<<grid, 256, lds, s>>>((const ZT*)z, bias, out, h, w, H, W, N, sy, sx, zs_bytes);
+            conv_bilinear_blend3_kernel<ZT, OUT, true><<<grid, 256, lds, s>>>((const ZT*)z, bias, out, h, w, H, W, N, sy, sx, zs_bytes);
         else
-            conv_bilinear_blend2_kernel<ZT, OUT, false><<<grid, 256, lds, s>>>((const ZT*)z, bias, out, h, w, H, W, N, sy, sx, zs_bytes);
+            conv_bilinear_blend3_kernel<ZT, OUT, false><<<grid, 256, lds, s>>>((const ZT*)z, bias, out, h, w, H, W, N, sy, sx, zs_bytes);
     }
     return isp_launch_status();
 }
