@@ -499,10 +499,11 @@ def fp32_mode_block(arch, upsampler, B=32, S=448, iters=2):
             "peak_mem_GiB": mem, "steps": iters,
             "noc_16bit_vs_reference": {
                 "source": "tests/test_noc_dataset_gpu.py over tests/golden/noc_dataset*.npz (reference NoBRS evaluation, 20 clicks, flip + zoom-in)",
-                "grabcut_layout_bilinear_50_objects": {"NoC@80/85/90": {"reference = fp32 mode": [5.82, 8.22, 12.26], "16-bit path": [5.80, 8.22, 12.54]}, "objects_differing": 4},
+                "grabcut_layout_bilinear_50_objects": {"NoC@80/85/90": {"reference = fp32 mode": [5.82, 8.22, 12.26], "16-bit path": [5.74, 8.20, 11.96]}, "objects_differing": 4},
                 "grabcut_layout_lift": {"NoC@85": {"reference = fp32 mode": 4.10, "16-bit path": 4.00}, "objects_differing": 1},
                 "grabcut_layout_loftup": {"NoC@80/85/90": {"reference = fp32 mode = 16-bit path": [2.68, 3.88, 5.84]}, "objects_differing": 0},
-                "sbd_layout_46_objects": {"NoC@80/85/90": {"reference = fp32 mode": [12.07, 17.07, 19.72], "16-bit path": [12.04, 17.07, 19.87]}, "objects_differing": 4}}}
+                "sbd_layout_46_objects": {"NoC@80/85/90": {"reference = fp32 mode": [12.07, 17.07, 19.72], "16-bit path": [12.07, 17.09, 19.63]}, "objects_differing": 2},
+                "measured": "round 4, with the head's first convolution through the resize on the 16-bit path (python -m pytest tests/test_noc_dataset_gpu.py -s)"}}
 
 
 def train_block(arch, upsampler, B, S, sim_clicks=2, warm=2, iters=5):
