@@ -283,8 +283,8 @@ class DINOv2Featurizer(nn.Module):
             # weights (and every forward under ISEGPROBE_F16_PROBE=always) records the largest magnitude of each 16-bit
             # intermediate; at >= half of the range the weights are marked bf16-only (bf16 has fp32's range) and this
             # forward is redone in bf16 from a copy of the stream.  One device->host read per weight version.
-            probe = (("f16_ok" not in P or F16_PROBE_ALWAYS or P.pop("f16_reprobe", False))
-                     and not torch.cuda.is_current_stream_capturing())
+            probe = (not torch.cuda.is_current_stream_capturing()  # (a capture keeps the re-probe request for the next eager forward)
+                     and ("f16_ok" not in P or F16_PROBE_ALWAYS or P.pop("f16_reprobe", False)))
             peak = torch.zeros((), device=x.device) if probe else None
             x_in = x.clone() if probe else None
 

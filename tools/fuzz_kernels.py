@@ -123,5 +123,28 @@ for r in range(rounds):
                 continue
             y = ops.layernorm(xx.to(din).contiguous(), gg, bb, 1e-5, out_dtype=dout)
             check(f"layernorm {din}->{dout} rows{rows} D{Dn}", y, F.layer_norm(xx.to(din).float(), (Dn,), gg, bb, 1e-5), tol)
+    # ---- first head conv through the bilinear resize (random geometry with up-scaling >= 6: 5 x 5 footprint at most), exact-fp32 attention
+    hb, wb = ri(2, 20), ri(2, 20)
+    Hb, Wb = hb * ri(6, 15) + ri(0, 5), wb * ri(6, 15) + ri(0, 5)
+    Cb, Nb = pick([64, 128, 384]), pick([64, 128, 192, 384])
+    if ops.conv3x3_of_bilinear_supported(hb, wb, Hb, Wb, Nb):
+        Bb = ri(1, 2)
+        xb = torch.randn(Bb, hb, wb, Cb, device="cuda")
+        wb4 = torch.randn(Nb, Cb, 3, 3, device="cuda") / math.sqrt(9 * Cb)
+        bb_ = torch.randn(Nb, device="cuda") * 0.2
+        yb = F.interpolate(xb.half().float().permute(0, 3, 1, 2), size=(Hb, Wb), mode="bilinear", align_corners=True)
+        refb = F.relu(F.conv2d(yb, wb4.half().float(), bb_, padding=1)).permute(0, 2, 3, 1)
+        wz = wb4.permute(2, 3, 0, 1).reshape(9 * Nb, Cb).half().contiguous()
+        zb = ops.linear(xb.half().view(-1, Cb), wz)
+        check(f"conv_of_bilinear f16 B{Bb} {hb}x{wb}->{Hb}x{Wb} C{Cb} N{Nb}", ops.conv3x3_of_bilinear_blend(zb, bb_, Bb, hb, wb, Hb, Wb, Nb), refb, 3e-3)
+        z32 = (xb.view(-1, Cb) @ wb4.permute(2, 3, 0, 1).reshape(9 * Nb, Cb).t()).contiguous()
+        y32 = F.interpolate(xb.permute(0, 3, 1, 2), size=(Hb, Wb), mode="bilinear", align_corners=True)
+        check(f"conv_of_bilinear f32 {hb}x{wb}->{Hb}x{Wb}", ops.conv3x3_of_bilinear_blend(z32, bb_, Bb, hb, wb, Hb, Wb, Nb, out_dtype=torch.float32),
+              F.relu(F.conv2d(y32, wb4, bb_, padding=1)).permute(0, 2, 3, 1), 3e-5)
+    Ba, La, ha = ri(1, 3), ri(1, 700), ri(1, 6)
+    qkv = torch.randn(Ba * La, 3 * ha * 64, device="cuda")
+    q_, k_, v_ = (qkv.double().view(Ba, La, 3, ha, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    refa = (torch.softmax((q_ * 0.125) @ k_.transpose(-1, -2), dim=-1) @ v_).permute(0, 2, 1, 3).reshape(Ba * La, ha * 64).float()
+    check(f"attention_f32 B{Ba} L{La} heads{ha}", ops.attention_packed_qkv_f32(qkv, Ba, La, ha, 0.125), refa, 3e-6)
 print(f"{bad} mismatches")
 sys.exit(1 if bad else 0)
