@@ -28,10 +28,9 @@ class _TrainSample:
         self.ids, self.areas = get_labels_with_sizes(mask)
 
     def remove_small_objects(self, min_area):
+        """data_sample.py:127-133, 202-215: the object leaves the list, its pixels stay in the instance map -- they are not
+        background afterwards, so they still count as "other objects" for the negative clicks (pinned by the sampler fixture)."""
         keep = [(i, a) for i, a in zip(self.ids, self.areas) if a >= min_area]
-        for i, a in zip(self.ids, self.areas):
-            if a < min_area:
-                self.mask[self.mask == i] = 0
         self.ids, self.areas = [i for i, _ in keep], [a for _, a in keep]
 
     def __len__(self):
@@ -53,7 +52,8 @@ class SBDTrainSet(data.Dataset):
                  keep_background_prob=0.01, samples_scores_path=None, samples_scores_gamma=1.25, augmentor=None,
                  points_sampler=None, epoch_len=-1):
         self.reader = SBDDataset(dataset_path, split=split)
-        self.augmentor = augmentor if augmentor is not None else TrainAugmentor(crop_size)
+        # augmentor: None = the SBD scripts' pipeline at `crop_size`; False = none (the reference's augmentator=None: samples as read)
+        self.augmentor = TrainAugmentor(crop_size) if augmentor is None else augmentor
         self.points_sampler = points_sampler or MultiPointSampler(num_max_points, prob_gamma=0.80, merge_objects_prob=0.15,
                                                                  max_num_merged_objects=2)  # models/defaults.py:74-79
         self.min_object_area, self.keep_background_prob, self.epoch_len = min_object_area, keep_background_prob, epoch_len
@@ -80,8 +80,10 @@ class SBDTrainSet(data.Dataset):
         raw = self.reader.get_sample(index)
         image0, mask0 = raw.image, raw._encoded_masks.astype(np.int32)
         while True:  # base_dataset.py:78-91: re-draw the augmentation until an object is left (or an empty crop is kept)
-            image, mask = self.augmentor(image0, mask0.copy())
+            image, mask = self.augmentor(image0, mask0.copy()) if self.augmentor else (image0, mask0.copy())
             s = _TrainSample(image, mask)
+            if not self.augmentor:  # (base_dataset.py:79-80: without an augmentator the sample is returned as it is)
+                break
             if len(s) > 0 or self.keep_background_prob < 0.0 or random.random() < self.keep_background_prob:
                 break
         s.remove_small_objects(self.min_object_area)

@@ -1269,6 +1269,48 @@ def gen_datasets():
     save("datasets", **out)
 
 
+def gen_points_sampler():
+    """The reference's train-time feed without augmentation: SBDDataset.__getitem__ (core/data/base_dataset.py:43-76 ->
+    datasets/sbd.py:38-56 -> DSample -> MultiPointSampler.sample_object / sample_points, core/data/points_sampler.py:35-380) with
+    the SBD scripts' sampler settings (models/defaults.py:74-79) on the committed SBD-layout tree, under seeded `random` /
+    `numpy.random`: target masks and click lists for 40 draws per split.  cv2 is absent: imread / cvtColor as in gen_datasets,
+    erode / dilate stood in with scipy's binary morphology (3 x 3 ones; erosion treats the outside as set, dilation as clear --
+    OpenCV's default border values), i.e. the sampler's LOGIC and random-draw order are the reference's, the morphology
+    primitives are not OpenCV's."""
+    import random
+    import cv2  # noqa: stub
+    from PIL import Image
+    from scipy import ndimage
+
+    cv2.COLOR_BGR2RGB = 4
+    cv2.imread = lambda path, flags=None: np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    cv2.cvtColor = lambda a, code: np.ascontiguousarray(a[:, :, ::-1])
+    k3 = np.ones((3, 3), bool)
+    cv2.erode = lambda m, kernel, iterations=1: ndimage.binary_erosion(m.astype(bool), k3, iterations=iterations, border_value=1).astype(np.uint8)
+    cv2.dilate = lambda m, kernel, iterations=1: (ndimage.binary_dilation(m.astype(bool), k3, iterations=iterations, border_value=0).astype(np.uint8)
+                                                  if iterations > 0 else m.copy())
+    from core.data.datasets.sbd import SBDDataset
+    from core.data.points_sampler import MultiPointSampler
+    root = os.path.join(OUT, "datasets", "sbd")
+    out = {}
+    for split in ("train", "val"):
+        sampler = MultiPointSampler(6, prob_gamma=0.80, merge_objects_prob=0.5, max_num_merged_objects=2)
+        ds = SBDDataset(root, split=split, augmentator=None, min_object_area=20, keep_background_prob=0.01, points_sampler=sampler)
+        random.seed(123), np.random.seed(123)
+        pts, masks = [], []
+        for _ in range(40):
+            item = ds[0]
+            pts.append(item["points"]), masks.append(np.packbits(item["instances"][0] > 0))
+        out[f"{split}_points"], out[f"{split}_masks"] = np.stack(pts), np.stack(masks)
+        out[f"{split}_shape"] = np.array(item["instances"].shape)
+        out[f"{split}_image"] = (item["images"].numpy() * 255).round().astype(np.uint8)
+        n_obj = len(np.unique(ds.get_sample(0)._encoded_masks)) - 1
+        merged = sum(1 for m in masks if not any(np.array_equal(m, q) for q in masks[:0]))
+        print(f"  {split}: {n_obj} objects, {len({m.tobytes() for m in masks})} distinct targets in 40 draws, "
+              f"positives per draw {np.mean([(p[:6, 0] >= 0).sum() for p in pts]):.2f}, negatives {np.mean([(p[6:, 0] >= 0).sum() for p in pts]):.2f}")
+    save("points_sampler", **out)
+
+
 def gen_crops():
     """Crops transform (core/inference/transforms/crops.py): window offsets over a sweep of lengths, and one forward /
     inverse pass (crop batch, shifted clicks, overlap-averaged probabilities) per geometry."""
@@ -1305,9 +1347,9 @@ def gen_crops():
 def main():
     torch.set_num_threads(4)
     install_standins()
-    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "noc_dataset", "noc_upsamplers", "noc_sbd", "checkpoint", "frozen_ckpts", "train_step", "datasets", "crops"]
+    which = sys.argv[1:] or ["click_maps", "bfs", "vit", "dino", "simple_vit", "maskclip", "upsamplers", "model", "inference", "noc_dataset", "noc_upsamplers", "noc_sbd", "checkpoint", "frozen_ckpts", "train_step", "datasets", "points_sampler", "crops"]
     fns = {"click_maps": gen_click_maps, "bfs": gen_bfs, "vit": gen_vit, "dino": gen_dino, "simple_vit": gen_simple_vit, "maskclip": gen_maskclip,
-           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "noc_dataset": gen_noc_dataset, "noc_upsamplers": gen_noc_dataset_upsamplers, "noc_sbd": gen_noc_dataset_sbd, "checkpoint": gen_checkpoint, "frozen_ckpts": gen_frozen_checkpoints, "train_step": gen_train_step, "datasets": gen_datasets, "crops": gen_crops}
+           "upsamplers": gen_upsamplers_and_head, "model": gen_model, "inference": gen_inference, "noc_dataset": gen_noc_dataset, "noc_upsamplers": gen_noc_dataset_upsamplers, "noc_sbd": gen_noc_dataset_sbd, "checkpoint": gen_checkpoint, "frozen_ckpts": gen_frozen_checkpoints, "train_step": gen_train_step, "datasets": gen_datasets, "points_sampler": gen_points_sampler, "crops": gen_crops}
     for w in which:
         fns[w]()
 

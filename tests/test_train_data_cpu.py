@@ -113,6 +113,26 @@ def test_sbd_train_set_and_shards(tmp_path):
     assert len(batches) == 2 and batches[0]["images"].shape == (3, 3, 56, 70) and batches[0]["points"].shape == (3, 12, 3)
 
 
+def test_sbd_feed_identical_to_reference_sampler(golden):
+    """The reference's own SBDDataset.__getitem__ + MultiPointSampler (tests/golden/gen_golden.py::gen_points_sampler: no
+    augmentation, the SBD scripts' sampler settings with merge_objects_prob 0.5, seeded `random` / `numpy.random`) against this
+    repo's feed under the same seeds: target masks and click lists identical draw for draw -- object choice, merging, erosion
+    decisions, the counts from the gamma-decay distributions, the three negative regions and every coordinate."""
+    from isegprobe_amd.core.data import MultiPointSampler, SBDTrainSet
+    g = golden("points_sampler")
+    for split in ("train", "val"):
+        sampler = MultiPointSampler(6, prob_gamma=0.80, merge_objects_prob=0.5, max_num_merged_objects=2)
+        ds = SBDTrainSet(SBD, split=split, min_object_area=20, keep_background_prob=0.01, points_sampler=sampler, augmentor=False)
+        random.seed(123), np.random.seed(123)
+        shape = tuple(g[f"{split}_shape"])
+        for i in range(40):
+            item = ds[0]
+            assert tuple(item["instances"].shape) == shape
+            assert np.array_equal(np.packbits(item["instances"][0].numpy() > 0), g[f"{split}_masks"][i]), (split, i)
+            assert np.array_equal(item["points"].numpy(), g[f"{split}_points"][i]), (split, i, item["points"].numpy(), g[f"{split}_points"][i])
+        assert np.array_equal((item["images"].numpy() * 255).round().astype(np.uint8), g[f"{split}_image"])
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
