@@ -465,8 +465,10 @@ def cfg0_block(B=32, S=448, warm=2, iters=5):
             "first_conv_through_resize": {"blend_launch_ms": blend_ms, "bound": "hbm", "algorithmic_bytes": out_bytes + B * h * h * 9 * D * 2.0,
                                           "achieved": (out_bytes + B * h * h * 9 * D * 2.0) / (blend_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": (out_bytes + B * h * h * 9 * D * 2.0) / (blend_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                          "note": "blend kernel: writes the [B,S,S,N] half map once, reads the [B*h*w, 9N] tap planes; "
-                                                  "36 multiply-adds per output value instead of 9*C"},
+                                          "write_ceiling_note": "on-box ceilings for a written map of this size (tools/write_bw.py): broadcast multiply 3.8 TB/s, "
+                                                                "the plain resize kernel writing the same map 2.9 TB/s, a constant fill 6.9 TB/s",
+                                          "note": "blend kernel (both separable phases on v_mfma_f32_16x16x16_f16 fed by transposed LDS reads): writes the "
+                                                  "[B,S,S,N] half map once, reads the [B*h*w, 9N] tap planes"},
             "materialised_route": {"images_per_sec": B / dt_old, "ms_per_step": dt_old * 1e3, "max_abs_logit_diff_vs_default": diff}}
 
 
