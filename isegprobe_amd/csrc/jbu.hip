@@ -212,16 +212,18 @@ __global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const void* __restr
     // spatial Gaussian of the 49 taps (pixel-independent): computed once per block, read back as LDS broadcasts
     float* const s_gauss = reinterpret_cast<float*>(smem + KERNELS_LDS_MAIN + TAB_GAUSS);
     float* const s_by = reinterpret_cast<float*>(smem + KERNELS_LDS_MAIN + TAB_BY);  // [8 rows][7][8]
-    float* const s_bx = reinterpret_cast<float*>(smem + KERNELS_LDS_MAIN + TAB_BX);  // [32 cols][7][16]
+    float* const s_bx = reinterpret_cast<float*>(smem + KERNELS_LDS_MAIN + TAB_BX);  // [7][4 float4][32 cols]
     for (int i = threadIdx.x; i < TSY * DIA * 8 / 4; i += 256) {
         const int r = i / (DIA * 8 / 4);
         reinterpret_cast<float4*>(s_by)[i] =
             reinterpret_cast<const float4*>(bys + (size_t)min(ty0 + r, GH - 1) * (DIA * 8))[i - r * (DIA * 8 / 4)];
     }
+    // (stored column-fastest, [float4 j of the row][32 cols]: the 32 lanes of a tile row read float4 j of 32 DIFFERENT columns --
+    // row-major [col][28 float4] put lanes 448 bytes apart, 4 lanes per bank group: SQ_LDS_BANK_CONFLICT was 40 % of the LDS cycles)
     for (int i = threadIdx.x; i < TSX * DIA * 16 / 4; i += 256) {
-        const int c = i / (DIA * 16 / 4);
+        const int c = i & (TSX - 1), j = i / TSX;  // lane-linear LDS writes; the table rows come from L2
         reinterpret_cast<float4*>(s_bx)[i] =
-            reinterpret_cast<const float4*>(bxs + (size_t)min(tx0 + c, GW - 1) * (DIA * 16))[i - c * (DIA * 16 / 4)];
+            reinterpret_cast<const float4*>(bxs + (size_t)min(tx0 + c, GW - 1) * (DIA * 16))[j];
     }
     if (threadIdx.x < TAPS) {
         const int t = threadIdx.x;
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const void* __restr
     // composite 8x8 kernel on the source grid: rows first (hrow[ry][tx] = sum_ty by[ty][ry] k[ty][tx],
     // k is dead afterwards), then the two halves of the 16 circular column slots
     const float* byp = s_by + ly * (DIA * 8);    // = bys[y], bxs[x] (clamped like y, x), from the block's LDS copy
-    const float* bxp = s_bx + lx * (DIA * 16);
+    const float* bxp = s_bx + lx * 4;  // float4 j of this column at bxp + j * (TSX * 4)
     // The 256-byte record of a pixel is staged in LDS and leaves as 16 bytes per lane with 16 lanes per record: a
     // thread storing its own record directly issues 64 separate 16-byte segments per instruction (partial lines).
     // Wave-private staging [64 px][16 chunks], chunk slot XORed with the pixel index (conflict-free both ways).
@@ -415,8 +417,8 @@ __global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const void* __restr
         f32x2 bx[DIA][4];
 #pragma unroll
         for (int tx = 0; tx < DIA; ++tx) {
-            const float4 b0 = *reinterpret_cast<const float4*>(bxp + tx * 16 + half * 8);
-            const float4 b1 = *reinterpret_cast<const float4*>(bxp + tx * 16 + half * 8 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(bxp + (tx * 4 + half * 2) * (TSX * 4));
+            const float4 b1 = *reinterpret_cast<const float4*>(bxp + (tx * 4 + half * 2 + 1) * (TSX * 4));
             bx[tx][0] = f32x2{b0.x, b0.y}, bx[tx][1] = f32x2{b0.z, b0.w};
             bx[tx][2] = f32x2{b1.x, b1.y}, bx[tx][3] = f32x2{b1.z, b1.w};
         }
