@@ -132,6 +132,14 @@ class DataParallelTrainer:
         return loss.detach()
 
 
+def load_weights(model, path_to_weights: str):
+    """core/training/trainer.py:621-626: the checkpoint's tensors laid over the model's own state dict (a probe checkpoint holds
+    embed_coords.* and head.* only), strict=False."""
+    current = model.state_dict()
+    current.update(torch.load(path_to_weights, map_location="cpu", weights_only=False)["state_dict"])
+    return model.load_state_dict(current, strict=False)
+
+
 class EpochTrainer:
     """The epoch loop of the reference's iSegTrainer (core/training/trainer.py:180-314: ``run`` / ``training``) around a
     step object: for every epoch -- sampler.set_epoch, one optimisation step per batch of this rank's loader, the losses

@@ -222,3 +222,14 @@ def test_two_epochs_two_ranks_gloo(tmp_path):
     assert "embed_coords.proj.weight" in keys and any(k.startswith("head.convs.0.conv") for k in keys) and "head.classifier.bias" in keys
     assert not any(k.startswith(("backbone.", "upsampler.")) for k in keys)
     assert saved["config"]["class"] == "core.model.iseg_probe_model.iSegProbeModel"
+    # training.weights (trainer.py:550-557, 621-626): the probe checkpoint's tensors over a freshly built model
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import build_model, seeded_
+    from isegprobe_amd.core.training.trainer import load_weights
+    fresh = seeded_(build_model("bilinear"), 99)
+    before = fresh.backbone.model.blocks[0].attn.qkv.weight.clone()
+    msg = load_weights(fresh, os.path.join(ckpt, "last_checkpoint.pth"))
+    assert not msg.unexpected_keys
+    assert all(torch.equal(fresh.state_dict()[k], v) for k, v in saved["state_dict"].items())
+    assert torch.equal(fresh.backbone.model.blocks[0].attn.qkv.weight, before)  # frozen parts are not in the file

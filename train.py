@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--epochs", type=int, default=None, help="with --dataset: training_params.epochs (train_cfg.yaml:21)")
     ap.add_argument("--epoch-len", type=int, default=-1, help="with --dataset: samples per epoch (-1: the dataset's size)")
     ap.add_argument("--workers", type=int, default=None, help="with --dataset: DataLoader workers (dataloader.workers)")
+    ap.add_argument("--weights", default=None, help="checkpoint whose tensors initialise the model (reference training.weights, trainer.py:550-557)")
+    ap.add_argument("--start-epoch", type=int, default=0, help="with --dataset: continue at this epoch (training.start_epoch: the LR "
+                                                               "schedule is advanced to it, trainer.py:168-170)")
     ap.add_argument("--validate", action="store_true", help="with --dataset: a validation pass over <root>/val.txt after every epoch "
                                                             "(reference training_params.do_validation)")
     ap.add_argument("--val-len", type=int, default=-1, help="with --validate: samples per validation pass (-1: the split's size)")
@@ -124,6 +127,10 @@ def main():
             args.size = int(cs[0] if isinstance(cs, (list, tuple)) else cs)
         if "training.local_rank" in given:  # the reference reads the rank's device from YAML only (train_cfg.yaml:36)
             os.environ.setdefault("LOCAL_RANK", str(cfg["training"]["local_rank"]))
+        if cfg["training"].get("weights"):
+            args.weights = str(cfg["training"]["weights"])
+        if "training.start_epoch" in given:
+            args.start_epoch = int(cfg["training"]["start_epoch"])
         if "datasets.SBD_PATH" in given:
             args.dataset = str(cfg["datasets"]["SBD_PATH"])
         tp = cfg["training_params"]
@@ -149,6 +156,11 @@ def main():
     torch.manual_seed(0)  # identical initial weights on every rank
     model = iSegProbeModel(**model_configs(args.model, args.size, args.arch, args.upsampler, args.injection),
                            use_disks=True, norm_radius=5, with_prev_mask=True).cuda()
+    if args.weights:
+        from isegprobe_amd.core.training.trainer import load_weights
+        msg = load_weights(model, args.weights)
+        if D_rank0():
+            print(f"Loaded weights from {args.weights} with msg: {msg}")
     trainer = DataParallelTrainer(model, lr=args.lr, frozen_bn_batch_stats=not args.eval_frozen_bn)
     if args.dataset:
         # the reference's loop (trainer.py:180-314): epochs over the SBD train split, clicks from MultiPointSampler, this
@@ -171,7 +183,7 @@ def main():
                                  epoch_len=args.val_len)
             val_loader = make_loader(valset, args.batch, workers=args.workers, seed=max(args.seed, 0), shuffle=False)
         EpochTrainer(trainer, loader, checkpoints_path=args.save, lr_milestones=args.lr_milestones,
-                     checkpoint_interval=args.checkpoint_interval, device="cuda", val_loader=val_loader).run(args.epochs)
+                     checkpoint_interval=args.checkpoint_interval, device="cuda", val_loader=val_loader).run(args.epochs, start_epoch=args.start_epoch)
         D.synchronize()
         return
     rng = np.random.default_rng(100 + D.get_rank())
