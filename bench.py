@@ -128,8 +128,8 @@ def upsampler_bytes(upsampler, C, h, w, H, W, e=2):
 
 # ---------------------------------------------------------------------------------------------- clock / power samples
 class Telemetry:
-    """Shader clock and socket power sampled on a host thread WHILE the timed region runs, so that a few-percent swing of
-    the headline between boxes or rounds is attributable (the head convolutions run at the socket's power limit: the clock
+    """Shader clock and socket power sampled on a host thread while steps of the workload run (bench.py uses it around the timed
+    region, not inside it), so that a few-percent swing of the headline between boxes or rounds is attributable (the head convolutions run at the socket's power limit: the clock
     the chip holds there differs from device to device).  Source: the amdgpu hwmon files of the device torch runs on
     (freq1_input = gfx clock in Hz, power1_average / power1_input in microwatts), else `rocm-smi --json` snapshots.
     Reading a sysfs file costs microseconds and touches neither the GPU queue nor the timed thread."""
@@ -668,20 +668,27 @@ def run_forward(args):
     stack = getattr(model.upsampler, "upsampler", None)
     fused_jbu = getattr(model, "fold_upsampler_affine", False) and hasattr(stack, "forward_stages")
 
+    # Shader clock / socket power are sampled AROUND the timed region -- during the warm-up steps in front of it and during a few
+    # untimed steps of the same workload behind it -- never inside it: a sampler thread polling the SMU through hwmon while the
+    # timed steps ran cost one run 10 % of its headline (823 against 934 img/s for the region that followed without it).
     with torch.no_grad():
-        for _ in range(args.warmup):
-            model(image, points)
-        barrier()
+        with Telemetry(period=0.05) as tele_pre:
+            for _ in range(args.warmup):
+                model(image, points)
+            barrier()
         with OpTimer(ops, ("conv3x3", "conv3x3_folded_affine", "conv3x3_relu_classifier")) as t_conv, \
                 OpTimer(ops, ("attention_packed_qkv",)) as t_att, \
                 OpTimer(model.backbone, ("forward_fused_clicks",)) as t_vit, \
-                OpTimer(stack if fused_jbu else model.upsampler, ("forward_stages",) if fused_jbu else ("forward",)) as t_up, \
-                Telemetry() as tele:
+                OpTimer(stack if fused_jbu else model.upsampler, ("forward_stages",) if fused_jbu else ("forward",)) as t_up:
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 out = model(image, points)["instances"]
             barrier()
             dt = time.perf_counter() - t0
+        with Telemetry(period=0.05) as tele_post:
+            for _ in range(min(5, args.steps)):
+                model(image, points)
+            barrier()
     assert out.shape == (args.batch, 1, args.size, args.size) and torch.isfinite(out).all()
     dt = max_over_ranks(dt)
 
@@ -744,7 +751,8 @@ def run_forward(args):
             line["alt_head_bf16"] = {"value": B * args.steps / dt_bf16, "unit": "images/sec", "ms_per_step": dt_bf16 / args.steps * 1e3,
                                      "note": "same steps with ISEGPROBE_HEAD_F16=0 (bf16 head convolutions: bench-workload logit "
                                              "error 8.5e-3 max / 1.7e-3 rms instead of 5.7e-3 / 1.2e-3)"}
-        line["telemetry_timed_region"] = tele.summary()  # shader clock / socket power while the timed steps ran
+        line["telemetry_around_timed_region"] = {"before_warmup_steps": tele_pre.summary(), "after_untimed_steps": tele_post.summary(),
+                                                 "note": "same workload, sampled outside the timed steps (hwmon polling inside them perturbs the run)"}
         if traffic is not None:
             # mean over the step's two launches, like `traffic`: both read a [B,S,S,C] 16-bit map once, the first writes one
             # (the second's output is the classifier's partial sums, 4 bytes x slots per pixel)
