@@ -600,13 +600,17 @@ def _dist_setup(args):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = "cpu" if args.dry_run else "cuda"
+    # Rehearsal of the N > 1 paths on a ONE-GPU box: ISEGPROBE_SHARE_GPU=1 puts every rank on device 0 and
+    # ISEGPROBE_DIST_BACKEND=gloo replaces RCCL (which wants one device per rank) -- same code, same barriers, same JSON.
+    share = os.environ.get("ISEGPROBE_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("ISEGPROBE_DIST_BACKEND") or ("gloo" if args.dry_run else "nccl")  # "nccl" = RCCL
     if not args.dry_run:
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(0 if share else local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if args.dry_run else "nccl", init_method="env://")  # "nccl" = RCCL
+        dist.init_process_group(backend, init_method="env://")
 
     def barrier():
         if dist is not None:
@@ -850,19 +854,19 @@ def run_train(args):
     trainer = DataParallelTrainer(model, lr=5e-5)
     batch = synthetic_train_batch(args.batch, args.size, seed=2000 + rank)
     ar_ms = []
-    orig = trainer.bucket.all_reduce_mean
+    orig = trainer.bucket.finish_overlapped
 
-    def timed_all_reduce(*a, **k):  # HIP events around the RCCL all-reduce (torch enqueues it on its NCCL stream and
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # joins the current one)
-        s.record()
-        r = orig(*a, **k)
+    def timed_finish(*a, **k):  # HIP events around what is left of the gradient all-reduce behind backward: the head's slice was
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)  # issued inside it (GradBucket.arm_early);
+        s.record()                                                                        # here: the click encoder's slice,
+        r = orig(*a, **k)                                                                 # the wait for both, the division
         e.record()
         ar_ms.append((s, e))
         return r
     for _ in range(args.warmup):
         trainer.step(batch, num_iters=args.sim_clicks)
     barrier()
-    trainer.bucket.all_reduce_mean = timed_all_reduce
+    trainer.bucket.finish_overlapped = timed_finish
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(batch, num_iters=args.sim_clicks)
@@ -881,8 +885,9 @@ def run_train(args):
             "config": {"workload": f"{args.arch} + {args.upsampler} + ConvSegHead({D},2,1), {S}x{S} crops, batch {B}/GPU, clicks before "
                                    f"the backbone, {args.sim_clicks} simulated corrective clicks per step, seeded random-init weights",
                        "per_gpu_batch": B, "global_batch": world * B, "image_size": S, "parallelism": f"dp{world}"},
-            "collective": {"op": "all_reduce(sum)/world of ONE flat fp32 bucket (trainable gradients: embed_coords + head)",
-                           "backend": "nccl (RCCL)" if world > 1 else "none (single process)", "bytes": nbytes,
+            "collective": {"op": "all_reduce(sum)/world of ONE flat fp32 bucket (trainable gradients: embed_coords + head), the head's slice issued "
+                                 "from inside backward; ms_per_step = the part exposed behind backward (HIP events around finish_overlapped)",
+                           "backend": (os.environ.get("ISEGPROBE_DIST_BACKEND") or "nccl (RCCL)") if world > 1 else "none (single process)", "bytes": nbytes,
                            "ms_per_step": ar if world > 1 else 0.0,
                            "bus_GBs": (2.0 * (world - 1) / world * nbytes / (ar * 1e-3) / 1e9) if (world > 1 and ar) else None},
             "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,

@@ -134,3 +134,26 @@ def test_rccl_initialises_and_reduces_on_this_box():
     assert out.get(timeout=300) is True
     p.join(timeout=120)
     assert p.exitcode == 0
+
+
+@pytest.mark.parametrize("mode", ["forward", "train"])
+def test_bench_two_ranks_rehearsal_on_one_gpu(mode):
+    """`python bench.py --gpus 2 [--mode train]` with REAL GPU work on a one-GPU box: ISEGPROBE_SHARE_GPU=1 puts both ranks on
+    device 0, ISEGPROBE_DIST_BACKEND=gloo stands in for RCCL (which wants one device per rank).  Same launch plumbing, barriers,
+    max-over-ranks timing, overlapped gradient all-reduce and single JSON line as the scaling runs the driver starts on 8 GPUs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ISEGPROBE_SHARE_GPU="1", ISEGPROBE_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"]
+    cmd += ["--mode", "train", "--arch", "dinov2_vits14", "--size", "224", "--sim-clicks", "1"] if mode == "train" else ["--no-stages"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    if mode == "train":
+        assert d["collective"]["bytes"] == 11526148 and d["collective"]["ms_per_step"] > 0 and d["config"]["parallelism"] == "dp2"
