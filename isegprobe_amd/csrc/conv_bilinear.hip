@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void conv_bilinear_blend4_kernel(const _Float1
 
     for (int ng = 0; ng < N; ng += G * CB) {
         __syncthreads();  // the previous pass's last phase A is done with zs (and its phase B with us)
-        if (!(abl & 2))
+        if (!(abl & 2))  // (abl & 2, timing experiment: no staging -- the phases run on whatever the LDS holds)
         for (int i = tid; i < nq * PIECES; i += 256) {
             const int q = i / PIECES, pc = i - q * PIECES;
             const int t = pc / (PIECES / 9), r = pc - t * (PIECES / 9);
@@ -359,6 +359,8 @@ __global__ __launch_bounds__(256) void conv_bilinear_blend4_kernel(const _Float1
                 d[c] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, bya, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             }
             const int X = X0 + px;
+            // (abl & 1, timing experiment: no stores.  The second clause is always true but opaque to the compiler, so the
+            //  arithmetic above is not removed with them.)
             if (Y < H && X < W && !((abl & 1) && n0 + (int)blockIdx.x < 1000000)) {
                 float v[16];
 #pragma unroll
