@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--dataset", default=None,
                     help="SBD root (img/, inst/, train.txt): train on it for --epochs epochs instead of synthetic batches "
                          "(reference: DATASETS.SBD_PATH of configs/main_cfg.yaml; Hydra form +datasets.SBD_PATH=<root>)")
+    ap.add_argument("--main-cfg", default=None, help="the reference's configs/main_cfg.yaml: --dataset defaults to its DATASETS.SBD_PATH "
+                                                     "(models/defaults.py:82), the sampling-weights pickle to ./assets/sbd_samples_weights.pkl if present")
     ap.add_argument("--epochs", type=int, default=None, help="with --dataset: training_params.epochs (train_cfg.yaml:21)")
     ap.add_argument("--epoch-len", type=int, default=-1, help="with --dataset: samples per epoch (-1: the dataset's size)")
     ap.add_argument("--workers", type=int, default=None, help="with --dataset: DataLoader workers (dataloader.workers)")
@@ -147,6 +149,13 @@ def main():
     args.epochs = args.epochs if args.epochs is not None else TRAIN_DEFAULTS["training_params"]["epochs"]
     args.workers = args.workers if args.workers is not None else TRAIN_DEFAULTS["dataloader"]["workers"]
 
+    if args.main_cfg and not args.dataset:
+        import yaml
+        args.dataset = str((yaml.safe_load(open(args.main_cfg)) or {}).get("DATASETS", {}).get("SBD_PATH") or "") or None
+        if args.dataset is None:
+            raise SystemExit(f"{args.main_cfg}: no DATASETS.SBD_PATH")
+        if args.samples_scores is None and os.path.exists("./assets/sbd_samples_weights.pkl"):
+            args.samples_scores = "./assets/sbd_samples_weights.pkl"  # models/defaults.py:88
     from isegprobe_amd.core.model import iSegProbeModel
     from isegprobe_amd.core.training.trainer import DataParallelTrainer
     from isegprobe_amd.core.utils import distributed as D
