@@ -294,14 +294,18 @@ class DINOv2Featurizer(nn.Module):
                 return t
             D = self.model.embed_dim
             x16 = stats = None  # half copy + row statistics of the stream, emitted by the residual GEMMs (VIT_LNFOLD)
+            # the LN-folded consumers take at most 8 statistics slots; the producer's slot count follows its tile configuration
+            # (12 for D = 384 on 64-row tiles, i.e. single-image clicks and small batches; 12 for D = 768): those shapes keep
+            # the LayerNorm launches
+            lnfold = VIT_LNFOLD and ops.gemm_f16_stats_slots(x.shape[0], D) <= 8
             for blk in P["blocks"]:
-                if VIT_LNFOLD and stats is not None:  # norm1 folded into the qkv GEMM
+                if lnfold and stats is not None:  # norm1 folded into the qkv GEMM
                     qkv = seen(ops.linear_lnfold(x16, stats, *blk["qkv_fold"], D, LN_EPS))
                 else:
                     hbuf = seen(ops.layernorm(x, blk["n1w"], blk["n1b"], LN_EPS, out_dtype=H16))
                     qkv = seen(ops.linear(hbuf, blk["h_qkv_w"], blk["qkv_b2"]))
                 att = seen(ops.attention_packed_qkv(qkv, B, L, heads, None, q_logit2=True))
-                if VIT_LNFOLD:
+                if lnfold:
                     # The residual GEMMs also write a half copy of the updated stream and its per-row sums; the next
                     # GEMM multiplies that RAW copy by W diag(gain) and applies rstd (acc - mean s) + (c + W b) in its
                     # epilogue: no LayerNorm launch between the GEMMs of a block (24 of the 25 per forward)

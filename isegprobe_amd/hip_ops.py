@@ -169,6 +169,11 @@ def linear_residual_stats_(x, A, Wt, bias=None, gamma=None):
     return x16, stats
 
 
+def gemm_f16_stats_slots(M, N):
+    """Partial-statistics slots ``linear_residual_stats_`` writes for an M x N problem (follows the tile configuration)."""
+    return int(_lib.lib().isp_gemm_f16_stats_slots(M, N))
+
+
 def vit_mlp_pack(norm_w, norm_b, fc1_w, fc1_b, fc2_w, fc2_b, ls=None, dtype=BF16):
     """Weights of isp_vit_mlp_fused from a block's fp32 parameters: LayerNorm affine folded into fc1, LayerScale into
     fc2, fc2's hidden axis permuted inside every group of 16 to the 32x32 accumulator order of the first product

@@ -617,3 +617,24 @@ def test_head_through_resize_vs_materialised_route(up, monkeypatch):
     # both are 16-bit routes of the same fp32 function: their difference is bounded by the sum of their errors (1e-2 each)
     assert err.max().item() <= 1e-2, err.max().item()
     assert err.pow(2).mean().sqrt().item() <= 2e-3
+
+
+def test_vit_lnfold_switch_falls_back_at_small_batches(monkeypatch):
+    """ISEGPROBE_VIT_LNFOLD=1 (LayerNorm folded into the qkv / fc1 GEMMs, opt-in): the LN-folded consumers take at most 8
+    statistics slots, single-image clicks and small batches produce 12 (64-row tiles) -- round 3 returned ISP_ERR_INVALID there
+    (ADVICE); such shapes now keep the LayerNorm launches and the forward is the plain one bit for bit."""
+    from isegprobe_amd import hip_ops as ops
+    from isegprobe_amd.core.model.featurizers import DINOv2 as dv
+    assert ops.gemm_f16_stats_slots(2 * 257, 384) > 8 and ops.gemm_f16_stats_slots(32800, 384) <= 8
+    torch.manual_seed(2)
+    x = torch.randn(2, 3, 224, 224).cuda()
+    clicks = (0.3 * torch.randn(2, 256, 384)).cuda()
+    plain = seeded_(dv.DINOv2Featurizer("custom", "before_backbone", vit_kwargs=S14), 5).cuda().eval()
+    with torch.no_grad():
+        ref = plain(x, clicks).float()
+    monkeypatch.setattr(dv, "VIT_LNFOLD", True)
+    folded = seeded_(dv.DINOv2Featurizer("custom", "before_backbone", vit_kwargs=S14), 5).cuda().eval()
+    with torch.no_grad():
+        y = folded(x, clicks).float()
+    assert folded.packed()["blocks"][0]["qkv_fold"] is not None  # the fold weights were packed: the switch is on
+    assert torch.equal(y, ref)
