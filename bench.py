@@ -791,6 +791,17 @@ def run_forward(args):
                                     "note": "frac = the stage run on its own; frac_in_step = HIP events inside the timed steps, where "
                                             "FeatUp-JBU's guidance-only kernels share the chip on a second stream",
                                     "traffic": None}
+        trunk_pmc = _pmc_traffic("r04_bench_pmc.json")
+        if trunk_pmc is not None and "roofline_vit" in line and B == 32 and S == 448 and args.arch == "dinov2_vits14":
+            # fabric bytes per step of the trunk's kernels (4 profiled forwards: 1 warm-up + 3 steps)
+            per = {k: v["traffic_bytes_per_launch"] * v["FETCH_SIZE"]["launches"] / 4.0 for k, v in trunk_pmc["kernels"].items()
+                   if k.startswith(("gemm_tile_kernel", "attention64", "layernorm_kernel", "patchify_rows")) and "traffic_bytes_per_launch" in v}
+            line["roofline_vit"]["traffic"] = sum(per.values())
+            line["roofline_vit"]["traffic_note"] = ("fabric bytes per step summed over the trunk's kernels (GEMMs, attention, LayerNorm, patch matrix), "
+                                                    "rocprofv3 --pmc passes of this program (profiles/r04_bench_pmc.json)")
+            att = [v for k, v in trunk_pmc["kernels"].items() if k.startswith("attention64") and "traffic_bytes_per_launch" in v]
+            if att:
+                line["_attention_traffic_per_launch"] = att[0]["traffic_bytes_per_launch"]
         att_ms = (st or {}).get("attention_launch_ms") or (float(np.mean(att_in)) if att_in else None)
         if att_ms:
             fl = B * attention_flops(D, L, h * w) / L
@@ -798,7 +809,8 @@ def run_forward(args):
                                           "bound": "mfma", "achieved": fl / (att_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                                           "unit": "TFLOP/s", "frac": fl / (att_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                                           "launch_ms": att_ms, "launch_ms_in_step_beside_jbu_records": float(np.mean(att_in)) if att_in else None,
-                                          "launches_per_step": L, "flops_per_launch": fl, "traffic": None}
+                                          "launches_per_step": L, "flops_per_launch": fl, "traffic": line.pop("_attention_traffic_per_launch", None)}
+        line.pop("_attention_traffic_per_launch", None)
         up_ms_in = t_up.mean_ms()
         up_ms_seq = None if not st else st.get("upsampler(+resize)_ms", st.get("upsampler_ms"))
         by = upsampler_bytes(args.upsampler, D, h, w, S, S)
