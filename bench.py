@@ -717,6 +717,30 @@ def run_forward(args):
         finally:
             model.head_f16, conv_heads.HEAD_F16 = saved
 
+    # The same steps with FeatUp-JBU's guidance-only records on the MAIN stream (ISEGPROBE_JBU_SIDE_STREAM=0): what the overlap on
+    # the second stream buys, and the trunk's in-step time when nothing shares the chip with it.  Never `value`.
+    alt_serial = None
+    if fused_jbu and world == 1 and not args.no_alt:
+        saved_env = os.environ.get("ISEGPROBE_JBU_SIDE_STREAM")
+        os.environ["ISEGPROBE_JBU_SIDE_STREAM"] = "0"
+        try:
+            with torch.no_grad():
+                for _ in range(2):
+                    model(image, points)
+                barrier()
+                with OpTimer(model.backbone, ("forward_fused_clicks",)) as t_vit_serial:
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        model(image, points)
+                    barrier()
+                    dts = time.perf_counter() - t0
+            alt_serial = (dts, t_vit_serial.mean_ms())
+        finally:
+            if saved_env is None:
+                os.environ.pop("ISEGPROBE_JBU_SIDE_STREAM", None)
+            else:
+                os.environ["ISEGPROBE_JBU_SIDE_STREAM"] = saved_env
+
     if rank == 0:
         B, S, D, L = args.batch, args.size, vit["embed_dim"], vit["depth"]
         h = w = S // 14
@@ -763,6 +787,14 @@ def run_forward(args):
             alg = B * S * S * (2.0 * xin.shape[3] * 2 + Wt.shape[0] * 2 + 4.0 * ops._lib.lib().isp_conv3x3_partial_slots(Wt.shape[0])) / 2
             line["roofline"]["algorithmic_bytes_per_launch"] = alg
             line["roofline"]["traffic_over_algorithmic"] = traffic / alg
+        if alt_serial is not None:
+            fl_v = B * vit_flops(D, L, h * w)
+            line["alt_records_on_main_stream"] = {
+                "value": B * args.steps / alt_serial[0], "unit": "images/sec", "ms_per_step": alt_serial[0] / args.steps * 1e3,
+                "vit_ms_in_step": alt_serial[1], "vit_frac_in_step": fl_v / (alt_serial[1] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                "note": "same steps with ISEGPROBE_JBU_SIDE_STREAM=0: the trunk runs with the chip to itself (its in-step time is its "
+                        "stand-alone time) and the step is slower -- the second stream hides the record kernels behind the trunk at the "
+                        "price of the trunk's own kernels sharing CUs with them"}
         pk = _pmc_traffic("r01_peaks.json")
         if pk is not None:
             rnd = pk["mfma_bf16_16x16x32_register_loop_tflops"]["random"]
