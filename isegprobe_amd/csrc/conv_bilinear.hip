@@ -240,11 +240,16 @@ __device__ __forceinline__ f16x4_t tr_read4(const char* p) {
 template <int OUT, bool RELU>
 __global__ __launch_bounds__(256) void conv_bilinear_blend4_kernel(const _Float16* __restrict__ z, const float* __restrict__ bias,
                                                                    void* __restrict__ out, int h, int w, int H, int W, int N,
-                                                                   float sy, float sx, int zs_bytes, int G, int abl) {
+                                                                   float sy, float sx, int zs_bytes) {
     constexpr int CB = 64, ES = 2, VEC = 8;
     constexpr int UROW = CB * ES;
-    // G channel blocks are staged per pass (their loads' latency is paid once per G blocks): [q][tap][G x 64 channels]
-    const int TAPB = G * CB * ES, QPITCH = 9 * TAPB + 16, PIECES = 9 * TAPB / 16;
+    // one 64-channel block per staging pass, [q][tap][64 channels] (two blocks per pass -- half the passes, 46 KiB of LDS --
+    // measured 1.97 against 1.76 ms)
+    constexpr int TAPB = CB * ES, QPITCH = 9 * TAPB + 16, PIECES = 9 * TAPB / 16;
+#ifndef ISP_BLEND_ABLATE  // timing builds only (-DISP_BLEND_ABLATE=1: no stores, 2: no staging, 3: neither); such a library computes garbage
+#define ISP_BLEND_ABLATE 0
+#endif
+    constexpr int abl = ISP_BLEND_ABLATE;
     constexpr int KF = 5;  // k = tap * KF + source index inside the footprint (<= 5 per axis): 15 rows, row 15 is a zero-weight dummy
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const zs = lds;
@@ -313,23 +318,22 @@ __global__ __launch_bounds__(256) void conv_bilinear_blend4_kernel(const _Float1
     const int nq = fy * fx, n_rows = 3 * fy;
     const int Y = Y0 + n;  // phase B: this lane's pixel row
 
-    for (int ng = 0; ng < N; ng += G * CB) {
-        __syncthreads();  // the previous pass's last phase A is done with zs (and its phase B with us)
-        if (!(abl & 2))  // (abl & 2, timing experiment: no staging -- the phases run on whatever the LDS holds)
-        for (int i = tid; i < nq * PIECES; i += 256) {
-            const int q = i / PIECES, pc = i - q * PIECES;
-            const int t = pc / (PIECES / 9), r = pc - t * (PIECES / 9);
-            const int qy = qy_lo + q / fx, qx = qx_lo + q % fx;
-            const _Float16* src = zb + ((size_t)qy * w + qx) * zrow + (size_t)t * N + ng + r * VEC;
-            *reinterpret_cast<uint4*>(zs + q * QPITCH + pc * 16) = *reinterpret_cast<const uint4*>(src);
-        }
-      for (int gi = 0; gi < G; ++gi) {
-        const int n0 = ng + gi * CB;
-        __syncthreads();  // stage landed (gi = 0) / the previous block's phase B is done with us
+    for (int n0 = 0; n0 < N; n0 += CB) {
+        // no barrier here: every wave is past the barrier behind the previous block's phase A, so zs is free, and a wave that
+        // finishes its phase B early starts fetching the next block while the others still store
+        if (!(abl & 2))
+            for (int i = tid; i < nq * PIECES; i += 256) {
+                const int q = i / PIECES, pc = i - q * PIECES;
+                const int t = pc / (PIECES / 9), r = pc - t * (PIECES / 9);
+                const int qy = qy_lo + q / fx, qx = qx_lo + q % fx;
+                const _Float16* src = zb + ((size_t)qy * w + qx) * zrow + (size_t)t * N + n0 + r * VEC;
+                *reinterpret_cast<uint4*>(zs + q * QPITCH + pc * 16) = *reinterpret_cast<const uint4*>(src);
+            }
+        __syncthreads();  // stage landed; the previous block's phase B is done with us
         // ---- phase A: wave `wid` forms the U rows R = wid, wid + 4, ..
         for (int R = wid; R < n_rows; R += 4) {
             const int ty = R / fy, qy = R - ty * fy;
-            const char* zr = zs + qy * fx * QPITCH + ty * 3 * TAPB + za + gi * (CB * ES);
+            const char* zr = zs + qy * fx * QPITCH + ty * 3 * TAPB + za;
             f32x4 d[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -359,8 +363,7 @@ __global__ __launch_bounds__(256) void conv_bilinear_blend4_kernel(const _Float1
                 d[c] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, bya, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             }
             const int X = X0 + px;
-            // (abl & 1, timing experiment: no stores.  The second clause is always true but opaque to the compiler, so the
-            //  arithmetic above is not removed with them.)
+            // (abl & 1: no stores.  The second clause is always true but opaque to the compiler, so the arithmetic above stays.)
             if (Y < H && X < W && !((abl & 1) && n0 + (int)blockIdx.x < 1000000)) {
                 float v[16];
 #pragma unroll
@@ -376,7 +379,6 @@ __global__ __launch_bounds__(256) void conv_bilinear_blend4_kernel(const _Float1
                 store8<OUT>(out, at_ + 32, v + 8);
             }
         }
-      }
     }
 }
 
@@ -406,15 +408,11 @@ int launch(const void* z, const float* bias, void* out, int B, int h, int w, int
     const int zs_bytes = FY * FX * (9 * CB * ES + 16);
     if (form == 4) {
         if constexpr (std::is_same<ZT, _Float16>::value) {
-            static const int abl = [] { const char* e = getenv("ISEGPROBE_BLEND_ABL"); return e ? atoi(e) : 0; }();  // timing experiments: 1 no stores, 2 no staging
-            // one 64-channel block per staging pass: two blocks per pass (half the passes, 46 KiB of LDS) measured 1.97 against 1.76 ms
-            const int G = 1, us_bytes = 3 * FY * TPX * (CB * ES);
-            const int zs4 = FY * FX * (9 * G * CB * ES + 16);
-            const int lds = zs4 + us_bytes;
+            const int lds = zs_bytes + 3 * FY * TPX * (CB * ES);
             if (relu)
-                conv_bilinear_blend4_kernel<OUT, true><<<grid, 256, lds, s>>>((const _Float16*)z, bias, out, h, w, H, W, N, sy, sx, zs4, G, abl);
+                conv_bilinear_blend4_kernel<OUT, true><<<grid, 256, lds, s>>>((const _Float16*)z, bias, out, h, w, H, W, N, sy, sx, zs_bytes);
             else
-                conv_bilinear_blend4_kernel<OUT, false><<<grid, 256, lds, s>>>((const _Float16*)z, bias, out, h, w, H, W, N, sy, sx, zs4, G, abl);
+                conv_bilinear_blend4_kernel<OUT, false><<<grid, 256, lds, s>>>((const _Float16*)z, bias, out, h, w, H, W, N, sy, sx, zs_bytes);
         }
     } else {
         const int lds = zs_bytes + 3 * FY * TPX * (CB * ES);  // 3 x 3 footprint: 10.5 + 18 KiB; 5 x 5: 29.2 + 30 KiB

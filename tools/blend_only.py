@@ -26,7 +26,7 @@ def timed(fn, n=10):
     torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 t = timed(lambda: ops.conv3x3_of_bilinear_blend(z, bias, B, h, w, H, W, N))
-print(f"blend (form {os.environ.get('ISEGPROBE_BLEND_FORM', '4')}, ablation {os.environ.get('ISEGPROBE_BLEND_ABL', '0')}): {t:.3f} ms")
+print(f"blend (form {os.environ.get('ISEGPROBE_BLEND_FORM', '4')}, ablation builds: -DISP_BLEND_ABLATE via ISEGPROBE_HIP_LIB): {t:.3f} ms")
 xb = torch.randn(B, h, w, N, device="cuda").to(torch.bfloat16)
 t = timed(lambda: ops.resize_nhwc(xb, H, W, "bilinear"))
 print(f"plain bilinear resize kernel writing the same {B * H * W * N * 2 / 1e9:.2f} GB map: {t:.3f} ms")
