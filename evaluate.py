@@ -8,6 +8,10 @@ NoC table).
     python evaluate.py +checkpoint=/path/to/ckpt +datasets=GrabCut,Berkeley eval_mode=fixed224 n_clicks=20
                                                       # the reference's Hydra form (README.md:97-103; keys of
                                                       # configs/eval_cfg.yaml; dataset roots from main_cfg_path's DATASETS)
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 evaluate.py --dataset ... --logs-path ...
+                                                      # images sharded over the GPUs of the node (one process per GPU, no
+                                                      # data-path collective); rank 0 gathers the IoU arrays and writes the
+                                                      # same table a single process would
 """
 import argparse
 import os
@@ -42,7 +46,9 @@ def main(argv=None):
                     help="feed the network at most this many clicks of each polarity (-1 = n_clicks; eval_cfg.yaml clicks_limit, "
                          "inference/utils.py:286-289 -> predictor net_clicks_limit)")
     ap.add_argument("--min-n-clicks", type=int, default=1, help="clicks before the IoU target may stop an object (eval_cfg.yaml min_n_clicks)")
-    ap.add_argument("--logs", default=None, help="directory for the results table / IoU pickles (default: a temp dir)")
+    ap.add_argument("--logs", "--logs-path", dest="logs", default=None,
+                    help="directory for the results table / IoU pickles (default: a temp dir).  Under torchrun write --logs-path: "
+                         "its own parser claims `--logs` as an abbreviation of --logs-specs")
     ap.add_argument("--host-clicker", action="store_true",
                     help="robot user + IoU on the host (numpy/scipy) as in the reference, instead of the device clicker")
     ap.add_argument("--fp32", action="store_true",
@@ -86,7 +92,17 @@ def main(argv=None):
 
     from isegprobe_amd.core.inference.utils import get_zoom_in_params
     crop = get_zoom_in_params(args.eval_mode, args.dataset_name)["target_size"]  # (model construction: the first dataset's size)
-    device = torch.device("cuda")
+    # Under torchrun every rank evaluates images rank, rank + world, ... on its own GPU.  The only exchange is the
+    # gather of the per-object IoU arrays -- host objects, so the process group is gloo (RCCL would stage them through device
+    # tensors for nothing).  ISEGPROBE_SHARE_GPU=1 puts every rank on device 0 (rehearsal on a one-GPU box).
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    shard = None
+    if world > 1:
+        from isegprobe_amd.core.utils import distributed as D
+        D.init_distributed("gloo")
+        shard = (rank, world)
+        torch.cuda.set_device(0 if os.environ.get("ISEGPROBE_SHARE_GPU", "0") == "1" else D.get_local_rank())
+    device = torch.device("cuda", torch.cuda.current_device())
     if args.checkpoint:
         from isegprobe_amd.core.inference.utils import load_is_model
         model = load_is_model(args.checkpoint, device)  # reference-format {"state_dict", "config"} (inference/utils.py:37-83)
@@ -106,14 +122,23 @@ def main(argv=None):
 
     tmp = None
     if args.synthetic:
-        tmp = tempfile.TemporaryDirectory()
-        args.dataset = str(write_synthetic_grabcut(tmp.name, args.synthetic))
+        if world > 1:  # one tree for all ranks: rank 0 writes it, the others learn its path
+            from torch import distributed as dist
+            if rank == 0:
+                tmp = tempfile.TemporaryDirectory()
+                write_synthetic_grabcut(tmp.name, args.synthetic)
+            box = [tmp.name if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            args.dataset = box[0]
+        else:
+            tmp = tempfile.TemporaryDirectory()
+            args.dataset = str(write_synthetic_grabcut(tmp.name, args.synthetic))
     if jobs is None:
         if not args.dataset:
             raise SystemExit("give --dataset, --synthetic N or +datasets=...")
         jobs = [(args.dataset_name, args.dataset)]
     from isegprobe_amd.core.inference.utils import save_iou_analysis_data, save_results
-    logs = args.logs or tempfile.mkdtemp(prefix="isegprobe_eval_")
+    logs = (args.logs or tempfile.mkdtemp(prefix="isegprobe_eval_")) if rank == 0 else None
     out = []
     for i, (name, root) in enumerate(jobs):
         dataset = get_dataset(name, root)
@@ -125,7 +150,10 @@ def main(argv=None):
                                   zoom_in_params=get_zoom_in_params(args.eval_mode, name))
         all_ious, elapsed = evaluate_dataset(dataset, predictor, pred_thr=args.thresh, max_iou_thr=max_iou_thr,
                                              min_clicks=args.min_n_clicks, max_clicks=args.n_clicks,
-                                             device_clicker=False if args.host_clicker else None)
+                                             device_clicker=False if args.host_clicker else None, shard=shard)
+        if rank:  # the gathered arrays are on every rank; the table and the log files are rank 0's
+            out.append((name, all_ious, None))
+            continue
         # the reference's table / log files (inference/utils.py:174-246,365-543); NoC thresholds up to target_iou
         res = save_results(model.upsampler.__class__.__name__, name, logs, (all_ious, elapsed), eval_mode=args.eval_mode,
                            n_clicks=args.n_clicks, target_iou=max_iou_thr if print_ious else args.target_iou, print_ious=print_ious,
@@ -133,6 +161,10 @@ def main(argv=None):
         out.append((name, all_ious, res))
         save_iou_analysis_data(name, logs, (all_ious, elapsed), eval_mode=args.eval_mode, n_clicks=args.n_clicks)
         print(f"{name}: SPC {elapsed / max(sum(len(x) for x in all_ious), 1):.4f} s; logs, IoU pickles: {logs}")
+    if world > 1:
+        from torch import distributed as dist
+        dist.barrier()  # nobody is still reading the synthetic tree when rank 0 removes it
+        dist.destroy_process_group()
     if tmp:
         tmp.cleanup()
     return out

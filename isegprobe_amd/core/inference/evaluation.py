@@ -10,16 +10,46 @@ from .clicker import Click, Clicker, DeviceClicker
 from .predictors import BasePredictor
 
 
-def evaluate_dataset(dataset, predictor: BasePredictor, **kwargs) -> Tuple[List[np.ndarray], float]:
-    all_ious = []
+def evaluate_dataset(dataset, predictor: BasePredictor, shard: Tuple[int, int] = None, **kwargs) -> Tuple[List[np.ndarray], float]:
+    """Per-object IoU arrays in dataset order, and the wall time (reference evaluation.py:22-40).
+
+    ``shard=(rank, world)``: objects of different images are independent, so rank r runs images r, r + world, ... on its own
+    GPU -- no data-path collective -- and the per-object arrays are gathered afterwards (``gather_sharded_ious``) into the
+    order the single-process loop produces; the time is the slowest rank's.  The reference evaluates on one GPU
+    (inference/utils.py:270-274); the arrays, and so every NoC / IoU figure derived from them, are the same either way."""
+    rank, world = shard if shard is not None else (0, 1)
+    mine = []  # (image index, [IoU array per object])
     start_time = time()
-    for index in range(len(dataset)):
+    for index in range(rank, len(dataset), world):
         sample = dataset.get_sample(index)
+        per_object = []
         for object_id in sample.objects_ids:
             _, sample_ious, _ = evaluate_sample(sample.image, sample.gt_mask(object_id), predictor,
                                                 sample_id=index, **kwargs)
-            all_ious.append(sample_ious)
-    return all_ious, time() - start_time
+            per_object.append(sample_ious)
+        mine.append((index, per_object))
+    elapsed = time() - start_time
+    if world > 1:
+        return gather_sharded_ious(mine, elapsed, len(dataset))
+    return [a for _, per_object in mine for a in per_object], elapsed
+
+
+def gather_sharded_ious(mine, elapsed, n_images):
+    """All ranks' (image index, per-object IoU arrays) -> the single-process list (image order, objects in ``objects_ids`` order)
+    on every rank, with the slowest rank's time.  A few KB of host objects: ``all_gather_object`` on whatever process group the
+    caller initialised."""
+    from torch import distributed as dist
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, (mine, elapsed))
+    by_index = {}
+    for part, _ in parts:
+        for index, per_object in part:
+            if index in by_index:
+                raise RuntimeError(f"image {index} was evaluated by two ranks")
+            by_index[index] = per_object
+    if sorted(by_index) != list(range(n_images)):
+        raise RuntimeError(f"sharded evaluation covered {len(by_index)} of {n_images} images")
+    return [a for index in range(n_images) for a in by_index[index]], max(t for _, t in parts)
 
 
 class _HostUser:

@@ -233,3 +233,90 @@ def test_grad_bucket_survives_zero_grad():
     b.check_bound()
     m(torch.ones(2, 4)).sum().backward()
     assert b.flat.abs().sum() > 0 and m.weight.grad.data_ptr() == b.flat.data_ptr()
+
+
+class _StubDataset:
+    """Seven images with 1-3 objects each (uneven over three ranks), seeded ellipses."""
+
+    def __init__(self):
+        import numpy as np
+        self.np = np
+
+    def __len__(self):
+        return 7
+
+    def get_sample(self, index):
+        np = self.np
+        rng = np.random.default_rng(100 + index)
+        yy, xx = np.mgrid[:40, :56]
+        n_obj = 1 + index % 3
+        masks = []
+        for _ in range(n_obj):
+            cy, cx, ry, rx = rng.integers(8, 32), rng.integers(8, 48), rng.integers(4, 12), rng.integers(4, 16)
+            masks.append(((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1)
+        image = rng.integers(0, 255, (40, 56, 3)).astype(np.uint8)
+
+        class _S:
+            objects_ids = list(range(n_obj))
+
+            def gt_mask(self, i):
+                return masks[i]
+        s = _S()
+        s.image = image
+        return s
+
+
+class _StubPredictor:
+    """A deterministic 'network': a probability map that depends on the image and grows a disk around every positive click."""
+    device = "cpu"
+
+    def set_input_image(self, image):
+        import numpy as np
+        self.base = image[..., 0].astype(np.float32) / 1024.0
+
+    def get_prediction(self, clicker):
+        import numpy as np
+        p = self.base.copy()
+        yy, xx = np.mgrid[:p.shape[0], :p.shape[1]]
+        for k, c in enumerate(clicker.clicks_list):
+            d = (yy - c.coords[0]) ** 2 + (xx - c.coords[1]) ** 2 <= (4 + k) ** 2
+            p[d] = 0.9 if c.is_positive else 0.1
+        return p
+
+
+def _eval_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from isegprobe_amd.core.inference.evaluation import evaluate_dataset
+    dist.init_process_group("gloo", init_method="env://")
+    ious, elapsed = evaluate_dataset(_StubDataset(), _StubPredictor(), shard=(rank, world), pred_thr=0.5, max_iou_thr=0.6,
+                                     max_clicks=6, device_clicker=False)
+    if rank == world - 1:  # every rank holds the gathered list; report the last one's
+        out.put(([a.tolist() for a in ious], elapsed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_equals_single_process():
+    """evaluate_dataset(shard=(rank, world)) on three gloo ranks: the gathered per-object IoU arrays are the single-process list,
+    element for element and in its order (7 images, 1-3 objects each: uneven shards)."""
+    from isegprobe_amd.core.inference.evaluation import evaluate_dataset
+    from isegprobe_amd.core.inference.utils import compute_noc_metric
+    ref, _ = evaluate_dataset(_StubDataset(), _StubPredictor(), pred_thr=0.5, max_iou_thr=0.6, max_clicks=6, device_clicker=False)
+    assert len(ref) == sum(1 + i % 3 for i in range(7))
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 3, port, out)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got, elapsed = out.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(got) == len(ref) and elapsed > 0
+    import numpy as np
+    for a, b in zip(got, ref):
+        assert np.array_equal(np.asarray(a, np.float32), b)
+    assert compute_noc_metric([np.asarray(a, np.float32) for a in got], [0.8, 0.9], 6) == compute_noc_metric(ref, [0.8, 0.9], 6)

@@ -157,3 +157,4 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(mode):
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
     if mode == "train":
         assert d["collective"]["bytes"] == 11526148 and d["collective"]["ms_per_step"] > 0 and d["config"]["parallelism"] == "dp2"
+

@@ -169,3 +169,33 @@ def test_noc_sbd_layout_16bit_path(golden, tmp_path):
           f"{[(int(i), noc[i].tolist(), g['noc_per_object'][i].tolist()) for i in differ]}; mean |dIoU| {np.abs(ious - ref).mean():.2e}")
     assert np.abs(noc.mean(0) - g["noc"]).max() <= 0.5 and len(differ) <= 6
     assert abs(ious.mean() - ref.mean()) < 5e-3
+
+
+def test_sharded_evaluation_over_two_ranks_equals_single_process(golden, tmp_path):
+    """`torchrun --nproc-per-node 2 evaluate.py` shards the 50 images over the ranks (here both ranks on the box's
+    one GPU, ISEGPROBE_SHARE_GPU=1): the IoU pickle rank 0 writes holds exactly the single-process run's arrays -- same order,
+    same values -- and one table is printed."""
+    import pickle
+    import subprocess
+    import sys
+    import evaluate
+    _, ckpt = _checkpoint(golden, tmp_path, "bilinear")
+    args = ["--checkpoint", str(ckpt), "--dataset", os.path.join(GOLDEN, "noc_grabcut"), "--dataset-name", "GrabCut",
+            "--eval-mode", "fixed56", "--n-clicks", "20", "--thresh", "0.5"]
+    (_, ref, _), = evaluate.main(args + ["--logs", str(tmp_path / "logs1")])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ISEGPROBE_SHARE_GPU="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 2000), os.path.join(root, "evaluate.py")] + args + ["--logs-path", str(tmp_path / "logs2")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.count("GrabCut: SPC") == 1  # rank 0's table only
+    pk1, pk2 = sorted((tmp_path / "logs1").rglob("*.pkl")), sorted((tmp_path / "logs2").rglob("*.pkl"))
+    assert pk2 and [p.name for p in pk1] == [p.name for p in pk2]
+    for a, b in zip(pk1, pk2):  # <logs>/ious/GrabCut_fixed56_NoBRS_20.pkl: the list of per-object IoU arrays
+        la, lb = pickle.load(open(a, "rb")), pickle.load(open(b, "rb"))
+        assert len(la) == len(lb) == len(ref) == 50
+        for x, y, z in zip(la, lb, ref):
+            assert np.array_equal(np.asarray(x), np.asarray(y)) and np.array_equal(np.asarray(x), z)
+    assert len({tuple(np.asarray(a).round(4)) for a in ref}) > 40  # the arrays differ between objects: the order is being tested
