@@ -83,6 +83,20 @@ def D_rank0():
     return int(os.environ.get("RANK", "0")) == 0
 
 
+def find_resume_checkpoint(exp_dir, prefix):
+    """The checkpoint a resumed experiment continues from (reference trainer.py:559-568): exactly one file
+    ``<exp_dir>/checkpoints/<prefix>*.pth`` -- the layout ``init_experiment`` gives an experiment (exp.py:53-56) -- or, for a
+    bare checkpoint directory such as --save writes, ``<exp_dir>/<prefix>*.pth``.  None or several matches are an error, as there."""
+    from pathlib import Path
+    root = Path(exp_dir)
+    where = root / "checkpoints" if (root / "checkpoints").is_dir() else root
+    found = sorted(where.glob(f"{prefix}*.pth"))
+    if len(found) != 1:
+        raise SystemExit(f"resume: {len(found)} checkpoints match {where}/{prefix}*.pth (exactly one expected)"
+                         + "".join(f"\n  {f}" for f in found))
+    return str(found[0])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
@@ -105,6 +119,9 @@ def main():
     ap.add_argument("--epoch-len", type=int, default=-1, help="with --dataset: samples per epoch (-1: the dataset's size)")
     ap.add_argument("--workers", type=int, default=None, help="with --dataset: DataLoader workers (dataloader.workers)")
     ap.add_argument("--weights", default=None, help="checkpoint whose tensors initialise the model (reference training.weights, trainer.py:550-557)")
+    ap.add_argument("--resume-exp", default=None, help="experiment directory to continue (reference training.resume_exp): loads the ONE "
+                                                       "checkpoint <dir>/checkpoints/<--resume-prefix>*.pth (trainer.py:559-568); --weights wins")
+    ap.add_argument("--resume-prefix", default="latest", help="reference training.resume_prefix (train_cfg.yaml:33), e.g. last_checkpoint or 004")
     ap.add_argument("--start-epoch", type=int, default=0, help="with --dataset: continue at this epoch (training.start_epoch: the LR "
                                                                "schedule is advanced to it, trainer.py:168-170)")
     ap.add_argument("--validate", action="store_true", help="with --dataset: a validation pass over <root>/val.txt after every epoch "
@@ -133,6 +150,10 @@ def main():
             args.weights = str(cfg["training"]["weights"])
         if "training.start_epoch" in given:
             args.start_epoch = int(cfg["training"]["start_epoch"])
+        if cfg["training"].get("resume_exp"):
+            args.resume_exp = str(cfg["training"]["resume_exp"])
+        if "training.resume_prefix" in given:
+            args.resume_prefix = str(cfg["training"]["resume_prefix"])
         if "datasets.SBD_PATH" in given:
             args.dataset = str(cfg["datasets"]["SBD_PATH"])
         tp = cfg["training_params"]
@@ -165,6 +186,8 @@ def main():
     torch.manual_seed(0)  # identical initial weights on every rank
     model = iSegProbeModel(**model_configs(args.model, args.size, args.arch, args.upsampler, args.injection),
                            use_disks=True, norm_radius=5, with_prev_mask=True).cuda()
+    if args.weights is None and args.resume_exp:
+        args.weights = find_resume_checkpoint(args.resume_exp, args.resume_prefix)
     if args.weights:
         from isegprobe_amd.core.training.trainer import load_weights
         msg = load_weights(model, args.weights)
