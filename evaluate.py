@@ -51,12 +51,16 @@ def main(argv=None):
                          "its own parser claims `--logs` as an abbreviation of --logs-specs")
     ap.add_argument("--host-clicker", action="store_true",
                     help="robot user + IoU on the host (numpy/scipy) as in the reference, instead of the device clicker")
+    ap.add_argument("--save-feats", type=int, default=0, metavar="N",
+                    help="dump the low- / high-resolution features of the first click of the first N images under "
+                         "<logs>/feats/<dataset>/ (eval_cfg.yaml save_feats / save_feats_for_n_imgs, inference/utils.py:587-627)")
     ap.add_argument("--fp32", action="store_true",
                     help="checking mode: fp32-accurate arithmetic (model.forward_fp32, three bf16 products; 3-4x slower)")
     from isegprobe_amd.core.utils.overrides import DATASET_PATH_KEYS, EVAL_DEFAULTS, apply_overrides, split_overrides
     overrides, rest = split_overrides(argv)
     args = ap.parse_args(rest)
     jobs = None  # [(dataset name, root)]
+    feats_folder = "features"
     print_ious, iou_analysis = True, False
     if overrides:
         cfg = apply_overrides(EVAL_DEFAULTS, overrides)
@@ -72,6 +76,8 @@ def main(argv=None):
         args.min_n_clicks, iou_analysis = int(cfg["min_n_clicks"]), bool(cfg["iou_analysis"])
         if cfg["logs_path"]:
             args.logs = str(cfg["logs_path"])
+        if cfg["save_feats"]:
+            args.save_feats, feats_folder = int(cfg["save_feats_for_n_imgs"]), str(cfg["save_feats_folder_name"])
         if "datasets" in given and not args.dataset and not args.synthetic:
             import yaml
             if not os.path.exists(str(cfg["main_cfg_path"])):
@@ -148,7 +154,12 @@ def main(argv=None):
             predictor_params["net_clicks_limit"] = args.n_clicks if args.clicks_limit == -1 else args.clicks_limit
         predictor = get_predictor(model, "NoBRS", device, prob_thresh=args.thresh, predictor_params=predictor_params,
                                   zoom_in_params=get_zoom_in_params(args.eval_mode, name))
+        feats_callback = None
+        if args.save_feats and rank == 0 and world == 1:
+            from isegprobe_amd.core.inference.utils import get_save_feats_callback
+            feats_callback = get_save_feats_callback(logs, name, feats_folder, exec_for_n_imgs=args.save_feats)
         all_ious, elapsed = evaluate_dataset(dataset, predictor, pred_thr=args.thresh, max_iou_thr=max_iou_thr,
+                                             feats_callback=feats_callback,
                                              min_clicks=args.min_n_clicks, max_clicks=args.n_clicks,
                                              device_clicker=False if args.host_clicker else None, shard=shard)
         if rank:  # the gathered arrays are on every rank; the table and the log files are rank 0's

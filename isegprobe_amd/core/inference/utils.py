@@ -139,6 +139,40 @@ def save_iou_analysis_data(dataset_name, logs_path, dataset_results, eval_mode="
     return path
 
 
+def get_save_feats_callback(logs_path, dataset_name, save_folder_name="features", exec_for_n_imgs=10):
+    """``feats_callback`` of ``evaluate_sample`` that dumps the raw features of the first click of the first ``exec_for_n_imgs``
+    images (reference inference/utils.py:587-627, eval_cfg.yaml ``save_feats``): ``<logs>/feats/<dataset>/<folder>_<time>/
+    <sample>_<click>_{LowRes,HighRes}.pth`` -- here contiguous fp32 NCHW CPU tensors, whatever layout / dtype the HIP path held
+    them in -- and ``images/<sample>_<click>_image.jpg``, the image with the clicks drawn (PIL; the reference draws with OpenCV)."""
+    from datetime import datetime
+    from pathlib import Path
+
+    import torch
+    save_path = Path(logs_path) / "feats" / dataset_name / f"{save_folder_name}_{datetime.now().strftime('%Y-%m-%d_%H:%M')}"
+    (save_path / "images").mkdir(parents=True, exist_ok=True)
+
+    def callback(image, feats, sample_id, click_indx, clicks_list):
+        if sample_id >= exec_for_n_imgs or click_indx >= 1:
+            return None
+        from PIL import Image, ImageDraw
+
+        from ..model._tensor import to_nchw_f32
+        for k, v in feats.items():
+            torch.save(to_nchw_f32(v).cpu(), str(save_path / f"{sample_id}_{click_indx}_{k}.pth"))
+        if isinstance(image, dict):
+            image = image["image"]
+        pic = Image.fromarray(np.ascontiguousarray(image).astype(np.uint8))
+        draw = ImageDraw.Draw(pic)
+        for click in clicks_list or ():
+            y, x = click.coords
+            colour = (0, 255, 0) if click.is_positive else (255, 0, 0)
+            draw.ellipse((x - 6, y - 6, x + 6, y + 6), fill=colour, outline=colour)
+        pic.save(str(save_path / "images" / f"{sample_id}_{click_indx}_image.jpg"))
+
+    callback.save_path = save_path
+    return callback
+
+
 def load_single_is_model(state_dict, device, eval_ritm=False, **kwargs):
     """core/inference/utils.py:60-83: rebuild the model from the checkpoint's config, load the saved (trainable) weights
     over the freshly constructed ones, freeze, move, eval.  ``eval_ritm`` keeps the reference's positional slot

@@ -66,7 +66,7 @@ EVAL_DEFAULTS = {
     "mode": "NoBRS", "checkpoint": None, "exp_path": "", "datasets": "GrabCut,Berkeley,SBD,DAVIS", "gpus": "0", "cpu": False,
     "target_iou": 0.90, "iou_analysis": False, "n_clicks": 20, "min_n_clicks": 1, "thresh": 0.5, "clicks_limit": None,
     "eval_mode": "fixed224", "eval_ritm": False, "save_ious": False, "print_ious": True, "vis_preds": False,
-    "save_feats": False, "model_name": None, "main_cfg_path": "./configs/main_cfg.yaml", "logs_path": "", "wandb": False,
+    "save_feats": False, "save_feats_folder_name": "features", "save_feats_for_n_imgs": 50, "model_name": None, "main_cfg_path": "./configs/main_cfg.yaml", "logs_path": "", "wandb": False,
 }
 DATASET_PATH_KEYS = {"GrabCut": "GRABCUT_PATH", "Berkeley": "BERKELEY_PATH", "DAVIS": "DAVIS_PATH", "SBD": "SBD_PATH",
                      "SBD_Train": "SBD_PATH", "PascalVOC": "PASCALVOC_PATH", "COCO_MVal": "COCO_MVAL_PATH"}  # inference/utils.py:86-104

@@ -199,3 +199,23 @@ def test_sharded_evaluation_over_two_ranks_equals_single_process(golden, tmp_pat
         for x, y, z in zip(la, lb, ref):
             assert np.array_equal(np.asarray(x), np.asarray(y)) and np.array_equal(np.asarray(x), z)
     assert len({tuple(np.asarray(a).round(4)) for a in ref}) > 40  # the arrays differ between objects: the order is being tested
+
+
+def test_save_feats_dump(golden, tmp_path):
+    """evaluate.py --save-feats N (eval_cfg.yaml save_feats): LowRes / HighRes tensors of the first click of the first N images as
+    fp32 NCHW .pth files plus the image with its click; the evaluation's IoUs are untouched by the extra forward."""
+    import evaluate
+    _, ckpt = _checkpoint(golden, tmp_path, "bilinear")
+    args = ["--checkpoint", str(ckpt), "--dataset", os.path.join(GOLDEN, "noc_grabcut"), "--dataset-name", "GrabCut",
+            "--eval-mode", "fixed56", "--n-clicks", "3", "--thresh", "0.5"]
+    (_, plain, _), = evaluate.main(args + ["--logs", str(tmp_path / "a")])
+    (_, dumped, _), = evaluate.main(args + ["--logs", str(tmp_path / "b"), "--save-feats", "2"])
+    assert all(np.array_equal(x, y) for x, y in zip(plain, dumped))
+    files = sorted(p.name for p in (tmp_path / "b" / "feats" / "GrabCut").rglob("*.pth"))
+    assert files == ["0_0_HighRes.pth", "0_0_LowRes.pth", "1_0_HighRes.pth", "1_0_LowRes.pth"]
+    root = next((tmp_path / "b" / "feats" / "GrabCut").iterdir())
+    lo, hi = torch.load(root / "0_0_LowRes.pth"), torch.load(root / "0_0_HighRes.pth")
+    assert lo.dtype == hi.dtype == torch.float32 and lo.is_contiguous() and hi.is_contiguous() and not lo.is_cuda
+    assert lo.shape[0] == hi.shape[0] == 2 and lo.shape[1] == hi.shape[1]  # the flip pair; same channels
+    assert lo.shape[2:] == (4, 4) and hi.shape[2:] == (56, 56) and torch.isfinite(hi).all() and float(hi.abs().max()) > 0
+    assert sorted(p.name for p in (root / "images").iterdir()) == ["0_0_image.jpg", "1_0_image.jpg"]
