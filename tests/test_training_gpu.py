@@ -491,6 +491,38 @@ def test_train_py_on_sbd_tree(tmp_path):
     assert type(model.upsampler).__name__ == "LoftUpUpsampler" and model.backbone.feats_injection_mode == "before_backbone"
 
 
+def test_train_py_two_ranks_on_sbd_tree(tmp_path):
+    """The same entry point under `torch.distributed.run --nproc-per-node 2` with real GPU steps (both ranks on the box's one
+    GPU, gloo in place of RCCL: ISEGPROBE_SHARE_GPU=1 ISEGPROBE_DIST_BACKEND=gloo): per-rank shards of every epoch, the overlapped
+    gradient all-reduce inside the step, one log and one set of checkpoints (rank 0's), and a checkpoint that loads back."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import GOLDEN
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ckpt = str(tmp_path / "ckpts")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ISEGPROBE_SHARE_GPU="1", ISEGPROBE_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 2000), os.path.join(root, "train.py"),
+           "--dataset", os.path.join(GOLDEN, "datasets", "sbd"), "--epochs", "2", "--epoch-len", "8", "--batch", "2", "--size", "112",
+           "--workers", "0", "--model", "dinov2/patch-embed_bilinear", "--save", ckpt,
+           "training_params.lr_milestones=[1]", "training_params.checkpoint_interval=[[0,1]]"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "world 2" in out.stdout and "2 steps per rank and epoch at batch 2" in out.stdout, out.stdout[-2000:]
+    epochs = re.findall(r"Epoch (\d+), training loss ([0-9.eE+-]+|nan|inf), lr ([0-9.eE+-]+), (\d+) steps", out.stdout)
+    assert [(e[0], e[3]) for e in epochs] == [("0", "2"), ("1", "2")], out.stdout[-2000:]  # one log: rank 0's
+    assert all(np.isfinite(float(e[1])) and float(e[1]) > 0 for e in epochs)
+    assert sorted(os.listdir(ckpt)) == ["000.pth", "001.pth", "last_checkpoint.pth"]
+    import isegprobe_amd
+    from isegprobe_amd.core.inference.utils import load_is_model
+    isegprobe_amd.install_as_core()
+    model = load_is_model(os.path.join(ckpt, "last_checkpoint.pth"), torch.device("cuda"))
+    assert type(model.upsampler).__name__ == "BilinearUpsampler"
+
+
 @pytest.mark.parametrize("upsampler", ["bilinear", "loftup", "lift"])
 def test_before_backbone_gradients_with_oracle_relu_masks(upsampler):
     """The reference's default training mode (clicks before the backbone, models/sbd/dinov2/patch-embed_*.py:40) held tighter

@@ -181,8 +181,13 @@ def main():
     from isegprobe_amd.core.training.trainer import DataParallelTrainer
     from isegprobe_amd.core.utils import distributed as D
 
-    distributed = D.init_distributed()
-    torch.cuda.set_device(D.get_local_rank())
+    # ISEGPROBE_DIST_BACKEND=gloo ISEGPROBE_SHARE_GPU=1: rehearsal of the multi-rank run on a one-GPU box (every rank on device 0,
+    # gloo over device tensors in place of RCCL, which wants one device per rank) -- as bench.py and evaluate.py take them
+    share = os.environ.get("ISEGPROBE_SHARE_GPU", "0") == "1"
+    if share:
+        torch.cuda.set_device(0)
+    distributed = D.init_distributed(os.environ.get("ISEGPROBE_DIST_BACKEND") or None)
+    torch.cuda.set_device(0 if share else D.get_local_rank())
     torch.manual_seed(0)  # identical initial weights on every rank
     model = iSegProbeModel(**model_configs(args.model, args.size, args.arch, args.upsampler, args.injection),
                            use_disks=True, norm_radius=5, with_prev_mask=True).cuda()
