@@ -7,7 +7,9 @@
  * distanceTransform_5x5): fixed point with DIST_SHIFT = 16, step costs a = 1, b = 1.4, c = 2.1969 (the
  * DIST_L2 / 5x5 metrics of getDistanceTransformMask) rounded to integers, a forward raster pass over the
  * causal half of the 5x5 neighbourhood, a backward pass over the other half, INT_MAX>>2 outside the image,
- * result (float)(t * 2^-16).  No reference test pins it: PARITY UNPINNED (see oracle/__init__.py). */
+ * result (float)(t * 2^-16).  No reference test pins it: PARITY UNPINNED (see oracle/__init__.py).  What CAN be checked here is:
+ * known answers of the mask, and that the two passes equal the exact shortest-path distance of the 5x5 mask's 16 moves
+ * (Dijkstra, tests/test_click_sim_cpu.py) -- i.e. only the constants and the fixed-point format rest on the recollection. */
 #include <limits.h>
 #include <stdint.h>
 #include <stdlib.h>
