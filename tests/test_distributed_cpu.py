@@ -238,12 +238,12 @@ def test_grad_bucket_survives_zero_grad():
 class _StubDataset:
     """Seven images with 1-3 objects each (uneven over three ranks), seeded ellipses."""
 
-    def __init__(self):
+    def __init__(self, n=7):
         import numpy as np
-        self.np = np
+        self.np, self.n = np, n
 
     def __len__(self):
-        return 7
+        return self.n
 
     def get_sample(self, index):
         np = self.np
@@ -284,13 +284,13 @@ class _StubPredictor:
         return p
 
 
-def _eval_worker(rank, world, port, out):
+def _eval_worker(rank, world, port, out, n_images=7):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import torch.distributed as dist
     from isegprobe_amd.core.inference.evaluation import evaluate_dataset
     dist.init_process_group("gloo", init_method="env://")
-    ious, elapsed = evaluate_dataset(_StubDataset(), _StubPredictor(), shard=(rank, world), pred_thr=0.5, max_iou_thr=0.6,
+    ious, elapsed = evaluate_dataset(_StubDataset(n_images), _StubPredictor(), shard=(rank, world), pred_thr=0.5, max_iou_thr=0.6,
                                      max_clicks=6, device_clicker=False)
     if rank == world - 1:  # every rank holds the gathered list; report the last one's
         out.put(([a.tolist() for a in ious], elapsed))
@@ -298,17 +298,18 @@ def _eval_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_sharded_evaluation_equals_single_process():
-    """evaluate_dataset(shard=(rank, world)) on three gloo ranks: the gathered per-object IoU arrays are the single-process list,
-    element for element and in its order (7 images, 1-3 objects each: uneven shards)."""
+@pytest.mark.parametrize("world,n_images", [(3, 7), (4, 3)])
+def test_sharded_evaluation_equals_single_process(world, n_images):
+    """evaluate_dataset(shard=(rank, world)) on gloo ranks: the gathered per-object IoU arrays are the single-process list,
+    element for element and in its order (1-3 objects per image: uneven shards; with 4 ranks and 3 images one rank has nothing)."""
     from isegprobe_amd.core.inference.evaluation import evaluate_dataset
     from isegprobe_amd.core.inference.utils import compute_noc_metric
-    ref, _ = evaluate_dataset(_StubDataset(), _StubPredictor(), pred_thr=0.5, max_iou_thr=0.6, max_clicks=6, device_clicker=False)
-    assert len(ref) == sum(1 + i % 3 for i in range(7))
+    ref, _ = evaluate_dataset(_StubDataset(n_images), _StubPredictor(), pred_thr=0.5, max_iou_thr=0.6, max_clicks=6, device_clicker=False)
+    assert len(ref) == sum(1 + i % 3 for i in range(n_images))
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_eval_worker, args=(r, 3, port, out)) for r in range(3)]
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, out, n_images)) for r in range(world)]
     for p in procs:
         p.start()
     got, elapsed = out.get(timeout=180)
