@@ -277,7 +277,7 @@ def test_bn_train_kernels_vs_torch():
 
 
 # ------------------------------------------------------------------ device click simulation
-@pytest.mark.parametrize("B,H,W,P", [(2, 56, 70, 3), (3, 224, 224, 24), (1, 300, 448, 5), (2, 17, 9, 2)])
+@pytest.mark.parametrize("B,H,W,P", [(2, 56, 70, 3), (3, 224, 224, 24), (1, 300, 448, 5), (2, 17, 9, 2), (1, 62, 126, 2), (2, 3, 130, 1)])
 def test_device_next_points_matches_oracle(B, H, W, P):
     """get_next_points on the device == the oracle (C restatement of OpenCV's 5x5 chamfer transform + the
     reference's selection logic, trainer.py:575-618) for the same uniform draws: identical points tensors.
@@ -312,6 +312,20 @@ def test_device_next_points_matches_oracle(B, H, W, P):
                                   torch.from_numpy(points).cuda(), click_indx, torch.from_numpy(draws), workspace=ws)
         assert np.array_equal(got.cpu().numpy(), ref), (trial, got.cpu().numpy(), ref)
         points = ref
+        if trial == 0:
+            # the distance planes themselves, every pixel: the workspace holds them skewed (csrc/click_sim.hip: padded pixel
+            # (i, j) of sample b, mask m at [b][m][j + 3 i][i], rows of ((H + 2 + 63) // 64) * 64 words)
+            PH, PW = H + 2, W + 2
+            T, PHS = PW + 3 * (PH - 1), (PH + 63) // 64 * 64
+            planes = ws[: B * 2 * T * PHS * 4].view(torch.int32).view(B, 2, T, PHS).cpu().numpy().astype(np.int64)
+            ii, jj = np.mgrid[:PH, :PW]
+            g = gt[:, 0] > 0.5
+            masks = (g & (pred[:, 0] < 0.49), ~g & (pred[:, 0] > 0.49))  # FN, FP (trainer.py:585-590)
+            for b in range(B):
+                for m in range(2):
+                    want = osim.chamfer5(np.pad(masks[m][b], 1).astype(np.uint8))
+                    got_dt = (planes[b, m][jj + 3 * ii, ii].astype(np.float64) / 65536.0).astype(np.float32)
+                    assert np.array_equal(got_dt, want), (b, m, np.abs(got_dt - want).max())
     # a sample whose prediction is perfect has no inner pixel: its row of points must stay untouched
     perfect = (gt > 0.5).astype(np.float32)
     ref = osim.get_next_points(perfect, gt, points, 1, np.zeros(B, np.int64))
