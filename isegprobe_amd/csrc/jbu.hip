@@ -342,6 +342,11 @@ __global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const void* __restr
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
                     wf[ot][ks] = *reinterpret_cast<const f16x8_t*>(wsrc + (ot * 16 + fr) * 64 + ks * 32 + fq * 8);
+            // (the layer's biases once, not per (pixel tile, unit tile): inside the loops each was a global load with its own
+            //  wait -- 32 L2 round trips in series per workgroup)
+            float4 bias4[4];
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) bias4[ot] = *reinterpret_cast<const float4*>(bsrc + ot * 16 + fq * 4);
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt) {
                 const int row = wv * 64 + pt * 16 + fr;  // B operand: X[pixel = row][k..k+7]
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void jbu_kernels_kernel(const void* __restr
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ot][0], x0, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ot][1], x1, acc, 0, 0, 0);
                     // D[unit = 16*ot + 4*fq + j][pixel = row]
-                    const float4 bb = *reinterpret_cast<const float4*>(bsrc + ot * 16 + fq * 4);
+                    const float4 bb = bias4[ot];
                     float r0 = acc[0] + bb.x, r1 = acc[1] + bb.y, r2 = acc[2] + bb.z, r3 = acc[3] + bb.w;
                     if (layer == 0) {
                         r0 = gelu_sig5(r0), r1 = gelu_sig5(r1), r2 = gelu_sig5(r2), r3 = gelu_sig5(r3);
