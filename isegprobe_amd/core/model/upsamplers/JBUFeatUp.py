@@ -228,23 +228,36 @@ class _JBUFn(torch.autograd.Function):
             kcs.append(kc)
             x = ops.jbu_apply(x, kc, BF16 if i == 3 else ops.F16)
         conv = stack.fixup_proj[1]
-        w = conv.weight.detach().flatten(1).to(BF16).contiguous()
+        w32 = conv.weight.detach().flatten(1).float()
+        bias = conv.bias.detach().float().contiguous()
         B, H, W, C = x.shape
-        fix = None if drops is None else drops["fixup"].to(BF16).view(B, 1, 1, C)
-        xin = x if fix is None else (x * fix).contiguous()  # z = x + 0.1 (W (m o x) + b)
-        y = ops.linear_axpy_res(xin.view(-1, C), w, conv.bias.detach().float().contiguous(), x.view(-1, C), 0.1)
-        ctx.kcs, ctx.wT, ctx.fix = kcs, conv.weight.detach().flatten(1).t().contiguous().to(BF16), fix
-        return y.view(B, H, W, C)
+        if drops is None:
+            y = ops.linear_axpy_res(x.view(-1, C), w32.to(BF16).contiguous(), bias, x.view(-1, C), 0.1).view(B, H, W, C)
+            ctx.wT = w32.t().contiguous().to(BF16)
+        else:
+            # Dropout2d(0.2) in front of the 1x1 conv: z = x + 0.1 (W (m o x) + b) with one multiplier per (image, channel), i.e.
+            # image b sees the weights W diag(m_b) -- folded into B small weight matrices, one GEMM per image, instead of
+            # masking (and, in the backward, converting / scaling / adding) the full-resolution map with framework kernels
+            m = drops["fixup"].float().view(B, 1, C)
+            wb = (w32[None] * m).to(BF16).contiguous()              # [B, C_out, C_in]: W diag(m_b)
+            y = torch.empty_like(x)
+            for bi in range(B):
+                ops.linear_axpy_res(x[bi].view(-1, C), wb[bi], bias, x[bi].view(-1, C), 0.1, out=y[bi].view(-1, C))
+            ctx.wT = wb.transpose(1, 2).contiguous()                # [B, C_in, C_out]: (W diag(m_b))^T
+        ctx.kcs, ctx.per_image = kcs, drops is not None
+        return y
 
     @staticmethod
     def backward(ctx, g_out):
         B, H, W, C = g_out.shape
-        g = g_out.contiguous().view(-1, C)
-        if ctx.fix is None:
-            g = ops.linear_axpy_res(g, ctx.wT, None, g, 0.1).view(B, H, W, C)  # (I + 0.1 W)^T
-        else:  # (I + 0.1 W diag(m))^T g = g + 0.1 m o (W^T g)
-            t = ops.linear(g, ctx.wT).view(B, H, W, C)
-            g = (g.view(B, H, W, C).float() + 0.1 * (t * ctx.fix).float()).to(BF16)
+        g = g_out.contiguous()
+        if not ctx.per_image:
+            g = ops.linear_axpy_res(g.view(-1, C), ctx.wT, None, g.view(-1, C), 0.1).view(B, H, W, C)  # (I + 0.1 W)^T
+        else:  # (I + 0.1 W diag(m_b))^T g_b, image by image
+            gi = torch.empty_like(g)
+            for bi in range(B):
+                ops.linear_axpy_res(g[bi].view(-1, C), ctx.wT[bi], None, g[bi].view(-1, C), 0.1, out=gi[bi].view(-1, C))
+            g = gi
         for kc in reversed(ctx.kcs):
             g = ops.jbu_apply_bwd(g, kc)
         ctx.kcs = None

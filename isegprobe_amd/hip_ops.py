@@ -802,11 +802,16 @@ def jbu_apply_bwd(gout, kc):
     return gsrc
 
 
-def linear_axpy_res(A, Wt, bias, res, alpha):
-    """bf16 (or f16, all operands alike): res + alpha * (A Wt^T + bias)."""
+def linear_axpy_res(A, Wt, bias, res, alpha, out=None):
+    """bf16 (or f16, all operands alike): res + alpha * (A Wt^T + bias); ``out`` (same shape / dtype, contiguous) to write into."""
     _need(res, A.dtype, "res")
     N = Wt.shape[0]
-    out = torch.empty(A.shape[0], N, device=A.device, dtype=A.dtype)
+    if out is None:
+        out = torch.empty(A.shape[0], N, device=A.device, dtype=A.dtype)
+    else:
+        _need(out, A.dtype, "out")
+        if tuple(out.shape) != (A.shape[0], N):
+            raise IspError("linear_axpy_res: out shape mismatch")
     gemm(A, Wt, _epilogue(_lib.EP_AXPY_RES_BF16, out, N, bias, res=res, alpha=alpha))
     return out
 
