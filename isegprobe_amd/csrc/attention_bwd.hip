@@ -170,10 +170,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
     const int per = (nt_all + gridDim.z - 1) / gridDim.z;
     const int t_begin = blockIdx.z * per, nt = min(nt_all, t_begin + per);
     if (t_begin >= nt) return;
+    // dK/dV launch: log-sum-exp and delta of the streamed (query) rows, one tile ahead in registers.  (Loaded inside the
+    // sub-tile loop they were two global round trips per 16 streamed rows in front of the exponentials -- behind the next
+    // tile's LDS-DMA in the vmcnt queue, so the first of them also waited for that.)
+    constexpr int NMI = G::STR / 16;
+    float4 l_nxt[NMI], d_nxt[NMI];
+    auto fetch_stats = [&](int t) {
+#pragma unroll
+        for (int mi = 0; mi < NMI; ++mi) {
+            const size_t at = stat_row + (size_t)t * G::STR + 16 * mi + 4 * fq;
+            l_nxt[mi] = *reinterpret_cast<const float4*>(lse + at);
+            d_nxt[mi] = *reinterpret_cast<const float4*>(delta + at);
+        }
+    };
+    if (OWN_KEYS) fetch_stats(t_begin);
     stage(t_begin, smem);
     __syncthreads();
     for (int t = t_begin; t < nt; ++t) {
         const char* buf = smem + ((t - t_begin) & 1) * STAGE;
+        float4 l_cur[NMI], d_cur[NMI];
+        if (OWN_KEYS) {
+#pragma unroll
+            for (int mi = 0; mi < NMI; ++mi) l_cur[mi] = l_nxt[mi], d_cur[mi] = d_nxt[mi];
+            if (t + 1 < nt) fetch_stats(t + 1);  // (in front of the DMA issue: older in the vmcnt queue)
+        }
         if (t + 1 < nt) stage(t + 1, smem + ((t - t_begin + 1) & 1) * STAGE);
 #pragma unroll
         for (int mi = 0; mi < G::STR / 16; ++mi) {  // 16 streamed rows s = 16mi + 4fq + r at a time, owner o = fr
@@ -194,8 +214,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
             const int sbase = t * G::STR + 16 * mi + 4 * fq;
             float l4[4], d4[4];
             if (OWN_KEYS) {  // statistics belong to the streamed (query) rows; buffers are padded to 64
-                const float4 lv = *reinterpret_cast<const float4*>(lse + stat_row + sbase);
-                const float4 dv = *reinterpret_cast<const float4*>(delta + stat_row + sbase);
+                const float4 lv = l_cur[mi], dv = d_cur[mi];
                 l4[0] = lv.x, l4[1] = lv.y, l4[2] = lv.z, l4[3] = lv.w;
                 d4[0] = dv.x, d4[1] = dv.y, d4[2] = dv.z, d4[3] = dv.w;
             }
