@@ -231,17 +231,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(Side own, Side str, const
                 }
             }
             // out1^T += stream1^T . dS ; out2^T += stream2^T . P   (contraction over these 16 streamed rows)
+            // (all transposed fragments of the sub-tile first: read one by one in front of their MFMAs, every product waited for
+            //  its own LDS round trip)
+            s16x4 a1v[DT], a2v[DT];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const s16x4 a1 = tr_read(buf + 2 * TILE + mi * 16 * G::ROW + t_off[dt]);
+                a1v[dt] = tr_read(buf + 2 * TILE + mi * 16 * G::ROW + t_off[dt]);
+                if (OWN_KEYS) a2v[dt] = tr_read(buf + 3 * TILE + mi * 16 * G::ROW + t_off[dt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
                 for (int ow = 0; ow < OW; ++ow)
-                    acc1[ow][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1, ds[ow], acc1[ow][dt], 0, 0, 0);
+                    acc1[ow][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1v[dt], ds[ow], acc1[ow][dt], 0, 0, 0);
                 if (OWN_KEYS) {
-                    const s16x4 a2 = tr_read(buf + 3 * TILE + mi * 16 * G::ROW + t_off[dt]);
 #pragma unroll
                     for (int ow = 0; ow < OW; ++ow)
-                        acc2[ow][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2, pp[ow], acc2[ow][dt], 0, 0, 0);
+                        acc2[ow][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a2v[dt], pp[ow], acc2[ow][dt], 0, 0, 0);
                 }
             }
         }
