@@ -154,6 +154,14 @@ int isp_conv3x3_partial_slots(int N);
 int isp_conv3x3_of_bilinear_supported(int h, int w, int H, int W, int N, int z_dtype);
 int isp_conv3x3_of_bilinear_blend(const void* z, int z_dtype, const float* bias, void* out, int out_dtype, int B, int h, int w,
                                   int H, int W, int N, int relu, void* stream);
+/* Training: adjoint of that blend w.r.t. the tap planes.  g [B,H,W,N] bf16 = gradient of the PRE-activation (the caller has
+ * applied the ReLU mask, e.g. isp_relu_mask_colsum, which also yields the bias gradient); dz [B*h*w, 9*N] bf16 =
+ * sum_p [p+t inside] a(p+t, q) g[p][n] -- from which dx = dz Wz and dWz = dz^T x are two small GEMMs at low resolution (autograd of
+ * trainer.py:214-232 through iseg_probe_model.py:120-129 + conv_heads.py:59-73).  Gathers, nothing atomic.  N % 8 == 0;
+ * workspace: isp_conv3x3_of_bilinear_bwd_workspace_bytes(B, h, W, N) bytes (the row-adjoint, fp32). */
+long isp_conv3x3_of_bilinear_bwd_workspace_bytes(int B, int h, int W, int N);
+int isp_conv3x3_of_bilinear_blend_bwd(const void* g_bf16, void* dz_bf16, void* workspace, int B, int h, int w, int H, int W, int N,
+                                      void* stream);
 int isp_sum_partials_f32(const float* partial, float* out, long M, int slots, float bias, void* stream);
 
 /* ---- LayerNorm over the last dim (fp32 statistics), nn.LayerNorm(eps) of DINOv2.py:98 and

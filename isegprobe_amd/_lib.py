@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ISEGPROBE_HIP_LIB") or os.path.join(_HERE, "csrc", "libisegprobe_hip.so")  # env override: kernel A/B experiments
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 ISP_F32, ISP_BF16, ISP_F16 = 0, 1, 2
 EP_BIAS_BF16, EP_BIAS_RELU_BF16, EP_BIAS_GELU_BF16, EP_BIAS_F32, EP_RESIDUAL_F32, EP_TOKENS_F32, EP_AXPY_RES_BF16, EP_BIAS_TAPS_RELU_BF16, EP_RELU_DOT_PARTIAL_F32, EP_BIAS_QGELU_BF16, EP_BIAS_GELU_SAVE_BF16, EP_MUL_DGELU_BF16, EP_BIAS_QGELU_SAVE_BF16, EP_MUL_DQGELU_BF16, EP_AXPY_RES_STATS_BF16, EP_LNFOLD_BF16, EP_LNFOLD_GELU_BF16, EP_RESIDUAL_STATS_F32, EP_LNFOLD_LAYERNORM_BF16, EP_BIAS_RELU_STATS_BF16 = range(20)
@@ -56,6 +56,8 @@ SIGNATURES = {
     "isp_conv3x3_partial_slots": [_i],
     "isp_conv3x3_of_bilinear_supported": [_i, _i, _i, _i, _i, _i],
     "isp_conv3x3_of_bilinear_blend": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "isp_conv3x3_of_bilinear_bwd_workspace_bytes": [_i, _i, _i, _i],
+    "isp_conv3x3_of_bilinear_blend_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "isp_sum_partials_f32": [_vp, _vp, _l, _i, _f, _vp],
     "isp_layernorm_fwd": [_vp, _vp, _vp, _vp, _l, _i, _f, _i, _i, _i, _i, _l, _l, _vp],
     "isp_attention_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i] + [_l] * 9 + [_f, _vp],
@@ -124,7 +126,7 @@ SIGNATURES = {
 _lib = None
 
 
-LONG_RETURNS = {"isp_robot_click_workspace_bytes", "isp_next_points_workspace_bytes"}
+LONG_RETURNS = {"isp_robot_click_workspace_bytes", "isp_next_points_workspace_bytes", "isp_conv3x3_of_bilinear_bwd_workspace_bytes"}
 
 
 def lib():

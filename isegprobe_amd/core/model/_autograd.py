@@ -86,6 +86,40 @@ def _conv3x3_grads(x, g, weight, need_dx):
     return dx, dweight
 
 
+class Conv3x3OfBilinearReluFn(torch.autograd.Function):
+    """relu(conv3x3(bilinear_ac(x, (H, W))) + bias) without the resized map, forward AND backward (iseg_probe_model.py:120-129 +
+    conv_heads.py:59-73 under autograd): x [B,h,w,C] bf16 NHWC low-resolution features, weight [N,C,3,3] fp32 -> [B,H,W,N] bf16.
+    Forward: Z = x [W_0 .. W_8]^T (one GEMM on IEEE-half operands) and the blend.  Backward: the ReLU-masked gradient goes
+    through the blend's adjoint to dZ [B h w, 9 N]; dx = dZ Wz and dWz = dZ^T x are low-resolution GEMMs -- no full-resolution
+    data-gradient conv, no full-resolution weight-gradient reduction."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, H, W):
+        B, h, w, C = x.shape
+        N = weight.shape[0]
+        wz32 = weight.detach().float().permute(2, 3, 0, 1).reshape(9 * N, C)  # rows t*N + n, t = ky*3 + kx
+        z = ops.linear(ops.to_f16(x).view(B * h * w, C), wz32.to(ops.F16).contiguous())
+        y = ops.conv3x3_of_bilinear_blend(z, bias.detach().float().contiguous(), B, h, w, H, W, N, relu=True, out_dtype=BF16)
+        ctx.save_for_backward(x, y, weight)
+        ctx.geom = (B, h, w, H, W, C, N)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, weight = ctx.saved_tensors
+        B, h, w, H, W, C, N = ctx.geom
+        m = _imposed_mask(y)
+        g, db = ops.relu_mask_colsum(gy.contiguous(), y if m is None else m)
+        dz = ops.conv3x3_of_bilinear_blend_bwd(g, B, h, w, H, W, N)
+        wz = weight.detach().float().permute(2, 3, 0, 1).reshape(9 * N, C)
+        dx = None
+        if ctx.needs_input_grad[0]:  # dx = dZ Wz: [B h w, 9N] x [9N, C]
+            dx = ops.linear(dz, wz.t().contiguous().to(BF16)).view(B, h, w, C)
+        dwz, _ = ops.linear_wgrad(dz, x.reshape(B * h * w, C), want_bias=False)  # [9N, C] f32
+        dweight = dwz.view(3, 3, N, C).permute(2, 3, 0, 1).contiguous()
+        return dx, dweight, db, None, None
+
+
 class Conv3x3ReluClassifierFn(torch.autograd.Function):
     """Last 3x3 conv + ReLU + 1x1 classifier of ConvSegHead (conv_heads.py:69-73) as one node: the
     classifier backward produces the conv's pre-activation gradient already ReLU-masked together with

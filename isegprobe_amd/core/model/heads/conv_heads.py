@@ -18,6 +18,7 @@ from .base_head import BaseClassifierHead
 
 HEAD_F16 = os.environ.get("ISEGPROBE_HEAD_F16", "1") != "0"  # f16 operands for the inference convolutions (see forward)
 CONV_OF_BILINEAR = os.environ.get("ISEGPROBE_CONV_OF_BILINEAR", "1") != "0"  # first conv through the bilinear resize (forward_of_bilinear)
+CONV_OF_BILINEAR_TRAIN = os.environ.get("ISEGPROBE_CONV_OF_BILINEAR_TRAIN", "1") != "0"  # ... in training too (its adjoint)
 HEAD_W_BITS = int(os.environ.get("ISEGPROBE_HEAD_W_BITS", "8"))  # significant bits kept in the half-format weights (8..11)
 if not 8 <= HEAD_W_BITS <= 11:
     raise ValueError(f"ISEGPROBE_HEAD_W_BITS={HEAD_W_BITS}: the half-format head weights keep 8 (bf16-valued) to 11 (full half) bits")
@@ -168,9 +169,13 @@ class _StackedHead(BaseClassifierHead):
                 and ops.conv3x3_of_bilinear_supported(h, w, H, W, conv.out_channels))
 
     def of_bilinear_applies(self, x, H, W):
-        """... and the call is an inference call on a GPU tensor."""
-        if grad_mode(self) or (torch.is_grad_enabled() and x.requires_grad) or not x.is_cuda:
+        """... and the call is on a GPU tensor: inference, or training with a bf16 stream (``forward_of_bilinear`` then records
+        ``Conv3x3OfBilinearReluFn``; ``ISEGPROBE_CONV_OF_BILINEAR_TRAIN=0`` keeps training on resize + conv)."""
+        if not x.is_cuda:
             return False
+        if grad_mode(self) or (torch.is_grad_enabled() and x.requires_grad):
+            if not CONV_OF_BILINEAR_TRAIN or x.dtype != BF16:
+                return False
         return self.of_bilinear_geometry(x.shape[1], x.shape[2], x.shape[3], H, W)
 
     def forward_of_bilinear(self, x, H, W):
@@ -181,6 +186,10 @@ class _StackedHead(BaseClassifierHead):
         of 9*C, and the [B,H,W,C] map is never written.  x: [B,C,h,w]-shaped NHWC view (bf16 or half)."""
         first = self.convs[0]
         layers = list(self.convs)[1:]
+        if grad_mode(self) or (torch.is_grad_enabled() and x.requires_grad):
+            from .._autograd import Conv3x3OfBilinearReluFn
+            y = Conv3x3OfBilinearReluFn.apply(to_nhwc_bf16(x), first.conv.weight, first.conv.bias, H, W)
+            return self._tail(y, layers)
         xl = to_nhwc_bf16(x, keep_f16=True)
         if xl.dtype != ops.F16:
             xl = ops.to_f16(xl)  # bf16 values are exact in half

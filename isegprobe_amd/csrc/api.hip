@@ -1,2 +1,2 @@
 #include "isp_common.h"
-extern "C" int isp_abi_version(void) { return 18; }
+extern "C" int isp_abi_version(void) { return 19; }

@@ -424,6 +424,99 @@ int launch(const void* z, const float* bias, void* out, int B, int h, int w, int
     return isp_launch_status();
 }
 
+// ---- adjoint of the blend (training): dZ_t[q][n] = sum_p [p + t inside] a(p + t, q) g[p][n] for the (ReLU-masked) output
+// gradient g [B, H, W, N].  Separable like the forward: along Y into V[b][qy][ty][X][n] (fp32 workspace), then along X into
+// dZ[b h w][(ty, tx) N + n].  Both kernels are gathers -- a thread owns one output entry (8 channels) and walks the ~2 / s
+// pixels whose bilinear footprint contains its source index, with the weight the forward used, (i0 == q ? 1 - l : 0) +
+// (i1 == q ? l : 0) from the same fp32 coordinate arithmetic; one load serves the three taps of the walked axis -- so nothing
+// is atomic and the result does not depend on the launch.  Memory-bound: g is read three times from L2 (once per row tap).
+__device__ __forceinline__ float tent(int d, float s, int n_in, int n_out, int q) {  // weight of source index q at output coordinate d
+    if (d < 0 || d >= n_out) return 0.f;
+    int i0, i1;
+    float l;
+    src_coord(d, s, n_in, i0, i1, l);
+    return (i0 == q ? 1.f - l : 0.f) + (i1 == q ? l : 0.f);
+}
+// output coordinates whose footprint can contain source index q: s d in (q - 1, q + 1)
+__device__ __forceinline__ void support(int q, float s, int n_out, int& lo, int& hi) {
+    if (s <= 0.f) {
+        lo = 0, hi = n_out - 1;
+        return;
+    }
+    lo = (int)floorf((float)(q - 1) / s) - 1, hi = (int)ceilf((float)(q + 1) / s) + 1;  // (one pixel of slack for the rounding)
+    lo = lo < 0 ? 0 : lo, hi = hi > n_out - 1 ? n_out - 1 : hi;
+}
+
+__global__ __launch_bounds__(256) void conv_bilinear_adj_y_kernel(const bf16_t* __restrict__ g, float* __restrict__ V, int h,
+                                                                  int H, int W, int N, float sy) {
+    const int n8 = N >> 3;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)W * n8) return;
+    const int qy = blockIdx.y, b = blockIdx.z;
+    int lo, hi;
+    support(qy, sy, H, lo, hi);
+    float acc[3][8];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    const bf16_t* gp = g + ((size_t)b * H * W) * N + idx * 8;
+    // output row y feeds tap ty through the resized-map row y + ty - 1
+    for (int y = (lo - 1 < 0 ? 0 : lo - 1); y <= (hi + 1 > H - 1 ? H - 1 : hi + 1); ++y) {
+        const float a0 = tent(y - 1, sy, h, H, qy), a1 = tent(y, sy, h, H, qy), a2 = tent(y + 1, sy, h, H, qy);
+        if (a0 == 0.f && a1 == 0.f && a2 == 0.f) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(gp + (size_t)y * W * N);
+        const unsigned* q = &v.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x0 = __uint_as_float(q[e] << 16), x1 = __uint_as_float(q[e] & 0xffff0000u);
+            acc[0][2 * e] += a0 * x0, acc[0][2 * e + 1] += a0 * x1;
+            acc[1][2 * e] += a1 * x0, acc[1][2 * e + 1] += a1 * x1;
+            acc[2][2 * e] += a2 * x0, acc[2][2 * e + 1] += a2 * x1;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        float* vp = V + ((((size_t)b * h + qy) * 3 + t) * W) * N + idx * 8;
+        *reinterpret_cast<float4*>(vp) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        *reinterpret_cast<float4*>(vp + 4) = make_float4(acc[t][4], acc[t][5], acc[t][6], acc[t][7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_bilinear_adj_x_kernel(const float* __restrict__ V, bf16_t* __restrict__ dz, int h,
+                                                                  int w, int W, int N, float sx, long total) {
+    const int n8 = N >> 3;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // ((b h + qy) w + qx) * 3 + ty) * n8 + c8
+    if (idx >= total) return;
+    const int c8 = (int)(idx % n8);
+    long r = idx / n8;
+    const int ty = (int)(r % 3);
+    r /= 3;
+    const int qx = (int)(r % w);
+    const long bq = r / w;  // b h + qy
+    int lo, hi;
+    support(qx, sx, W, lo, hi);
+    float acc[3][8];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    const float* vp = V + (((size_t)bq * 3 + ty) * W) * N + c8 * 8;
+    for (int x = (lo - 1 < 0 ? 0 : lo - 1); x <= (hi + 1 > W - 1 ? W - 1 : hi + 1); ++x) {
+        const float a0 = tent(x - 1, sx, w, W, qx), a1 = tent(x, sx, w, W, qx), a2 = tent(x + 1, sx, w, W, qx);
+        if (a0 == 0.f && a1 == 0.f && a2 == 0.f) continue;
+        const float4 u0 = *reinterpret_cast<const float4*>(vp + (size_t)x * N), u1 = *reinterpret_cast<const float4*>(vp + (size_t)x * N + 4);
+        const float u[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[0][e] += a0 * u[e], acc[1][e] += a1 * u[e], acc[2][e] += a2 * u[e];
+    }
+    bf16_t* zp = dz + ((size_t)(r)) * 9 * N + (size_t)(ty * 3) * N + c8 * 8;  // r = (b h + qy) w + qx
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        *reinterpret_cast<uint4*>(zp + (size_t)t * N) = make_uint4(pack2bf(acc[t][0], acc[t][1]), pack2bf(acc[t][2], acc[t][3]),
+                                                                   pack2bf(acc[t][4], acc[t][5]), pack2bf(acc[t][6], acc[t][7]));
+}
+
 }  // namespace
 
 extern "C" int isp_conv3x3_of_bilinear_supported(int h, int w, int H, int W, int N, int z_dtype) {
@@ -449,4 +542,25 @@ extern "C" int isp_conv3x3_of_bilinear_blend(const void* z, int z_dtype, const f
         if (out_dtype == ISP_F32) return launch<float, ISP_F32>(z, bias, out, B, h, w, H, W, N, relu, s);
     }
     return ISP_ERR_UNSUPPORTED;
+}
+
+extern "C" long isp_conv3x3_of_bilinear_bwd_workspace_bytes(int B, int h, int W, int N) {
+    if (B <= 0 || h <= 0 || W <= 0 || N <= 0) return ISP_ERR_INVALID;
+    return (long)B * h * 3 * W * N * 4;
+}
+
+extern "C" int isp_conv3x3_of_bilinear_blend_bwd(const void* g_bf16, void* dz_bf16, void* workspace, int B, int h, int w, int H,
+                                                 int W, int N, void* stream) {
+    ISP_CHECK_ARG(g_bf16 && dz_bf16 && workspace && B > 0 && B <= 65535 && h > 0 && h <= 65535 && w > 0 && H > 0 && W > 0 && N > 0 && N % 8 == 0);
+    ISP_CHECK_ARG(((uintptr_t)g_bf16 & 15) == 0 && ((uintptr_t)dz_bf16 & 15) == 0 && ((uintptr_t)workspace & 15) == 0);
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    hipStream_t s = (hipStream_t)stream;
+    const long cols = (long)W * (N / 8);
+    conv_bilinear_adj_y_kernel<<<dim3((unsigned)((cols + 255) / 256), h, B), 256, 0, s>>>((const bf16_t*)g_bf16, (float*)workspace, h,
+                                                                                         H, W, N, sy);
+    const long total = (long)B * h * w * 3 * (N / 8);
+    conv_bilinear_adj_x_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((const float*)workspace, (bf16_t*)dz_bf16, h, w, W, N, sx,
+                                                                              total);
+    return isp_launch_status();
 }

@@ -331,6 +331,22 @@ def conv3x3_of_bilinear_blend(z, bias, B, h, w, H, W, N, relu=True, out_dtype=F1
 
 
 
+def conv3x3_of_bilinear_blend_bwd(g, B, h, w, H, W, N):
+    """Adjoint of ``conv3x3_of_bilinear_blend`` w.r.t. the tap planes (training): g [B,H,W,N] bf16 pre-activation gradient
+    (ReLU mask applied) -> dz [B*h*w, 9*N] bf16."""
+    _need(g, BF16, "g")
+    if tuple(g.shape) != (B, H, W, N):
+        raise IspError(f"conv3x3_of_bilinear_blend_bwd: g must be [{B}, {H}, {W}, {N}], got {tuple(g.shape)}")
+    need = _lib.lib().isp_conv3x3_of_bilinear_bwd_workspace_bytes(B, h, W, N)
+    if need < 0:
+        check(int(need), "isp_conv3x3_of_bilinear_bwd_workspace_bytes")
+    ws = torch.empty(need, device=g.device, dtype=torch.uint8)
+    dz = torch.empty(B * h * w, 9 * N, device=g.device, dtype=BF16)
+    check(_lib.lib().isp_conv3x3_of_bilinear_blend_bwd(_p(g), _p(dz), _p(ws), B, h, w, H, W, N, _stream()),
+          "isp_conv3x3_of_bilinear_blend_bwd")
+    return dz
+
+
 def layernorm(x, gamma, beta, eps, out_dtype=BF16, group_out=0, skip=0, rows_out=None, D=None, ld_out=None):
     """LayerNorm over the first D columns of a [rows, ld] f32/bf16/f16 tensor (D defaults to ld); the
     output (f32, bf16, or f16) has row stride ld_out (default D) with columns [D, ld_out) zero-filled."""

@@ -583,3 +583,41 @@ def test_before_backbone_gradients_with_oracle_relu_masks(upsampler):
         worst[k] = (rms, cos)
     assert all(r <= 2e-2 for r, _ in worst.values()), worst
     assert all(c > 0.9997 for _, c in worst.values()), worst
+
+
+@pytest.mark.parametrize("B,h,w,H,W,C,N", [(2, 8, 8, 112, 112, 64, 64), (1, 16, 12, 224, 168, 128, 192), (2, 4, 5, 56, 70, 64, 128)])
+def test_conv3x3_of_bilinear_autograd_vs_materialised(B, h, w, H, W, C, N):
+    """Conv3x3OfBilinearReluFn (first head conv taken through the bilinear resize, forward and backward) against the
+    materialised route under the SAME ReLU mask: resize (ResizeBilinearFn) + Conv3x3ReluFn.  Output and the gradients of the
+    low-resolution features, the weight and the bias agree to the operand rounding of the 16-bit kernels."""
+    from isegprobe_amd import hip_ops as ops
+    from isegprobe_amd.core.model._autograd import Conv3x3OfBilinearReluFn, Conv3x3ReluFn, ResizeBilinearFn, impose_relu_masks
+    torch.manual_seed(h * W + N)
+    x0 = torch.randn(B, h, w, C, device="cuda").to(torch.bfloat16)
+    w0 = (torch.randn(N, C, 3, 3, device="cuda") / (9 * C) ** 0.5)
+    b0 = torch.randn(N, device="cuda") * 0.1
+    gy = torch.randn(B, H, W, N, device="cuda").to(torch.bfloat16)
+
+    def run(route, mask=None):
+        x = x0.clone().requires_grad_(True)
+        wt = w0.clone().requires_grad_(True)
+        bs = b0.clone().requires_grad_(True)
+        import contextlib
+        with (impose_relu_masks([mask]) if mask is not None else contextlib.nullcontext()):
+            if route == "through":
+                y = Conv3x3OfBilinearReluFn.apply(x, wt, bs, H, W)
+            else:
+                y = Conv3x3ReluFn.apply(ResizeBilinearFn.apply(x, H, W), wt, bs)
+            y.backward(gy)
+        return y.detach().float(), x.grad.float(), wt.grad.float(), bs.grad.float()
+    y1, dx1, dw1, db1 = run("through")
+    mask = (y1 > 0).to(torch.bfloat16)  # both routes differentiate through the same ReLU pattern
+    y1, dx1, dw1, db1 = run("through", mask)
+    y2, dx2, dw2, db2 = run("materialised", mask)
+
+    def rel(a, b):
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-12)).item()
+    assert (y1 - y2).abs().max().item() < 3e-2 and rel(y1, y2) < 1e-2
+    assert rel(dx1, dx2) < 2e-2, rel(dx1, dx2)
+    assert rel(dw1, dw2) < 2e-2, rel(dw1, dw2)
+    assert rel(db1, db2) < 1e-2, rel(db1, db2)
